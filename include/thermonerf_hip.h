@@ -1,0 +1,234 @@
+/*
+ * thermonerf_hip.h — C-ABI of libthermonerf_hip.so: the MI355X (gfx950) drop-in for ThermoNeRF's
+ * volumetric-rendering hot path.
+ *
+ * The reference is 100 % Python (a nerfstudio plugin) and has no FFI of its own; the entry points below are
+ * what a ctypes binding placed behind the reference's plugin surface binds (INTEGRATION.md shows the stub).
+ * Each entry point cites the reference interface it replaces:
+ *   REF = /root/reference/thermo_nerf/...        NS = nerfstudio 1.1.5 symbol invoked from that REF line.
+ *
+ * Conventions
+ *   - every pointer named  *_dev / inside the structs  is a DEVICE pointer to contiguous row-major fp32
+ *     (int32 where stated); the caller (PyTorch-ROCm) owns every buffer; nothing is allocated or freed here.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the device is never synchronised.
+ *   - return value: TN_OK or a negative TN_ERR_* code; no exceptions cross the boundary.
+ *   - re-entrant across devices/streams: the library keeps no mutable global state.
+ *   - `training` != 0 selects nerfstudio's train-mode semantics (no nan_to_num / clamp in the renderers).
+ */
+#ifndef THERMONERF_HIP_H
+#define THERMONERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TN_OK 0
+#define TN_ERR_NULL (-1)        /* a required pointer is NULL                           */
+#define TN_ERR_SHAPE (-2)       /* a dimension is out of the supported range            */
+#define TN_ERR_UNSUPPORTED (-3) /* configuration not implemented by the kernels         */
+#define TN_ERR_WORKSPACE (-4)   /* workspace too small (see tn_render_workspace_bytes)  */
+#define TN_ERR_LAUNCH (-5)      /* hipGetLastError() != hipSuccess after a launch       */
+
+#define TN_MAX_LEVELS 16
+
+/* NS HashEncoding (torch path): table [L*T, 2], per-level scalings taken from the module's `scalings`
+ * buffer (never recomputed here — SURVEY.md §8c). Built at REF thermal_nerf/thermal_field.py:62-88 (main
+ * field, via NerfactoField) and REF thermal_nerf/thermal_nerf_model.py:136-149 (proposal nets). */
+typedef struct tn_hashgrid {
+    const float *table;            /* [num_levels << log2_hashmap_size, 2]                         */
+    float scalings[TN_MAX_LEVELS]; /* HashEncoding.scalings                                        */
+    int32_t num_levels;            /* 1..16                                                        */
+    int32_t log2_hashmap_size;     /* 1..24                                                        */
+    /* optional re-laid ("dense") copy of the coarse levels produced by tn_hashgrid_prepare: for level
+     * l < num_dense_levels, dense + dense_offset[l] holds a [(res+2)^3, 2] x-major / z-fastest grid with
+     * dense[x][y][z] = table[hash(x,y,z)] — a pure layout change, results are bit-identical.        */
+    const float *dense;
+    int64_t dense_offset[TN_MAX_LEVELS]; /* in float2 elements                                      */
+    int32_t dense_res[TN_MAX_LEVELS];    /* grid side (= scalings[l] + 2)                           */
+    int32_t num_dense_levels;
+    int32_t _pad;
+} tn_hashgrid;
+
+/* torch.nn.Linear: weight [out_dim, in_dim], bias [out_dim]. */
+typedef struct tn_linear {
+    const float *weight;
+    const float *bias;
+    int32_t in_dim;
+    int32_t out_dim;
+} tn_linear;
+
+/* Position normalisation shared by both density fields (NS NerfactoField.get_density /
+ * HashMLPDensityField.get_density): contraction != 0 -> SceneContraction(order=inf) then (x+2)/4
+ * [REF thermal_nerf_model.py:91-94]; else (x - aabb_min) / (aabb_max - aabb_min). */
+typedef struct tn_space {
+    int32_t contraction;
+    float aabb_min[3];
+    float aabb_max[3];
+    int32_t _pad;
+} tn_space;
+
+/* NS HashMLPDensityField(num_layers=2, hidden_dim=16, use_linear=False), REF thermal_nerf_model.py:140-149. */
+typedef struct tn_density_field {
+    tn_hashgrid grid;
+    tn_linear l0; /* [hidden, 2*L] + ReLU */
+    tn_linear l1; /* [1, hidden]          */
+    tn_space space;
+    float average_init_density; /* 1.0 */
+    int32_t _pad;
+} tn_density_field;
+
+/* ThermalNerfactoTField, REF thermal_nerf/thermal_field.py:33-201 (NerfactoField base + thermal branch). */
+typedef struct tn_thermal_field {
+    tn_hashgrid grid;
+    tn_linear base0;  /* mlp_base.mlp.layers.0  [64, 32]  ReLU                    */
+    tn_linear base1;  /* mlp_base.mlp.layers.1  [1+geo, 64]                        */
+    tn_linear head0;  /* mlp_head.layers.0      [64, 16+geo+app] ReLU              */
+    tn_linear head1;  /* mlp_head.layers.1      [64, 64] ReLU                      */
+    tn_linear head2;  /* mlp_head.layers.2      [3, 64]  Sigmoid                   */
+    tn_linear th0;    /* mlp_thermal.layers.0   [64, geo] ReLU          REF :90-98 */
+    tn_linear th1;    /* mlp_thermal.layers.1   [64, 64] Sigmoid        REF :90-98 */
+    tn_linear thead;  /* field_head_thermal.net [1, 64] no activation   REF :100-102, thermal_field_head.py:50-51 */
+    const float *appearance; /* embedding_appearance.embedding.weight [num_images, app_dim]        */
+    int32_t num_images;
+    int32_t app_dim;       /* 32 */
+    int32_t geo_feat_dim;  /* 15 */
+    int32_t use_average_appearance; /* eval: mean(embedding) if != 0 else zeros   REF :128-137 */
+    int32_t sh_shifted;    /* 1: SH evaluated on (d+1)/2 (torch fallback), 0: on d */
+    tn_space space;
+    float average_init_density; /* 1.0, REF thermal_field.py:86 */
+    /* optional blob produced by tn_field_prepare (MFMA-fragment-ordered MLP weights); NULL = raw path */
+    const float *prepared;
+} tn_thermal_field;
+
+/* ------------------------------------------------------------------------------------------------------
+ * Per-sample entry points (the Field plugin surface)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* NS Frustums.get_positions: pos = origins + directions * (starts + ends) / 2.
+ * origins/directions [R,3]; starts/ends [R,n]; positions out [R,n,3]. */
+int tn_frustum_positions(const float *origins, const float *directions, const float *starts, const float *ends,
+                         int64_t num_rays, int32_t n, float *positions, void *stream);
+
+/* HashMLPDensityField.density_fn(positions) [REF thermal_nerf_model.py:146-149,222-224]:
+ * positions [N,3] -> density [N]. */
+int tn_density_fwd(const tn_density_field *field, const float *positions, int64_t n, float *density, void *stream);
+
+/* NerfactoField.get_density as used by ThermalNerfactoTField.forward [REF thermal_field.py:186-190]:
+ * positions [N,3] -> density [N], geo embedding [N, geo_feat_dim]. */
+int tn_field_density_fwd(const tn_thermal_field *field, const float *positions, int64_t n, float *density,
+                         float *geo, void *stream);
+
+/* ThermalNerfactoTField.get_outputs [REF thermal_field.py:108-181]:
+ * directions [N,3] (un-normalised to [0,1]; the kernel applies (d+1)/2), geo [N,geo], camera_indices [N] int32
+ * (only read when training != 0) -> rgb [N,3], thermal [N]. */
+int tn_field_heads_fwd(const tn_thermal_field *field, const float *directions, const float *geo,
+                       const int32_t *camera_indices, int64_t n, int32_t training, float *rgb, float *thermal,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Samplers and weights (NS ray_samplers.py / RaySamples.get_weights, invoked at
+ * REF thermal_nerf_model.py:172-179,222-224,233)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* UniformLinDispPiecewiseSampler: spacing bins [n+1] (= torch.linspace(0,1,n+1), host-computed, device
+ * resident) (+ optional per-ray stratified jitter t_rand [R], NULL in eval) -> spacing_bins [R,n+1],
+ * euclidean bins [R,n+1]. nears/fars [R]. */
+int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *nears, const float *fars,
+                      int64_t num_rays, int32_t n, float *spacing_bins, float *eucl_bins, void *stream);
+
+/* RaySamples.get_weights: deltas [R,n], densities [R,n] -> weights [R,n]. */
+int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays, int32_t n, float *weights,
+                   void *stream);
+
+/* PDFSampler.generate_ray_samples (histogram_padding 0.01, eps 1e-5): weights [R,n_in] (already annealed),
+ * existing spacing bins [R,n_in+1], u [n_out+1] (host-computed eval positions) or u_rand [R] jitter (training;
+ * NULL in eval), nears/fars [R] -> spacing_bins [R,n_out+1], eucl_bins [R,n_out+1]. */
+int tn_sample_pdf(const float *weights, const float *existing_bins, const float *u, const float *u_rand,
+                  const float *nears, const float *fars, int64_t num_rays, int32_t n_in, int32_t n_out,
+                  float *spacing_bins, float *eucl_bins, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Renderers
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* ThermalRenderer.forward [REF thermal_renderer.py:113-149] and NS RGBRenderer(background "last_sample")
+ * [witness REF rgb_concat/rgbt_renderer.py:62-81,159-174]: values [R,n,C], weights [R,n] -> out [R,C]
+ * = sum_s w*v + v[last]*(1 - sum_s w); eval (training == 0): nan_to_num(values) first, clamp [0,1] last. */
+int tn_composite_fwd(const float *values, const float *weights, int64_t num_rays, int32_t n, int32_t channels,
+                     int32_t training, float *out, void *stream);
+
+/* NS AccumulationRenderer + DepthRenderer("median") + DepthRenderer("expected") in one pass
+ * [REF thermal_nerf_model.py:238-243,267-270]. weights/starts/ends [R,n]; any output may be NULL.
+ * expected depth is clipped to the call-global [min(steps), max(steps)] exactly as the reference does;
+ * `minmax_scratch` = 2 floats of device scratch (required when expected != NULL). */
+int tn_depth_fwd(const float *weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
+                 float *accumulation, float *median, float *expected, float *minmax_scratch, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused forward: Model.forward (collider) + ThermalNerfModel.get_outputs
+ * [REF thermal_nerf_model.py:210-275]
+ * ---------------------------------------------------------------------------------------------------- */
+
+typedef struct tn_render_config {
+    int32_t num_proposal_samples[2]; /* (256, 96)                     */
+    int32_t num_nerf_samples;        /* 48 | 64 | 192 ... (<= 256)    */
+    int32_t training;                /* eval == 0                     */
+    float pdf_anneal;                /* ProposalNetworkSampler._anneal (1.0 at inference) */
+    int32_t _pad;
+} tn_render_config;
+
+typedef struct tn_render_inputs {
+    const float *origins;            /* [R,3] */
+    const float *directions;         /* [R,3] */
+    const float *nears;              /* [R]   (collider output) */
+    const float *fars;               /* [R]   */
+    const int32_t *camera_indices;   /* [R] or NULL (eval) */
+    const float *lin_bins0;          /* [P0+1] torch.linspace(0,1,P0+1) */
+    const float *u1;                 /* [P1+1] PDFSampler eval positions for level 1 */
+    const float *u2;                 /* [S+1]  PDFSampler eval positions for the final level */
+    const float *jitter;             /* [3,R] per-level single-jitter draws (training) or NULL */
+} tn_render_inputs;
+
+typedef struct tn_render_outputs {
+    float *rgb;            /* [R,3] */
+    float *accumulation;   /* [R]   */
+    float *depth;          /* [R]   median */
+    float *expected_depth; /* [R]   */
+    float *prop_depth_0;   /* [R]   */
+    float *prop_depth_1;   /* [R]   */
+    float *thermal;        /* [R]   */
+    /* optional (training / debugging): per-level weights and spacing/euclidean bins; NULL to skip */
+    float *weights[3];       /* [R,P0], [R,P1], [R,S]       */
+    float *spacing_bins[3];  /* [R,P0+1], [R,P1+1], [R,S+1] */
+    float *eucl_bins[3];     /* same shapes                  */
+} tn_render_outputs;
+
+size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays);
+
+int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_thermal_field *field,
+                       const tn_render_config *cfg, const tn_render_inputs *in, const tn_render_outputs *out,
+                       int64_t num_rays, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Weight preparation (layout-only transforms, run once per weight update)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* dense re-layout of the coarse hash levels; fills grid_out->dense* fields (grid_out may alias grid_in). */
+size_t tn_hashgrid_prepare_bytes(const tn_hashgrid *grid, int64_t max_bytes);
+int tn_hashgrid_prepare(const tn_hashgrid *grid_in, tn_hashgrid *grid_out, void *dense_dev, size_t dense_bytes,
+                        void *stream);
+
+/* MFMA-fragment-ordered copy of the main field's MLP weights. */
+size_t tn_field_prepare_bytes(const tn_thermal_field *field);
+int tn_field_prepare(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
+
+/* library identification: returns a static string "thermonerf_hip <version> gfx950". */
+const char *tn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THERMONERF_HIP_H */

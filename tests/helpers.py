@@ -1,0 +1,46 @@
+"""Shared test plumbing: build a model + the matching oracle config / CPU state dict."""
+from __future__ import annotations
+
+import functools
+from typing import Dict, Tuple
+
+import torch
+
+from oracle import hotpath as H
+from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+
+# a reduced configuration (small tables) keeps CPU-side construction fast; structure is unchanged
+SMALL = dict(log2_hashmap_size=15, num_levels=16, max_res=2048,
+             proposal_net_args_list=[
+                 {"hidden_dim": 16, "log2_hashmap_size": 13, "num_levels": 5, "max_res": 128, "use_linear": False},
+                 {"hidden_dim": 16, "log2_hashmap_size": 13, "num_levels": 5, "max_res": 256, "use_linear": False}])
+
+
+def oracle_config(cfg: ThermalNerfModelConfig) -> H.OracleConfig:
+    return H.OracleConfig(
+        num_levels=cfg.num_levels, base_res=cfg.base_res, max_res=cfg.max_res,
+        log2_hashmap_size=cfg.log2_hashmap_size, features_per_level=cfg.features_per_level,
+        hidden_dim=cfg.hidden_dim, appearance_embed_dim=cfg.appearance_embed_dim,
+        proposal_net_args_list=[dict(a, base_res=16) for a in cfg.proposal_net_args_list],
+        num_proposal_samples_per_ray=tuple(cfg.num_proposal_samples_per_ray),
+        num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+        use_average_appearance_embedding=cfg.use_average_appearance_embedding,
+        disable_scene_contraction=cfg.disable_scene_contraction, sh_input=cfg.sh_input,
+    )
+
+
+@functools.lru_cache(maxsize=8)
+def build(kind: str = "stress", S: int = 48, small: bool = True, num_images: int = 8, **over):
+    """Returns (cpu_model, cpu_state_dict, oracle_cfg).  Cached: treat the results as read-only."""
+    kw = dict(SMALL) if small else {}
+    kw.update(over)
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, **kw)
+    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=num_images)
+    synthetic.fill_model_(model, kind)
+    model.eval()
+    return model, synthetic.model_state_dict_cpu(model), oracle_config(cfg)
+
+
+def rays(h: int = 16, w: int = 16, view: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    o, d, _ = synthetic.orbit_camera_rays(h, w, view=view)
+    return o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()

@@ -1,0 +1,330 @@
+"""GPU parity: every HIP entry point (through the C-ABI, via the plugin-surface classes) against the CPU oracle
+on identical seeded inputs.  Tolerances (fp32): RGB pixel MAE <= 1e-4 of [0,1]; thermal <= 1e-4 of
+the normalised range (x (Tmax-Tmin) in degrees); depths <= 1e-4 relative; per-sample tensors max-abs 2e-5.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hotpath as H
+from tests import helpers
+from thermo_nerf_amd import (FieldHeadNames, FieldHeadNamesT, Frustums, RayBundle, RaySamples, ThermalRenderer,
+                             synthetic)
+from thermo_nerf_amd.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+from thermo_nerf_amd.samplers import PDFSampler, UniformLinDispPiecewiseSampler
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+RGB_MAE = 1e-4
+THERMAL_MAE = 1e-4
+DEPTH_REL = 1e-4
+
+
+def gpu_model(kind="stress", S=48, small=True, **over):
+    model, sd, ocfg = helpers.build(kind, S, small, **over)
+    return copy.deepcopy(model).to(DEV).eval(), sd, ocfg
+
+
+def bundle(o, d, cam=None):
+    return RayBundle(origins=o.to(DEV), directions=d.to(DEV),
+                     camera_indices=None if cam is None else cam.to(DEV))
+
+
+def assert_close(got, want, atol, rtol=0.0, name=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = (got - want).abs()
+    lim = atol + rtol * want.abs()
+    assert bool((err <= lim).all()), f"{name}: max err {err.max().item():.3e} (limit {atol}+{rtol}*|x|)"
+
+
+# --------------------------------------------------------------------------------------------------
+# samplers / weights
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("near", [0.0, 0.05])
+@pytest.mark.parametrize("n", [256, 96, 7])
+def test_sample_initial(near, n):
+    R = 37
+    o, d = helpers.rays(8, 8)
+    o, d = o[:R], d[:R]
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), 1000.0)
+    want = H.sample_initial(nears, fars, n, None)
+    rb = bundle(o, d)
+    rb.nears, rb.fars = nears.to(DEV), fars.to(DEV)
+    s = UniformLinDispPiecewiseSampler().eval()
+    rs = s(rb, num_samples=n)
+    assert_close(rs.frustums.starts, want.starts, 0, 2e-7, "starts")
+    assert_close(rs.frustums.ends, want.ends, 0, 2e-7, "ends")
+    assert_close(rs.spacing_starts, want.spacing_starts, 0, 0, "spacing")
+    # training: single jitter supplied explicitly
+    t = torch.rand(R, 1, generator=torch.Generator().manual_seed(3))
+    want = H.sample_initial(nears, fars, n, t)
+    s.train()
+    rs = s(rb, num_samples=n, t_rand=t.to(DEV))
+    assert_close(rs.frustums.ends, want.ends, 0, 5e-7, "ends(train)")
+    assert_close(rs.spacing_ends, want.spacing_ends, 1e-7, 0, "spacing(train)")
+
+
+@pytest.mark.parametrize("n", [48, 64, 192, 256, 5])
+def test_get_weights(n):
+    g = torch.Generator().manual_seed(n)
+    R = 33
+    deltas = torch.rand(R, n, 1, generator=g) * 0.1
+    dens = torch.exp(torch.randn(R, n, 1, generator=g) * 3)
+    dens[0] = 0.0
+    dens[1] = float("inf")  # alpha*T = nan -> nan_to_num
+    want = H.get_weights(deltas, dens)
+    fr = Frustums(origins=torch.zeros(R, n, 3, device=DEV), directions=torch.zeros(R, n, 3, device=DEV),
+                  starts=torch.zeros(R, n, 1, device=DEV), ends=deltas.to(DEV))
+    rs = RaySamples(frustums=fr, deltas=deltas.to(DEV))
+    got = rs.get_weights(dens.to(DEV))
+    assert_close(got, want, 2e-6, 1e-5, "weights")
+
+
+@pytest.mark.parametrize("n_in,n_out", [(256, 96), (96, 48), (96, 64), (96, 192), (64, 300)])
+def test_sample_pdf(n_in, n_out):
+    g = torch.Generator().manual_seed(n_in * 1000 + n_out)
+    R = 29
+    nears, fars = torch.zeros(R, 1), torch.full((R, 1), 1000.0)
+    prev = H.sample_initial(nears, fars, n_in, None)
+    w = torch.rand(R, n_in, 1, generator=g) ** 6
+    w[0] = 0.0  # all-zero weights -> uniform resample through the histogram padding
+    w[1] = 0.0
+    w[1, n_in // 2] = 1.0  # a spike
+    want = H.sample_pdf(prev, w, n_out, None)
+    o, d = helpers.rays(8, 8)
+    rb = bundle(o[:R], d[:R])
+    rb.nears, rb.fars = nears.to(DEV), fars.to(DEV)
+    rs0 = UniformLinDispPiecewiseSampler().eval()(rb, num_samples=n_in)
+    sampler = PDFSampler(single_jitter=True).eval()
+    rs = sampler(rb, rs0, w.to(DEV), num_samples=n_out)
+    assert_close(rs.spacing_starts, want.spacing_starts, 2e-6, 0, "pdf spacing")
+    assert_close(rs.frustums.ends, want.ends, 1e-6, 2e-5, "pdf ends")
+    # training jitter
+    u = torch.rand(R, 1, generator=g)
+    want = H.sample_pdf(prev, w, n_out, u)
+    sampler.train()
+    rs = sampler(rb, rs0, w.to(DEV), num_samples=n_out, u_rand=u.to(DEV))
+    assert_close(rs.spacing_ends, want.spacing_ends, 2e-6, 0, "pdf spacing (train)")
+
+
+# --------------------------------------------------------------------------------------------------
+# renderers
+# --------------------------------------------------------------------------------------------------
+def test_thermal_renderer_golden_g1(golden_dir):
+    """Against outputs of the REAL reference ThermalRenderer (fixture G1)."""
+    g = np.load(os.path.join(golden_dir, "thermal_renderer.npz"))
+    th, w = torch.from_numpy(g["thermal"]).to(DEV), torch.from_numpy(g["weights"]).to(DEV)
+    r = ThermalRenderer()
+    r.eval()
+    assert_close(r(th, w), torch.from_numpy(g["out_eval"]), 2e-6, 0, "thermal eval")
+    r.train()
+    got = r(th, w).cpu().numpy()
+    want = g["out_train"]
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("n", [48, 64, 192, 3])
+def test_rgb_depth_accumulation(n):
+    g = torch.Generator().manual_seed(77 + n)
+    R = 41
+    rgb = torch.rand(R, n, 3, generator=g)
+    rgb[2, 1, 0] = float("nan")
+    w = torch.rand(R, n, 1, generator=g)
+    w = w / w.sum(1, keepdim=True) * torch.rand(R, 1, 1, generator=g) * 1.2
+    w[0] = 0.0
+    edges = torch.sort(torch.rand(R, n + 1, generator=g) * 5, dim=-1).values
+    starts, ends = edges[:, :-1, None], edges[:, 1:, None]
+    for training in (False, True):
+        r = RGBRenderer().train(training)
+        want = H.render_rgb(rgb, w, training)
+        got = r(rgb.to(DEV), w.to(DEV)).cpu()
+        m = torch.isfinite(want)
+        assert bool((torch.isnan(got) == torch.isnan(want)).all())
+        assert_close(got[m], want[m], 2e-6, 0, f"rgb train={training}")
+    fr = Frustums(origins=torch.zeros(R, n, 3, device=DEV), directions=torch.zeros(R, n, 3, device=DEV),
+                  starts=starts.to(DEV), ends=ends.to(DEV))
+    rs = RaySamples(frustums=fr)
+    assert_close(AccumulationRenderer()(w.to(DEV)), H.render_accumulation(w), 2e-6, 0, "acc")
+    assert_close(DepthRenderer("expected")(w.to(DEV), rs), H.render_depth_expected(w, starts, ends), 1e-6, 1e-5, "exp depth")
+    got = DepthRenderer("median")(w.to(DEV), rs).cpu()
+    want = H.render_depth_median(w, starts, ends)
+    # a cumulative weight within rounding of 0.5 may pick the neighbouring sample: allow isolated flips
+    bad = ((got - want).abs() > 1e-6).float().mean().item()
+    assert bad <= 0.05, f"median depth mismatch fraction {bad}"
+
+
+# --------------------------------------------------------------------------------------------------
+# fields (per-sample)
+# --------------------------------------------------------------------------------------------------
+def sample_positions(n, seed=5):
+    """positions covering inside (|x|<1), the contracted shell and far away"""
+    p = (synthetic.counter_uniform(n * 3, seed).view(n, 3) * 2 - 1)
+    scale = torch.tensor([0.5, 1.0, 3.0, 50.0])[torch.arange(n) % 4][:, None]
+    p = p * scale
+    p[0] = torch.tensor([0.0, 0.0, 0.0])
+    p[1] = torch.tensor([1.0, 0.25, -0.5])  # on the contraction boundary
+    return p.contiguous()
+
+
+@pytest.mark.parametrize("kind", ["init", "stress"])
+@pytest.mark.parametrize("dense_mb", [0, 64])
+def test_proposal_density_fn(kind, dense_mb):
+    gm, sd, ocfg = gpu_model(kind, 48)
+    pos = sample_positions(4099)
+    for lvl in (0, 1):
+        gm.proposal_networks[lvl].dense_budget_bytes = dense_mb << 20
+        want = H.proposal_density(sd, lvl, pos, ocfg)
+        got = gm.proposal_networks[lvl].density_fn(pos.to(DEV))
+        assert_close(got, want, 1e-6, 2e-5, f"prop density {lvl}")
+
+
+@pytest.mark.parametrize("kind", ["init", "stress"])
+@pytest.mark.parametrize("dense_mb", [0, 64])
+def test_field_density_and_heads(kind, dense_mb):
+    gm, sd, ocfg = gpu_model(kind, 48)
+    gm.field.dense_budget_bytes = dense_mb << 20
+    n = 2053
+    pos = sample_positions(n, seed=9)
+    want_density, want_geo = H.field_density(sd, pos, ocfg)
+    got_density, got_geo = gm.field.density_at(pos.to(DEV))
+    assert_close(got_density, want_density, 1e-6, 3e-5, "density")
+    assert_close(got_geo, want_geo, 2e-5, 2e-5, "geo")
+    dirs = synthetic.counter_uniform(n * 3, 21).view(n, 3) * 2 - 1
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    cam = (synthetic.counter_uniform(n, 22) * 8).long().clamp(0, 7)[:, None]
+    for training in (False, True):
+        want_rgb, want_th = H.field_outputs(sd, dirs, want_geo, cam, ocfg, training)
+        fr = Frustums(origins=pos.to(DEV)[:, None, :], directions=dirs.to(DEV)[:, None, :],
+                      starts=torch.zeros(n, 1, 1, device=DEV), ends=torch.zeros(n, 1, 1, device=DEV))
+        rs = RaySamples(frustums=fr, camera_indices=cam.to(DEV)[:, None, :])
+        gm.field.train(training)
+        out = gm.field.get_outputs(rs, density_embedding=want_geo.to(DEV)[:, None, :])
+        assert_close(out[FieldHeadNames.RGB][:, 0], want_rgb, 2e-6, 0, f"rgb train={training}")
+        assert_close(out[FieldHeadNamesT.THERMAL][:, 0], want_th, 5e-6, 0, f"thermal train={training}")
+    gm.field.eval()
+
+
+def test_field_requires_camera_indices():
+    gm, _, _ = gpu_model("init", 48)
+    fr = Frustums(origins=torch.zeros(4, 1, 3, device=DEV), directions=torch.ones(4, 1, 3, device=DEV),
+                  starts=torch.zeros(4, 1, 1, device=DEV), ends=torch.zeros(4, 1, 1, device=DEV))
+    with pytest.raises(AttributeError, match="Camera indices"):
+        gm.field.get_outputs(RaySamples(frustums=fr, camera_indices=None), density_embedding=torch.zeros(4, 1, 15, device=DEV))
+
+
+# --------------------------------------------------------------------------------------------------
+# whole model
+# --------------------------------------------------------------------------------------------------
+def check_outputs(got, want, tag):
+    rgb_mae = (got["rgb"].cpu() - want["rgb"]).abs().mean().item()
+    th_mae = (got["thermal"].cpu() - want["thermal"]).abs().mean().item()
+    assert rgb_mae <= RGB_MAE, f"{tag}: rgb MAE {rgb_mae:.3e}"
+    assert th_mae <= THERMAL_MAE, f"{tag}: thermal MAE {th_mae:.3e}"
+    assert (got["rgb"].cpu() - want["rgb"]).abs().max().item() <= 20 * RGB_MAE, f"{tag}: rgb max"
+    assert_close(got["accumulation"], want["accumulation"], 2e-5, 0, f"{tag}: accumulation")
+    assert_close(got["expected_depth"], want["expected_depth"], 1e-6, DEPTH_REL, f"{tag}: expected_depth")
+    for k in ("depth", "prop_depth_0", "prop_depth_1"):
+        rel = ((got[k].cpu() - want[k]).abs() / want[k].abs().clamp_min(1e-6))
+        bad = (rel > DEPTH_REL).float().mean().item()
+        assert bad <= 0.02, f"{tag}: {k} mismatch fraction {bad} (median index flips only)"
+    assert set(k for k, v in want.items() if isinstance(v, torch.Tensor)) <= set(got)
+
+
+@pytest.mark.parametrize("kind", ["init", "stress", "scene"])
+@pytest.mark.parametrize("S", [48, 64, 192])
+@pytest.mark.parametrize("fused", [True, False])
+def test_get_outputs_eval(kind, S, fused):
+    gm, sd, ocfg = gpu_model(kind, S)
+    gm.config.fused = fused
+    o, d = helpers.rays(16, 16, view=S % 8)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    for k in ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal"):
+        assert got[k].shape == want[k].shape, k
+    check_outputs(got, want, f"{kind}/S{S}/fused={fused}")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_get_outputs_training_mode(fused):
+    """Train-mode forward: near plane 0.05, per-camera appearance, stratified jitter, no nan_to_num/clamp."""
+    gm, sd, ocfg = gpu_model("stress", 48)
+    gm.config.fused = fused
+    gm.train()
+    o, d = helpers.rays(12, 12, view=3)
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(11)
+    jit = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    cam = torch.randint(0, 8, (R, 1), generator=g)
+    want = H.get_outputs(sd, o, d, cam, ocfg, training=True, jitter=jit)
+    rb = gm.collider(bundle(o, d, cam))
+    with torch.no_grad():
+        if fused:
+            got = gm._get_outputs_fused(rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+        else:
+            got = gm._get_outputs_modular(rb, jitter=[j.to(DEV) for j in jit])
+    gm.eval()
+    check_outputs(got, want, f"train fused={fused}")
+    assert len(got["weights_list"]) == 3 and len(got["ray_samples_list"]) == 3
+    for i in range(3):
+        assert_close(got["weights_list"][i], want["weights_list"][i], 3e-5, 1e-4, f"weights_list[{i}]")
+        assert_close(got["ray_samples_list"][i].spacing_starts, want["ray_samples_list"][i].spacing_starts, 1e-5, 0,
+                     f"spacing_starts[{i}]")
+
+
+def test_full_size_tables_default_config():
+    """The reference's default sizes (T=2^19 x16, 2^17 x5 x2): exercises 32-bit index paths of the real tables."""
+    gm, sd, ocfg = gpu_model("stress", 64, small=False)
+    o, d = helpers.rays(12, 12, view=5)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    check_outputs(got, want, "full-size")
+
+
+@pytest.mark.parametrize("R", [0, 1, 3, 65, 1000])
+def test_ragged_ray_counts(R):
+    gm, sd, ocfg = gpu_model("stress", 48)
+    o, d = helpers.rays(32, 32, view=1)
+    o, d = o[:R].contiguous(), d[:R].contiguous()
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    assert got["rgb"].shape == (R, 3) and got["thermal"].shape == (R, 1)
+    if R:
+        want = H.get_outputs(sd, o, d, None, ocfg)
+        check_outputs(got, want, f"R={R}")
+
+
+def test_camera_ray_bundle_chunking_matches_single_call():
+    """get_outputs_for_camera_ray_bundle (row-major chunks) == oracle's chunked loop, incl. the per-chunk
+    expected-depth clip."""
+    gm, sd, ocfg = gpu_model("scene", 48)
+    gm.config.eval_num_rays_per_chunk = 100
+    o, d, _ = synthetic.orbit_camera_rays(15, 17, view=2)
+    want = H.get_outputs_for_camera_ray_bundle(sd, o, d, ocfg, chunk=100)
+    got = gm.get_outputs_for_camera_ray_bundle(RayBundle(origins=o, directions=d))
+    assert got["rgb"].shape == (15, 17, 3) and got["thermal"].shape == (15, 17, 1)
+    flat = lambda t: {k: v.reshape(-1, v.shape[-1]) for k, v in t.items()}
+    check_outputs(flat(got), flat(want), "chunked")
+
+
+def test_fused_is_deterministic_and_matches_modular():
+    gm, _, _ = gpu_model("stress", 64)
+    o, d = helpers.rays(24, 24, view=4)
+    with torch.no_grad():
+        gm.config.fused = True
+        a = gm(bundle(o, d))
+        b = gm(bundle(o, d))
+        gm.config.fused = False
+        c = gm(bundle(o, d))
+    for k in ("rgb", "thermal", "accumulation", "expected_depth"):
+        assert torch.equal(a[k], b[k]), f"{k} not deterministic"
+        assert_close(a[k], c[k].cpu(), 2e-5, 1e-4, f"fused vs modular {k}")

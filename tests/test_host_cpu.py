@@ -1,0 +1,96 @@
+"""CPU: host logic, the C-ABI library's exports, and the no-fallback guarantees (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import thermo_nerf_amd as tna
+from thermo_nerf_amd import _hip
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "thermonerf_hip.h")).read()
+    declared = set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no entry points parsed from the header"
+    lib = ctypes.CDLL(_hip.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/thermonerf_hip.h but not exported"
+    assert declared == set(_hip.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    assert b"gfx950" in _hip.load().tn_version()
+
+
+def test_struct_sizes_match_header_layout():
+    # sizes computed from the header's field order (LP64): catches drift between header and ctypes mirror
+    assert ctypes.sizeof(_hip.tn_hashgrid) == 8 + 64 + 4 + 4 + 8 + 128 + 64 + 4 + 4
+    assert ctypes.sizeof(_hip.tn_linear) == 24
+    assert ctypes.sizeof(_hip.tn_space) == 32
+    assert ctypes.sizeof(_hip.tn_density_field) == 288 + 24 + 24 + 32 + 8
+    assert ctypes.sizeof(_hip.tn_render_outputs) == 7 * 8 + 9 * 8
+
+
+def test_model_surface_and_state_dict_names():
+    model, sd, _ = helpers.build("init", 48)
+    for k in ("field.mlp_base.encoder.hash_table", "field.mlp_base.encoder.scalings",
+              "field.mlp_base.mlp.layers.0.weight", "field.mlp_base.mlp.layers.1.bias",
+              "field.embedding_appearance.embedding.weight", "field.mlp_head.layers.2.weight",
+              "field.mlp_thermal.layers.1.weight", "field.field_head_thermal.net.weight",
+              "field.field_head_thermal.net.bias", "proposal_networks.0.mlp_base.encoder.hash_table",
+              "proposal_networks.1.mlp_base.mlp.layers.1.weight", "camera_optimizer.pose_adjustment"):
+        assert k in sd, k
+    assert sd["field.mlp_head.layers.0.weight"].shape == (64, 63)
+    assert sd["field.mlp_thermal.layers.0.weight"].shape == (64, 15)
+    assert sd["field.field_head_thermal.net.weight"].shape == (1, 64)
+    assert set(model.get_param_groups()) == {"proposal_networks", "fields", "camera_opt"}
+    assert tna.RenderedImageModality.THERMAL.value == "thermal"
+    assert tna.FieldHeadNamesT.THERMAL.value == "thermal"
+
+
+def test_thermal_metadata_required():
+    with pytest.raises(ValueError, match="Thermal images not found"):
+        tna.ThermalNerfModel(tna.ThermalNerfModelConfig(**helpers.SMALL), metadata={}, scene_box=tna.SceneBox.unit(),
+                             num_train_data=2)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must raise, never compute: the product has no PyTorch/CPU arithmetic path."""
+    model, _, _ = helpers.build("init", 48)
+    o, d = helpers.rays(4, 4)
+    rb = tna.RayBundle(origins=o, directions=d, camera_indices=torch.zeros(16, 1, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(rb)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tna.ThermalRenderer()(torch.rand(4, 8, 1), torch.rand(4, 8, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.proposal_networks[0].density_fn(torch.rand(5, 3))
+
+
+def test_packed_samples_rejected_like_reference():
+    r = tna.ThermalRenderer()
+    with pytest.raises(NotImplementedError):
+        r(torch.rand(8, 1), torch.rand(8, 1), ray_indices=torch.zeros(8, dtype=torch.long), num_rays=2)
+
+
+def test_collider_eval_resets_near_plane():
+    model, _, _ = helpers.build("init", 48)
+    o, d = helpers.rays(2, 2)
+    rb = model.collider(tna.RayBundle(origins=o, directions=d))
+    assert float(rb.nears.max()) == 0.0 and float(rb.fars.min()) == 1000.0
+    model.collider.train()
+    rb = model.collider(tna.RayBundle(origins=o, directions=d))
+    assert abs(float(rb.nears.max()) - 0.05) < 1e-9
+    model.collider.eval()
+
+
+def test_anneal_schedule():
+    model, _, _ = helpers.build("init", 48)
+    model.set_step(0)
+    assert model.proposal_sampler._anneal == 0.0
+    model.set_step(500)
+    assert abs(model.proposal_sampler._anneal - 10 * 0.5 / (9 * 0.5 + 1)) < 1e-12
+    model.set_step(5000)
+    assert model.proposal_sampler._anneal == 1.0

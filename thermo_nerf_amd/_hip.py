@@ -1,0 +1,232 @@
+"""ctypes binding of ``libthermonerf_hip.so`` (the C-ABI declared in ``include/thermonerf_hip.h``).
+
+This is the only place the package touches the native library.  There is NO fallback: if the shared
+object is missing or a symbol cannot be resolved, importing callers get a ``RuntimeError`` — the product
+path never silently degrades to PyTorch/CPU arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB_NAME = "libthermonerf_hip.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+TN_MAX_LEVELS = 16
+
+TN_OK = 0
+_ERRORS = {
+    -1: "TN_ERR_NULL: a required pointer is NULL",
+    -2: "TN_ERR_SHAPE: a dimension is out of the supported range",
+    -3: "TN_ERR_UNSUPPORTED: configuration not implemented by the kernels",
+    -4: "TN_ERR_WORKSPACE: workspace too small",
+    -5: "TN_ERR_LAUNCH: HIP reported a launch error",
+}
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+class tn_hashgrid(C.Structure):
+    _fields_ = [
+        ("table", C.c_void_p),
+        ("scalings", C.c_float * TN_MAX_LEVELS),
+        ("num_levels", C.c_int32),
+        ("log2_hashmap_size", C.c_int32),
+        ("dense", C.c_void_p),
+        ("dense_offset", C.c_int64 * TN_MAX_LEVELS),
+        ("dense_res", C.c_int32 * TN_MAX_LEVELS),
+        ("num_dense_levels", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class tn_linear(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class tn_space(C.Structure):
+    _fields_ = [
+        ("contraction", C.c_int32),
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+        ("_pad", C.c_int32),
+    ]
+
+
+class tn_density_field(C.Structure):
+    _fields_ = [
+        ("grid", tn_hashgrid),
+        ("l0", tn_linear),
+        ("l1", tn_linear),
+        ("space", tn_space),
+        ("average_init_density", C.c_float),
+        ("_pad", C.c_int32),
+    ]
+
+
+class tn_thermal_field(C.Structure):
+    _fields_ = [
+        ("grid", tn_hashgrid),
+        ("base0", tn_linear),
+        ("base1", tn_linear),
+        ("head0", tn_linear),
+        ("head1", tn_linear),
+        ("head2", tn_linear),
+        ("th0", tn_linear),
+        ("th1", tn_linear),
+        ("thead", tn_linear),
+        ("appearance", C.c_void_p),
+        ("num_images", C.c_int32),
+        ("app_dim", C.c_int32),
+        ("geo_feat_dim", C.c_int32),
+        ("use_average_appearance", C.c_int32),
+        ("sh_shifted", C.c_int32),
+        ("space", tn_space),
+        ("average_init_density", C.c_float),
+        ("prepared", C.c_void_p),
+    ]
+
+
+class tn_render_config(C.Structure):
+    _fields_ = [
+        ("num_proposal_samples", C.c_int32 * 2),
+        ("num_nerf_samples", C.c_int32),
+        ("training", C.c_int32),
+        ("pdf_anneal", C.c_float),
+        ("_pad", C.c_int32),
+    ]
+
+
+class tn_render_inputs(C.Structure):
+    _fields_ = [
+        ("origins", C.c_void_p),
+        ("directions", C.c_void_p),
+        ("nears", C.c_void_p),
+        ("fars", C.c_void_p),
+        ("camera_indices", C.c_void_p),
+        ("lin_bins0", C.c_void_p),
+        ("u1", C.c_void_p),
+        ("u2", C.c_void_p),
+        ("jitter", C.c_void_p),
+    ]
+
+
+class tn_render_outputs(C.Structure):
+    _fields_ = [
+        ("rgb", C.c_void_p),
+        ("accumulation", C.c_void_p),
+        ("depth", C.c_void_p),
+        ("expected_depth", C.c_void_p),
+        ("prop_depth_0", C.c_void_p),
+        ("prop_depth_1", C.c_void_p),
+        ("thermal", C.c_void_p),
+        ("weights", C.c_void_p * 3),
+        ("spacing_bins", C.c_void_p * 3),
+        ("eucl_bins", C.c_void_p * 3),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/thermonerf_hip.h
+_vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+SIGNATURES = {
+    "tn_frustum_positions": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "tn_density_fwd": (C.c_int, [C.POINTER(tn_density_field), _vp, _i64, _vp, _vp]),
+    "tn_field_density_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _i64, _vp, _vp, _vp]),
+    "tn_field_heads_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_sample_initial": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_weights_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "tn_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "tn_composite_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "tn_depth_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tn_render_workspace_bytes": (_sz, [C.POINTER(tn_render_config), _i64]),
+    "tn_render_rays_fwd": (
+        C.c_int,
+        [C.POINTER(tn_density_field), C.POINTER(tn_density_field), C.POINTER(tn_thermal_field),
+         C.POINTER(tn_render_config), C.POINTER(tn_render_inputs), C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
+    ),
+    "tn_hashgrid_prepare_bytes": (_sz, [C.POINTER(tn_hashgrid), _i64]),
+    "tn_hashgrid_prepare": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_hashgrid), _vp, _sz, _vp]),
+    "tn_field_prepare_bytes": (_sz, [C.POINTER(tn_thermal_field)]),
+    "tn_field_prepare": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _sz, _vp]),
+    "tn_version": (C.c_char_p, []),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the shared object and bind every declared symbol.  Raises RuntimeError (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C thermo_nerf_amd/csrc`). thermo_nerf_amd has no CPU/PyTorch fallback for its kernels."
+        )
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise RuntimeError(f"failed to load {_LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{_LIB_NAME} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != TN_OK:
+        raise RuntimeError(f"{what} failed: {_ERRORS.get(code, f'error code {code}')}")
+
+
+def require_device_tensor(t: torch.Tensor, name: str, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """The kernels read raw device pointers: insist on a contiguous ROCm tensor of the right dtype."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}; thermo_nerf_amd runs only on a ROCm device (no CPU fallback exists)."
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_linear(layer: torch.nn.Linear) -> tn_linear:
+    w = require_device_tensor(layer.weight.detach(), "Linear.weight")
+    b = require_device_tensor(layer.bias.detach(), "Linear.bias")
+    return tn_linear(w.data_ptr(), b.data_ptr(), layer.in_features, layer.out_features)
+
+
+def make_space(contraction: bool, aabb: Optional[torch.Tensor]) -> tn_space:
+    s = tn_space()
+    s.contraction = 1 if contraction else 0
+    if aabb is not None:
+        a = aabb.detach().float().cpu()
+        for i in range(3):
+            s.aabb_min[i] = float(a[0, i])
+            s.aabb_max[i] = float(a[1, i])
+    return s

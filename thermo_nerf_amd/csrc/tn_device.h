@@ -1,0 +1,212 @@
+// Device-side building blocks shared by every kernel of libthermonerf_hip (gfx950 / wave64 only).
+//
+// Arithmetic follows the nerfstudio 1.1.5 torch-fallback op order with explicit
+// round-to-nearest mul/add intrinsics wherever the reference rounds twice, so position / hash-grid
+// arithmetic is reproducible against the fp32 CPU oracle irrespective of -ffp-contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/thermonerf_hip.h"
+
+#define TN_WAVE 64
+
+namespace tn {
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+
+// torch.nan_to_num defaults: nan -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX
+__device__ __forceinline__ float nan_to_num(float x) {
+    if (x != x) return 0.0f;
+    if (x == INFINITY) return 3.4028234663852886e38f;
+    if (x == -INFINITY) return -3.4028234663852886e38f;
+    return x;
+}
+
+// ---- NS UniformLinDispPiecewiseSampler spacing functions ---------------------------------
+__device__ __forceinline__ float spacing_fn(float x) { return x < 1.0f ? x / 2.0f : sub_rn(1.0f, 1.0f / mul_rn(2.0f, x)); }
+__device__ __forceinline__ float spacing_fn_inv(float x) {
+    return x < 0.5f ? mul_rn(2.0f, x) : 1.0f / sub_rn(2.0f, mul_rn(2.0f, x));
+}
+// spacing_to_euclidean_fn(x) = s_inv(x * s_far + (1 - x) * s_near)
+__device__ __forceinline__ float spacing_to_eucl(float x, float s_near, float s_far) {
+    return spacing_fn_inv(add_rn(mul_rn(x, s_far), mul_rn(sub_rn(1.0f, x), s_near)));
+}
+
+// ---- NS Frustums.get_positions: o + d * (s + e) / 2 ---------------------------------------------------
+__device__ __forceinline__ float frustum_pos(float o, float d, float s, float e) {
+    return add_rn(o, mul_rn(d, add_rn(s, e)) / 2.0f);
+}
+
+// ---- position normalisation + selector ----------------------------------------------------
+struct Space {
+    int contraction;
+    float mn[3];
+    float mx[3];
+};
+__device__ __forceinline__ Space make_space(const tn_space &s) {
+    Space r;
+    r.contraction = s.contraction;
+    for (int i = 0; i < 3; ++i) {
+        r.mn[i] = s.aabb_min[i];
+        r.mx[i] = s.aabb_max[i];
+    }
+    return r;
+}
+
+// returns selector (0/1) and writes p (already multiplied by the selector) in [0,1]
+__device__ __forceinline__ float normalize_position(const Space &sp, float x, float y, float z, float &px, float &py,
+                                                    float &pz) {
+    if (sp.contraction) {
+        const float mag = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+        if (!(mag < 1.0f)) {
+            const float k = sub_rn(2.0f, 1.0f / mag);
+            x = mul_rn(k, x / mag);
+            y = mul_rn(k, y / mag);
+            z = mul_rn(k, z / mag);
+        }
+        px = add_rn(x, 2.0f) / 4.0f;
+        py = add_rn(y, 2.0f) / 4.0f;
+        pz = add_rn(z, 2.0f) / 4.0f;
+    } else {
+        px = sub_rn(x, sp.mn[0]) / sub_rn(sp.mx[0], sp.mn[0]);
+        py = sub_rn(y, sp.mn[1]) / sub_rn(sp.mx[1], sp.mn[1]);
+        pz = sub_rn(z, sp.mn[2]) / sub_rn(sp.mx[2], sp.mn[2]);
+    }
+    const bool in = (px > 0.0f) && (px < 1.0f) && (py > 0.0f) && (py < 1.0f) && (pz > 0.0f) && (pz < 1.0f);
+    const float sel = in ? 1.0f : 0.0f;
+    px = mul_rn(px, sel);
+    py = mul_rn(py, sel);
+    pz = mul_rn(pz, sel);
+    return sel;
+}
+
+// ---- NS HashEncoding.pytorch_fwd, one level ----------------------------------------------
+// by-value device view of tn_hashgrid
+struct Grid {
+    const float2 *table;
+    const float2 *dense;
+    float scal[TN_MAX_LEVELS];
+    long long dense_off[TN_MAX_LEVELS];
+    int dense_res[TN_MAX_LEVELS];
+    int num_levels;
+    int num_dense;
+    unsigned mask;   // T - 1
+    unsigned tsize;  // T
+};
+
+#define TN_P1 2654435761u
+#define TN_P2 805459861u
+
+__device__ __forceinline__ float lerp_t(float a, float b, float o) {
+    // torch order: a*o + b*(1-o), three roundings
+    return add_rn(mul_rn(a, o), mul_rn(b, sub_rn(1.0f, o)));
+}
+
+template <bool DENSE>
+__device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, float py, float pz) {
+    const float s = g.scal[l];
+    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+    const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+    const float ox = sub_rn(sx, fxf), oy = sub_rn(sy, fyf), oz = sub_rn(sz, fzf);
+    float2 f0, f1, f2, f3, f4, f5, f6, f7;
+    if (DENSE) {
+        // dense[x][y][z] = table[hash(x,y,z)]; ceil corner == floor+1 whenever its weight is non-zero
+        const int res = g.dense_res[l];
+        const float2 *d = g.dense + g.dense_off[l];
+        const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
+        const int i00 = (fx * res + fy) * res + fz;
+        const int i10 = i00 + res * res;  // x+1
+        const int i01 = i00 + res;        // y+1
+        const int i11 = i10 + res;
+        f6 = d[i00];      // (f,f,f)
+        f2 = d[i00 + 1];  // (f,f,c)
+        f7 = d[i01];      // (f,c,f)
+        f3 = d[i01 + 1];  // (f,c,c)
+        f5 = d[i10];      // (c,f,f)
+        f1 = d[i10 + 1];  // (c,f,c)
+        f4 = d[i11];      // (c,c,f)
+        f0 = d[i11 + 1];  // (c,c,c)
+    } else {
+        const unsigned cx = (unsigned)(int)ceilf(sx), cy = (unsigned)(int)ceilf(sy), cz = (unsigned)(int)ceilf(sz);
+        const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
+        const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
+        const float2 *t = g.table + (size_t)l * g.tsize;
+        const unsigned m = g.mask;
+        f0 = t[(cx ^ hcy ^ hcz) & m];
+        f1 = t[(cx ^ hfy ^ hcz) & m];
+        f2 = t[(fx ^ hfy ^ hcz) & m];
+        f3 = t[(fx ^ hcy ^ hcz) & m];
+        f4 = t[(cx ^ hcy ^ hfz) & m];
+        f5 = t[(cx ^ hfy ^ hfz) & m];
+        f6 = t[(fx ^ hfy ^ hfz) & m];
+        f7 = t[(fx ^ hcy ^ hfz) & m];
+    }
+    float2 r;
+    {
+        const float f03 = lerp_t(f0.x, f3.x, ox), f12 = lerp_t(f1.x, f2.x, ox);
+        const float f56 = lerp_t(f5.x, f6.x, ox), f47 = lerp_t(f4.x, f7.x, ox);
+        const float f0312 = lerp_t(f03, f12, oy), f4756 = lerp_t(f47, f56, oy);
+        r.x = lerp_t(f0312, f4756, oz);
+    }
+    {
+        const float f03 = lerp_t(f0.y, f3.y, ox), f12 = lerp_t(f1.y, f2.y, ox);
+        const float f56 = lerp_t(f5.y, f6.y, ox), f47 = lerp_t(f4.y, f7.y, ox);
+        const float f0312 = lerp_t(f03, f12, oy), f4756 = lerp_t(f47, f56, oy);
+        r.y = lerp_t(f0312, f4756, oz);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float2 encode_level_any(const Grid &g, int l, float px, float py, float pz) {
+    if (l < g.num_dense) return encode_level<true>(g, l, px, py, pz);
+    return encode_level<false>(g, l, px, py, pz);
+}
+
+// ---- wave64 collectives ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+}  // namespace tn
+
+// host-side conversion of the C-ABI grid struct into the by-value kernel argument
+static inline tn::Grid tn_make_grid(const tn_hashgrid &h) {
+    tn::Grid g;
+    g.table = reinterpret_cast<const float2 *>(h.table);
+    g.dense = reinterpret_cast<const float2 *>(h.dense);
+    for (int i = 0; i < TN_MAX_LEVELS; ++i) {
+        g.scal[i] = h.scalings[i];
+        g.dense_off[i] = h.dense_offset[i];
+        g.dense_res[i] = h.dense_res[i];
+    }
+    g.num_levels = h.num_levels;
+    g.num_dense = h.dense ? h.num_dense_levels : 0;
+    g.tsize = 1u << h.log2_hashmap_size;
+    g.mask = g.tsize - 1u;
+    return g;
+}
+
+static inline int tn_check_grid(const tn_hashgrid &h) {
+    if (!h.table) return TN_ERR_NULL;
+    if (h.num_levels < 1 || h.num_levels > TN_MAX_LEVELS) return TN_ERR_SHAPE;
+    if (h.log2_hashmap_size < 1 || h.log2_hashmap_size > 24) return TN_ERR_SHAPE;
+    return TN_OK;
+}
+
+#define TN_LAUNCH_CHECK()                                  \
+    do {                                                   \
+        if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH; \
+    } while (0)

@@ -1,0 +1,452 @@
+// Fused forward of Model.forward (collider output in) + ThermalNerfModel.get_outputs
+// [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:210-275], one wave64 per ray.
+//
+//   proposal_kernel   NS ProposalNetworkSampler.generate_ray_samples, both proposal levels fused:
+//                     piecewise bins -> prop net 0 -> weights -> PDF -> prop net 1 -> weights -> PDF -> S+1 bins
+//                     (SURVEY §8a a4,a5,a6,a11) + the two prop_depth_i medians [REF :267-270].  Per-ray state
+//                     (bins, weights, cdf) lives in LDS; nothing but the final S+1 bin edges goes back to HBM.
+//   main_valu_kernel  ThermalNerfactoTField.forward [REF thermal_field.py:183-201] on the S final samples +
+//                     get_weights + RGB/thermal/accumulation/depth renderers [REF :233-243,271-273], lane per
+//                     sample, MLPs on the VALU with weights in LDS (reference form of the fused kernel).
+//   main_mfma_kernel  same contract, MLPs on the f32 MFMA pipe (tn_render_mfma.hip).
+#include "tn_field_eval.h"
+
+using namespace tn;
+
+namespace tn {
+// implemented in tn_render_mfma.hip
+int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                     const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                     hipStream_t stream);
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / TN_WAVE;
+constexpr int PH = 16;  // proposal-net hidden width (proposal_net_args_list: hidden_dim 16)
+
+struct PropNet {
+    Grid g;
+    tn_space space;
+    const float *w0, *b0, *w1, *b1;
+    float avg;
+};
+
+struct PropArgs {
+    PropNet net[2];
+    const float *origins, *dirs, *nears, *fars;
+    const float *lin0, *u1, *u2, *jitter;
+    long long R;
+    int P0, P1, S, training;
+    float anneal;
+    float *ws_spacing;       // [R,S+1] final spacing bins (always)
+    float *out_spacing[3];   // optional
+    float *out_eucl[3];      // optional
+    float *out_w[2];         // optional [R,P0], [R,P1]
+    float *prop_depth[2];    // optional
+};
+
+// one proposal level for one ray (one wave): density -> weights (left in wts[]) -> median depth
+__device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLds &w, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float s_near, float s_far, const float *bins,
+                                            int n, float *wts, int lane) {
+    const Space sp = make_space(net.space);
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) {
+            const float st = spacing_to_eucl(bins[i], s_near, s_far);
+            const float en = spacing_to_eucl(bins[i + 1], s_near, s_far);
+            float px, py, pz;
+            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                 frustum_pos(oz, dz, st, en), px, py, pz);
+            const float dens = proposal_density_eval<PH>(net.g, w, net.avg, px, py, pz, sel);
+            wts[i] = mul_rn(sub_rn(en, st), dens);
+        }
+    }
+    float carry = 0.0f, carry_w = 0.0f;
+    int med_idx = n;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < n;
+        const float dd = ok ? wts[i] : 0.0f;
+        const float incl = wave_incl_scan(dd, lane);
+        const float excl = carry + (incl - dd);
+        const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
+        carry += __shfl(incl, 63, 64);
+        const float incl_w = wave_incl_scan(wi, lane) + carry_w;
+        const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
+        if (hit && med_idx == n) med_idx = base + __ffsll((long long)hit) - 1;
+        carry_w = __shfl(incl_w, 63, 64);
+        if (ok) wts[i] = wi;
+    }
+    const int idx = min(med_idx, n - 1);
+    const float st = spacing_to_eucl(bins[idx], s_near, s_far);
+    const float en = spacing_to_eucl(bins[idx + 1], s_near, s_far);
+    return add_rn(st, en) / 2.0f;
+}
+
+// NS PDFSampler: wts[n_in] (weights), bins[n_in+1] (existing spacing bins) -> new_bins[n_out+1]
+__device__ __forceinline__ void pdf_resample(const float *wts, const float *bins, int n_in, float *cdf,
+                                             const float *u, bool jittered, float u_rand, float anneal, int n_out,
+                                             float *new_bins, int lane) {
+    float part = 0.0f;
+    for (int i = lane; i < n_in; i += 64) {
+        const float wa = (anneal == 1.0f) ? wts[i] : powf(wts[i], anneal);
+        part += add_rn(wa, 0.01f);
+    }
+    float ws = wave_sum(part);
+    const float padding = fmaxf(sub_rn(1e-5f, ws), 0.0f);
+    const float pad_each = padding / (float)n_in;
+    ws = add_rn(ws, padding);
+    float carry = 0.0f;
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int base = 0; base < n_in; base += 64) {
+        const int i = base + lane;
+        float pdf = 0.0f;
+        if (i < n_in) {
+            const float wa = (anneal == 1.0f) ? wts[i] : powf(wts[i], anneal);
+            pdf = add_rn(add_rn(wa, 0.01f), pad_each) / ws;
+        }
+        const float incl = wave_incl_scan(pdf, lane) + carry;
+        if (i < n_in) cdf[i + 1] = fminf(1.0f, incl);
+        carry = __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nb = n_out + 1;
+    const float jit = jittered ? u_rand / (float)nb : 0.0f;
+    for (int j = lane; j < nb; j += 64) {
+        const float uu = jittered ? add_rn(u[j], jit) : u[j];
+        int lo = 0, hi = n_in + 1;
+        while (lo < hi) {  // searchsorted(cdf, uu, side="right")
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int below = min(max(lo - 1, 0), n_in);
+        const int above = min(max(lo, 0), n_in);
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = bins[below], b1 = bins[above];
+        float t = nan_to_num(sub_rn(uu, c0) / sub_rn(c1, c0));
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        new_bins[j] = add_rn(b0, mul_rn(t, sub_rn(b1, b0)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void store_bins(const float *bins, int nb, float s_near, float s_far, float *spacing,
+                                           float *eucl, long long r, int lane) {
+    if (spacing)
+        for (int j = lane; j < nb; j += 64) spacing[r * nb + j] = bins[j];
+    if (eucl)
+        for (int j = lane; j < nb; j += 64) eucl[r * nb + j] = spacing_to_eucl(bins[j], s_near, s_far);
+}
+
+__global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, int nbmax) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int in0 = 2 * a.net[0].g.num_levels, in1 = 2 * a.net[1].g.num_levels;
+    float *wbase0 = smem;
+    float *wbase1 = wbase0 + two_layer_floats(in0, PH, 1);
+    float *per_wave = wbase1 + two_layer_floats(in1, PH, 1);
+    const TwoLayerLds w0 = stage_two_layer<PH>(wbase0, a.net[0].w0, a.net[0].b0, a.net[0].w1, a.net[0].b1, in0, 1);
+    const TwoLayerLds w1 = stage_two_layer<PH>(wbase1, a.net[1].w0, a.net[1].b0, a.net[1].w1, a.net[1].b1, in1, 1);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *binsA = per_wave + (size_t)wave * (3 * nbmax + nmax);
+    float *binsB = binsA + nbmax;
+    float *cdf = binsB + nbmax;
+    float *wts = cdf + nbmax;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
+        const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
+        const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
+        const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
+        // level 0 bins: linspace (+ single stratified jitter in training), SURVEY A.7
+        const int P0 = a.P0, P1 = a.P1, S = a.S;
+        for (int j = lane; j <= P0; j += 64) {
+            float b = a.lin0[j];
+            if (a.jitter) {
+                const float t = a.jitter[r];
+                const float lo = (j == 0) ? a.lin0[0] : add_rn(a.lin0[j], a.lin0[j - 1]) / 2.0f;
+                const float hi = (j == P0) ? a.lin0[P0] : add_rn(a.lin0[j + 1], a.lin0[j]) / 2.0f;
+                b = add_rn(lo, mul_rn(sub_rn(hi, lo), t));
+            }
+            binsA[j] = b;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        store_bins(binsA, P0 + 1, s_near, s_far, a.out_spacing[0], a.out_eucl[0], r, lane);
+        const float med0 = prop_level(a.net[0], w0, ox, oy, oz, dx, dy, dz, s_near, s_far, binsA, P0, wts, lane);
+        if (a.out_w[0]) for (int i = lane; i < P0; i += 64) a.out_w[0][r * P0 + i] = wts[i];
+        pdf_resample(wts, binsA, P0, cdf, a.u1, a.jitter != nullptr, a.jitter ? a.jitter[a.R + r] : 0.0f, a.anneal, P1,
+                     binsB, lane);
+        store_bins(binsB, P1 + 1, s_near, s_far, a.out_spacing[1], a.out_eucl[1], r, lane);
+        const float med1 = prop_level(a.net[1], w1, ox, oy, oz, dx, dy, dz, s_near, s_far, binsB, P1, wts, lane);
+        if (a.out_w[1]) for (int i = lane; i < P1; i += 64) a.out_w[1][r * P1 + i] = wts[i];
+        pdf_resample(wts, binsB, P1, cdf, a.u2, a.jitter != nullptr, a.jitter ? a.jitter[2 * a.R + r] : 0.0f, a.anneal,
+                     S, binsA, lane);
+        store_bins(binsA, S + 1, s_near, s_far, a.ws_spacing, a.out_eucl[2], r, lane);
+        if (a.out_spacing[2]) for (int j = lane; j <= S; j += 64) a.out_spacing[2][r * (S + 1) + j] = binsA[j];
+        if (lane == 0) {
+            if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
+            if (a.prop_depth[1]) a.prop_depth[1][r] = med1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// main field + composite, lane per sample (reference form)
+// ------------------------------------------------------------------------------------------------------
+struct MainArgs {
+    Grid g;
+    tn_space space;
+    const float *b0w, *b0b, *b1w, *b1b;
+    HeadsArgs heads;
+    float avg;
+    const float *origins, *dirs, *nears, *fars;
+    const int *cam;
+    const float *spacing;  // [R,S+1]
+    long long R;
+    int S, training;
+    float *rgb, *acc, *depth, *expected, *thermal;
+    float *out_w;  // optional [R,S]
+    unsigned *minmax;
+};
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+constexpr int GF = 15;  // geo_feat_dim supported by the fused path
+
+__global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int in_dim = 2 * a.g.num_levels;
+    const TwoLayerLds wb = stage_two_layer<HW>(smem, a.b0w, a.b0b, a.b1w, a.b1b, in_dim, 1 + GF);
+    const HeadsLds wh = stage_heads(smem + two_layer_floats(in_dim, HW, 1 + GF), a.heads, a.training);
+    __syncthreads();
+    const Space sp = make_space(a.space);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = a.S, A = a.heads.app_dim;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
+        const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
+        const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
+        const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
+        const float *app = a.training ? (a.heads.appearance + (long long)a.cam[r] * A) : wh.APP;
+        const float *sb = a.spacing + r * (S + 1);
+        float carry = 0.0f, carry_w = 0.0f;
+        float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
+        float last_r = 0.0f, last_g = 0.0f, last_b = 0.0f, last_t = 0.0f;
+        float smin = INFINITY, smax = -INFINITY;
+        int med_idx = S;
+        for (int base = 0; base < S; base += 64) {
+            const int i = base + lane;
+            const bool ok = i < S;
+            float dd = 0.0f, step = 0.0f, c[3] = {0.0f, 0.0f, 0.0f}, th = 0.0f;
+            if (ok) {
+                const float st = spacing_to_eucl(sb[i], s_near, s_far);
+                const float en = spacing_to_eucl(sb[i + 1], s_near, s_far);
+                step = add_rn(st, en) / 2.0f;
+                float px, py, pz;
+                const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                     frustum_pos(oz, dz, st, en), px, py, pz);
+                float hid[HW];
+                hidden_from_grid<HW>(a.g, wb, px, py, pz, hid);
+                float o[1 + GF];
+#pragma unroll
+                for (int q = 0; q < 1 + GF; ++q) {
+                    float acc = wb.B1[q];
+                    const float *wrow = wb.W1 + q * HW;
+#pragma unroll
+                    for (int h = 0; h < HW; ++h) acc = fmaf(wrow[h], hid[h], acc);
+                    o[q] = acc;
+                }
+                const float dens = mul_rn(mul_rn(a.avg, expf(o[0])), sel);
+                heads_eval<GF>(wh, GF, A, a.heads.sh_shifted, dx, dy, dz, o + 1, app, c, th);
+                dd = mul_rn(sub_rn(en, st), dens);
+                if (!a.training) {
+                    c[0] = nan_to_num(c[0]); c[1] = nan_to_num(c[1]); c[2] = nan_to_num(c[2]);
+                    th = nan_to_num(th);
+                }
+                smin = fminf(smin, step);
+                smax = fmaxf(smax, step);
+            }
+            const float incl = wave_incl_scan(dd, lane);
+            const float excl = carry + (incl - dd);
+            const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
+            carry += __shfl(incl, 63, 64);
+            const float incl_w = wave_incl_scan(wi, lane) + carry_w;
+            const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
+            if (hit && med_idx == S) med_idx = base + __ffsll((long long)hit) - 1;
+            carry_w = __shfl(incl_w, 63, 64);
+            wsum += wi;
+            wr += mul_rn(wi, c[0]);
+            wg += mul_rn(wi, c[1]);
+            wbl += mul_rn(wi, c[2]);
+            wth += mul_rn(wi, th);
+            wsteps += mul_rn(wi, step);
+            if (a.out_w && ok) a.out_w[r * S + i] = wi;
+            if (base + 64 >= S) {  // chunk holding the last sample
+                const int src = (S - 1) - base;
+                last_r = __shfl(c[0], src, 64);
+                last_g = __shfl(c[1], src, 64);
+                last_b = __shfl(c[2], src, 64);
+                last_t = __shfl(th, src, 64);
+            }
+        }
+        wsum = wave_sum(wsum);
+        wr = wave_sum(wr); wg = wave_sum(wg); wbl = wave_sum(wbl); wth = wave_sum(wth); wsteps = wave_sum(wsteps);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            smin = fminf(smin, __shfl_xor(smin, o, 64));
+            smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+        }
+        const int idx = min(med_idx, S - 1);
+        if (lane == 0) {
+            const float bg = sub_rn(1.0f, wsum);
+            float cr = add_rn(wr, mul_rn(last_r, bg)), cg = add_rn(wg, mul_rn(last_g, bg)), cb = add_rn(wbl, mul_rn(last_b, bg));
+            float ct = add_rn(wth, mul_rn(last_t, bg));
+            if (!a.training) {
+                cr = fminf(fmaxf(cr, 0.0f), 1.0f); cg = fminf(fmaxf(cg, 0.0f), 1.0f); cb = fminf(fmaxf(cb, 0.0f), 1.0f);
+                ct = fminf(fmaxf(ct, 0.0f), 1.0f);
+            }
+            a.rgb[r * 3 + 0] = cr; a.rgb[r * 3 + 1] = cg; a.rgb[r * 3 + 2] = cb;
+            a.thermal[r] = ct;
+            a.acc[r] = wsum;
+            const float st = spacing_to_eucl(sb[idx], s_near, s_far), en = spacing_to_eucl(sb[idx + 1], s_near, s_far);
+            a.depth[r] = add_rn(st, en) / 2.0f;
+            a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
+            atomicMin(&a.minmax[0], f2key(smin));
+            atomicMax(&a.minmax[1], f2key(smax));
+        }
+    }
+}
+
+__global__ void minmax_init_kernel(unsigned *mm) {
+    mm[0] = 0xffffffffu;
+    mm[1] = 0u;
+}
+
+__global__ void depth_clip_kernel(float *__restrict__ expected, long long num_rays, const unsigned *mm) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rays) return;
+    const float lo = key2f(mm[0]), hi = key2f(mm[1]);
+    expected[r] = fminf(fmaxf(expected[r], lo), hi);
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline PropNet make_prop(const tn_density_field *f) {
+    PropNet p;
+    p.g = tn_make_grid(f->grid);
+    p.space = f->space;
+    p.w0 = f->l0.weight; p.b0 = f->l0.bias; p.w1 = f->l1.weight; p.b1 = f->l1.bias;
+    p.avg = f->average_init_density;
+    return p;
+}
+
+inline unsigned ray_grid(long long R, int blocks_per_cu) {
+    const long long need = (R + kWaves - 1) / kWaves;
+    const long long cap = 256LL * blocks_per_cu;
+    return (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays) {
+    if (!cfg || num_rays < 0) return 0;
+    return align_up((size_t)num_rays * (size_t)(cfg->num_nerf_samples + 1) * sizeof(float), 256) + 256;
+}
+
+int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_thermal_field *field,
+                       const tn_render_config *cfg, const tn_render_inputs *in, const tn_render_outputs *out,
+                       int64_t num_rays, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!prop0 || !prop1 || !field || !cfg || !in || !out || !workspace) return TN_ERR_NULL;
+    if (!in->origins || !in->directions || !in->nears || !in->fars || !in->lin_bins0 || !in->u1 || !in->u2) return TN_ERR_NULL;
+    if (!out->rgb || !out->accumulation || !out->depth || !out->expected_depth || !out->thermal) return TN_ERR_NULL;
+    if (cfg->training && (!in->camera_indices || !in->jitter)) return TN_ERR_NULL;
+    TN_TRY(tn_check_density_field(prop0));
+    TN_TRY(tn_check_density_field(prop1));
+    TN_TRY(tn_check_thermal_field(field));
+    if (prop0->l0.out_dim != PH || prop1->l0.out_dim != PH) return TN_ERR_UNSUPPORTED;
+    if (field->geo_feat_dim != GF) return TN_ERR_UNSUPPORTED;
+    const int P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1], S = cfg->num_nerf_samples;
+    if (P0 < 1 || P1 < 1 || S < 1 || P0 > 1024 || P1 > 1024 || S > 1024 || num_rays < 0) return TN_ERR_SHAPE;
+    if (workspace_bytes < tn_render_workspace_bytes(cfg, num_rays)) return TN_ERR_WORKSPACE;
+    if (num_rays == 0) return TN_OK;
+    hipStream_t s = (hipStream_t)stream;
+
+    float *ws_spacing = reinterpret_cast<float *>(workspace);
+    unsigned *minmax = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) +
+                                                    align_up((size_t)num_rays * (S + 1) * sizeof(float), 256));
+    PropArgs pa;
+    pa.net[0] = make_prop(prop0);
+    pa.net[1] = make_prop(prop1);
+    pa.origins = in->origins; pa.dirs = in->directions; pa.nears = in->nears; pa.fars = in->fars;
+    pa.lin0 = in->lin_bins0; pa.u1 = in->u1; pa.u2 = in->u2;
+    pa.jitter = cfg->training ? in->jitter : nullptr;
+    pa.R = num_rays; pa.P0 = P0; pa.P1 = P1; pa.S = S; pa.training = cfg->training; pa.anneal = cfg->pdf_anneal;
+    pa.ws_spacing = ws_spacing;
+    for (int i = 0; i < 3; ++i) { pa.out_spacing[i] = out->spacing_bins[i]; pa.out_eucl[i] = out->eucl_bins[i]; }
+    pa.out_w[0] = out->weights[0]; pa.out_w[1] = out->weights[1];
+    pa.prop_depth[0] = out->prop_depth_0; pa.prop_depth[1] = out->prop_depth_1;
+    const int nmax = P0 > P1 ? P0 : P1;
+    int nbmax = nmax > S ? nmax : S;
+    nbmax += 1;
+    const size_t prop_smem = (size_t)(two_layer_floats(2 * prop0->grid.num_levels, PH, 1) +
+                                      two_layer_floats(2 * prop1->grid.num_levels, PH, 1) +
+                                      kWaves * (3 * nbmax + nmax)) * sizeof(float);
+    if (prop_smem > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)prop_smem) != hipSuccess)
+        return TN_ERR_LAUNCH;
+    hipLaunchKernelGGL(proposal_kernel, dim3(ray_grid(num_rays, 8)), dim3(kBlock), prop_smem, s, pa, nmax, nbmax);
+    TN_LAUNCH_CHECK();
+
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, minmax);
+    if (field->prepared) {
+        TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
+    } else {
+        MainArgs ma;
+        ma.g = tn_make_grid(field->grid);
+        ma.space = field->space;
+        ma.b0w = field->base0.weight; ma.b0b = field->base0.bias; ma.b1w = field->base1.weight; ma.b1b = field->base1.bias;
+        ma.heads = make_heads_args(field);
+        ma.avg = field->average_init_density;
+        ma.origins = in->origins; ma.dirs = in->directions; ma.nears = in->nears; ma.fars = in->fars;
+        ma.cam = in->camera_indices;
+        ma.spacing = ws_spacing;
+        ma.R = num_rays; ma.S = S; ma.training = cfg->training;
+        ma.rgb = out->rgb; ma.acc = out->accumulation; ma.depth = out->depth; ma.expected = out->expected_depth;
+        ma.thermal = out->thermal; ma.out_w = out->weights[2]; ma.minmax = minmax;
+        const size_t main_smem = (size_t)(two_layer_floats(2 * field->grid.num_levels, HW, 1 + GF) +
+                                          heads_floats(GF, field->app_dim)) * sizeof(float);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_valu_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)main_smem) != hipSuccess)
+            return TN_ERR_LAUNCH;
+        hipLaunchKernelGGL(main_valu_kernel, dim3(ray_grid(num_rays, 2)), dim3(kBlock), main_smem, s, ma);
+        TN_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(depth_clip_kernel, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, s, out->expected_depth,
+                       (long long)num_rays, minmax);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+const char *tn_version(void) { return "thermonerf_hip 0.1 gfx950"; }
+
+}  // extern "C"

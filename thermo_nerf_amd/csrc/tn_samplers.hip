@@ -1,0 +1,335 @@
+// Samplers, weights and renderers of the plugin surface (one wave64 per ray; rays are independent).
+//
+//   tn_frustum_positions  NS Frustums.get_positions
+//   tn_sample_initial     NS UniformLinDispPiecewiseSampler           
+//   tn_weights_fwd        NS RaySamples.get_weights                   (a6)  [REF thermal_nerf_model.py:233]
+//   tn_sample_pdf         NS PDFSampler.generate_ray_samples          (a11)
+//   tn_composite_fwd      ThermalRenderer / RGBRenderer(last_sample)  (a12,a13) [REF thermal_renderer.py:27-80,113-149]
+//   tn_depth_fwd          Accumulation + Depth(median|expected)       (a13) [REF thermal_nerf_model.py:238-243,267-270]
+//
+// All of these are HBM-streaming kernels: every input element is read once, coalesced along the sample axis.
+#include "tn_device.h"
+
+using namespace tn;
+
+namespace {
+
+constexpr int kBlock = 256;  // 4 waves / block, one ray per wave
+constexpr int kWavesPerBlock = kBlock / TN_WAVE;
+constexpr int kMaxPdfIn = 1024;
+
+__global__ void frustum_positions_kernel(const float *__restrict__ o, const float *__restrict__ d,
+                                         const float *__restrict__ starts, const float *__restrict__ ends,
+                                         long long total, int n, float *__restrict__ pos) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long r = i / n;
+    const float s = starts[i], e = ends[i];
+    pos[i * 3 + 0] = frustum_pos(o[r * 3 + 0], d[r * 3 + 0], s, e);
+    pos[i * 3 + 1] = frustum_pos(o[r * 3 + 1], d[r * 3 + 1], s, e);
+    pos[i * 3 + 2] = frustum_pos(o[r * 3 + 2], d[r * 3 + 2], s, e);
+}
+
+__global__ void sample_initial_kernel(const float *__restrict__ lin_bins, const float *__restrict__ t_rand,
+                                      const float *__restrict__ nears, const float *__restrict__ fars,
+                                      long long num_rays, int n, float *__restrict__ spacing,
+                                      float *__restrict__ eucl) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = n + 1;
+    if (i >= num_rays * nb) return;
+    const long long r = i / nb;
+    const int j = (int)(i - r * nb);
+    float b = lin_bins[j];
+    if (t_rand) {
+        // bins = lower + (upper - lower) * t ; centers between neighbouring linspace points
+        const float lo = (j == 0) ? lin_bins[0] : add_rn(lin_bins[j], lin_bins[j - 1]) / 2.0f;
+        const float hi = (j == n) ? lin_bins[n] : add_rn(lin_bins[j + 1], lin_bins[j]) / 2.0f;
+        b = add_rn(lo, mul_rn(sub_rn(hi, lo), t_rand[r]));
+    }
+    const float sn = spacing_fn(nears[r]), sf = spacing_fn(fars[r]);
+    spacing[i] = b;
+    eucl[i] = spacing_to_eucl(b, sn, sf);
+}
+
+// weights = nan_to_num((1 - exp(-d*sigma)) * exp(-exclusive_cumsum(d*sigma)))
+__global__ void weights_kernel(const float *__restrict__ deltas, const float *__restrict__ dens, long long num_rays,
+                               int n, float *__restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= num_rays) return;
+    const float *dl = deltas + r * n;
+    const float *dn = dens + r * n;
+    float *w = weights + r * n;
+    float carry = 0.0f;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const float dd = (i < n) ? mul_rn(dl[i], dn[i]) : 0.0f;
+        const float incl = wave_incl_scan(dd, lane);
+        const float excl = carry + (incl - dd);
+        if (i < n) {
+            const float alpha = sub_rn(1.0f, expf(-dd));
+            w[i] = nan_to_num(mul_rn(alpha, expf(-excl)));
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+__global__ void sample_pdf_kernel(const float *__restrict__ weights, const float *__restrict__ existing,
+                                  const float *__restrict__ u, const float *__restrict__ u_rand,
+                                  const float *__restrict__ nears, const float *__restrict__ fars,
+                                  long long num_rays, int n_in, int n_out, float *__restrict__ spacing,
+                                  float *__restrict__ eucl) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * kWavesPerBlock + wave;
+    float *cdf = smem + (size_t)wave * 2 * (n_in + 1);
+    float *bins = cdf + (n_in + 1);
+    if (r >= num_rays) return;
+    const float *w = weights + r * n_in;
+    const float *ex = existing + r * (long long)(n_in + 1);
+    // pass 1: sum of padded weights
+    float part = 0.0f;
+    for (int i = lane; i < n_in; i += 64) part += add_rn(w[i], 0.01f);
+    float ws = wave_sum(part);
+    const float padding = fmaxf(sub_rn(1e-5f, ws), 0.0f);
+    const float pad_each = padding / (float)n_in;
+    ws = add_rn(ws, padding);
+    // pass 2: cdf
+    float carry = 0.0f;
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int base = 0; base < n_in; base += 64) {
+        const int i = base + lane;
+        const float pdf = (i < n_in) ? add_rn(add_rn(w[i], 0.01f), pad_each) / ws : 0.0f;
+        const float incl = wave_incl_scan(pdf, lane) + carry;
+        if (i < n_in) cdf[i + 1] = fminf(1.0f, incl);
+        carry = __shfl(incl, 63, 64);
+    }
+    for (int i = lane; i <= n_in; i += 64) bins[i] = ex[i];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int nb = n_out + 1;
+    const float sn = spacing_fn(nears[r]), sf = spacing_fn(fars[r]);
+    const float jit = u_rand ? u_rand[r] / (float)nb : 0.0f;
+    for (int j = lane; j < nb; j += 64) {
+        const float uu = u_rand ? add_rn(u[j], jit) : u[j];
+        // searchsorted(cdf, uu, side="right"): first index with cdf[idx] > uu, over n_in+1 entries
+        int lo = 0, hi = n_in + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int below = min(max(lo - 1, 0), n_in);
+        const int above = min(max(lo, 0), n_in);
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float b0 = bins[below], b1 = bins[above];
+        float t = sub_rn(uu, c0) / sub_rn(c1, c0);
+        t = nan_to_num(t);
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const float b = add_rn(b0, mul_rn(t, sub_rn(b1, b0)));
+        spacing[r * nb + j] = b;
+        eucl[r * nb + j] = spacing_to_eucl(b, sn, sf);
+    }
+}
+
+template <int C>
+__global__ void composite_kernel(const float *__restrict__ values, const float *__restrict__ weights,
+                                 long long num_rays, int n, int training, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= num_rays) return;
+    const float *v = values + r * (long long)n * C;
+    const float *w = weights + r * n;
+    float acc = 0.0f;
+    float comp[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) comp[c] = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+        const float wi = w[i];
+        acc += wi;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float x = v[(long long)i * C + c];
+            if (!training) x = nan_to_num(x);
+            comp[c] += mul_rn(wi, x);
+        }
+    }
+    acc = wave_sum(acc);
+#pragma unroll
+    for (int c = 0; c < C; ++c) comp[c] = wave_sum(comp[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float last = v[(long long)(n - 1) * C + c];
+            if (!training) last = nan_to_num(last);
+            float o = add_rn(comp[c], mul_rn(last, sub_rn(1.0f, acc)));
+            if (!training) o = fminf(fmaxf(o, 0.0f), 1.0f);
+            out[r * C + c] = o;
+        }
+    }
+}
+
+// monotone float <-> uint key, so unsigned atomicMin/Max order floats
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void minmax_init_kernel(unsigned *mm) {
+    mm[0] = 0xffffffffu;  // running min key
+    mm[1] = 0u;           // running max key
+}
+
+__global__ void depth_kernel(const float *__restrict__ weights, const float *__restrict__ starts,
+                             const float *__restrict__ ends, long long num_rays, int n, float *__restrict__ accum,
+                             float *__restrict__ median, float *__restrict__ expected, unsigned *mm) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= num_rays) return;
+    const float *w = weights + r * n;
+    const float *st = starts + r * n;
+    const float *en = ends + r * n;
+    float carry = 0.0f, wsum = 0.0f, wsteps = 0.0f;
+    int med_idx = n;  // first index with cumsum >= 0.5 (searchsorted side="left")
+    float smin = INFINITY, smax = -INFINITY;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < n;
+        const float wi = ok ? w[i] : 0.0f;
+        const float step = ok ? add_rn(st[i], en[i]) / 2.0f : 0.0f;
+        const float incl = wave_incl_scan(wi, lane) + carry;
+        const unsigned long long hit = __ballot(ok && (incl >= 0.5f));
+        if (hit && med_idx == n) med_idx = base + __ffsll((long long)hit) - 1;
+        carry = __shfl(incl, 63, 64);
+        wsum += wi;
+        wsteps += mul_rn(wi, step);
+        if (ok) {
+            smin = fminf(smin, step);
+            smax = fmaxf(smax, step);
+        }
+    }
+    wsum = wave_sum(wsum);
+    wsteps = wave_sum(wsteps);
+    if (expected) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            smin = fminf(smin, __shfl_xor(smin, o, 64));
+            smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+        }
+    }
+    if (lane == 0) {
+        if (accum) accum[r] = wsum;
+        if (median) {
+            const int idx = min(med_idx, n - 1);
+            median[r] = add_rn(st[idx], en[idx]) / 2.0f;
+        }
+        if (expected) {
+            expected[r] = wsteps / add_rn(wsum, 1e-10f);
+            atomicMin(&mm[0], f2key(smin));
+            atomicMax(&mm[1], f2key(smax));
+        }
+    }
+}
+
+__global__ void depth_clip_kernel(float *__restrict__ expected, long long num_rays, const unsigned *mm) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rays) return;
+    const float lo = key2f(mm[0]), hi = key2f(mm[1]);
+    expected[r] = fminf(fmaxf(expected[r], lo), hi);
+}
+
+inline unsigned blocks_for(long long items, int per_block) { return (unsigned)((items + per_block - 1) / per_block); }
+
+}  // namespace
+
+extern "C" {
+
+int tn_frustum_positions(const float *origins, const float *directions, const float *starts, const float *ends,
+                         int64_t num_rays, int32_t n, float *positions, void *stream) {
+    if (!origins || !directions || !starts || !ends || !positions) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    if (num_rays == 0) return TN_OK;
+    const long long total = (long long)num_rays * n;
+    hipLaunchKernelGGL(frustum_positions_kernel, dim3(blocks_for(total, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, origins, directions, starts, ends, total, n, positions);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *nears, const float *fars,
+                      int64_t num_rays, int32_t n, float *spacing_bins, float *eucl_bins, void *stream) {
+    if (!lin_bins || !nears || !fars || !spacing_bins || !eucl_bins) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    if (num_rays == 0) return TN_OK;
+    const long long total = (long long)num_rays * (n + 1);
+    hipLaunchKernelGGL(sample_initial_kernel, dim3(blocks_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       lin_bins, t_rand, nears, fars, (long long)num_rays, n, spacing_bins, eucl_bins);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays, int32_t n, float *weights,
+                   void *stream) {
+    if (!deltas || !densities || !weights) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    if (num_rays == 0) return TN_OK;
+    hipLaunchKernelGGL(weights_kernel, dim3(blocks_for(num_rays, kWavesPerBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, deltas, densities, (long long)num_rays, n, weights);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_sample_pdf(const float *weights, const float *existing_bins, const float *u, const float *u_rand,
+                  const float *nears, const float *fars, int64_t num_rays, int32_t n_in, int32_t n_out,
+                  float *spacing_bins, float *eucl_bins, void *stream) {
+    if (!weights || !existing_bins || !u || !nears || !fars || !spacing_bins || !eucl_bins) return TN_ERR_NULL;
+    if (num_rays < 0 || n_in < 1 || n_in > kMaxPdfIn || n_out < 1) return TN_ERR_SHAPE;
+    if (num_rays == 0) return TN_OK;
+    const size_t smem = (size_t)kWavesPerBlock * 2 * (n_in + 1) * sizeof(float);
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(num_rays, kWavesPerBlock)), dim3(kBlock), smem,
+                       (hipStream_t)stream, weights, existing_bins, u, u_rand, nears, fars, (long long)num_rays, n_in,
+                       n_out, spacing_bins, eucl_bins);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_composite_fwd(const float *values, const float *weights, int64_t num_rays, int32_t n, int32_t channels,
+                     int32_t training, float *out, void *stream) {
+    if (!values || !weights || !out) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    if (channels != 1 && channels != 3 && channels != 4) return TN_ERR_UNSUPPORTED;
+    if (num_rays == 0) return TN_OK;
+    const dim3 grid(blocks_for(num_rays, kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (channels == 1)
+        hipLaunchKernelGGL(composite_kernel<1>, grid, block, 0, s, values, weights, (long long)num_rays, n, training, out);
+    else if (channels == 3)
+        hipLaunchKernelGGL(composite_kernel<3>, grid, block, 0, s, values, weights, (long long)num_rays, n, training, out);
+    else
+        hipLaunchKernelGGL(composite_kernel<4>, grid, block, 0, s, values, weights, (long long)num_rays, n, training, out);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_depth_fwd(const float *weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
+                 float *accumulation, float *median, float *expected, float *minmax_scratch, void *stream) {
+    if (!weights || !starts || !ends) return TN_ERR_NULL;
+    if (expected && !minmax_scratch) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    if (num_rays == 0) return TN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *mm = reinterpret_cast<unsigned *>(minmax_scratch);
+    if (expected) hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
+    hipLaunchKernelGGL(depth_kernel, dim3(blocks_for(num_rays, kWavesPerBlock)), dim3(kBlock), 0, s, weights, starts,
+                       ends, (long long)num_rays, n, accumulation, median, expected, mm);
+    if (expected)
+        hipLaunchKernelGGL(depth_clip_kernel, dim3(blocks_for(num_rays, kBlock)), dim3(kBlock), 0, s, expected,
+                           (long long)num_rays, mm);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+}  // extern "C"

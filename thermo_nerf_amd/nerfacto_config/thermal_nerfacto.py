@@ -1,0 +1,142 @@
+"""Config surface + base class shared by the thermal models.
+
+Mirror of [REF thermo_nerf/nerfacto_config/thermal_nerfacto.py:13-45] on top of the nerfstudio
+``NerfactoModelConfig`` fields the reference consumes at [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:91-184]
+(defaults = nerfstudio 1.1.5).  One value is added to ``implementation``: ``"hip"``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Literal, Optional, Tuple, Type
+
+import torch
+from torch import Tensor, nn
+
+from ..camera_optimizer import CameraOptimizerConfig
+from ..rays import RayBundle
+from ..scene import SceneBox
+
+
+@dataclass
+class NerfactoModelConfig:
+    """The NerfactoModelConfig (nerfstudio 1.1.5) fields read on the ThermoNeRF path."""
+
+    _target: Type = field(default_factory=lambda: ThermalNerfactoModel)
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    background_color: Literal["random", "last_sample", "black", "white"] = "last_sample"
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    hidden_dim_transient: int = 64
+    num_levels: int = 16
+    base_res: int = 16
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    features_per_level: int = 2
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    proposal_update_every: int = 5
+    proposal_warmup: int = 5000
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = field(
+        default_factory=lambda: [
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False},
+        ]
+    )
+    proposal_initial_sampler: Literal["piecewise", "uniform"] = "piecewise"
+    interlevel_loss_mult: float = 1.0
+    distortion_loss_mult: float = 0.002
+    orientation_loss_mult: float = 0.0001
+    pred_normal_loss_mult: float = 0.001
+    use_proposal_weight_anneal: bool = True
+    use_appearance_embedding: bool = True
+    use_average_appearance_embedding: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    predict_normals: bool = False
+    disable_scene_contraction: bool = False
+    use_gradient_scaling: bool = False
+    implementation: Literal["hip", "tcnn", "torch"] = "hip"
+    appearance_embed_dim: int = 32
+    average_init_density: float = 0.01  # ignored by the reference (REF thermal_field.py:86 hard-codes 1.0)
+    camera_optimizer: CameraOptimizerConfig = field(default_factory=lambda: CameraOptimizerConfig(mode="SO3xR3"))
+    eval_num_rays_per_chunk: int = 4096
+    # --- additions of this implementation -----------------------------------------------------------
+    fused: bool = True
+    """Run get_outputs through the single fused entry point tn_render_rays_fwd (False: one HIP call per
+    nerfstudio module, mirroring the reference's call sequence)."""
+    sh_input: Literal["shifted", "unit"] = "shifted"
+    """Direction convention fed to the SH basis in the torch fallback (SURVEY A.6 [UNSURE])."""
+    dense_grid_budget_mb: int = 0
+    """>0: re-lay the coarse hash levels densely within this budget (layout only, bit-identical)."""
+    use_mfma: bool = True
+    """Use the MFMA form of the main-field kernel when the library provides it."""
+
+    def setup(self, **kwargs) -> Any:
+        return self._target(self, **kwargs)
+
+
+@dataclass
+class ThermalNerfactoModelConfig(NerfactoModelConfig):
+    """[REF thermal_nerfacto.py:13-25]"""
+
+    _target: Type = field(default_factory=lambda: ThermalNerfactoModel)
+    max_temperature: float = 1.0
+    min_temperature: float = 0.0
+    cold: bool = False
+    camera_optimizer_mode: Literal["off", "SO3xR3", "SE3"] = "SO3xR3"
+
+
+class ThermalNerfactoModel(nn.Module):
+    """Base of the thermal models [REF thermal_nerfacto.py:28-45] with the slice of nerfstudio's ``Model`` the hot
+    path needs: ``forward`` (collider -> get_outputs) and chunked ``get_outputs_for_camera_ray_bundle``."""
+
+    config: ThermalNerfactoModelConfig
+
+    def __init__(self, config: ThermalNerfactoModelConfig, scene_box: SceneBox, num_train_data: int, **kwargs) -> None:
+        super().__init__()
+        config.camera_optimizer = CameraOptimizerConfig(mode=config.camera_optimizer_mode)  # REF :38-40
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data = num_train_data
+        self.kwargs = kwargs
+        self.collider = None
+        self.max_temperature = config.max_temperature
+        self.min_temperature = config.min_temperature
+        self.populate_modules()
+        self.device_indicator_param = nn.Parameter(torch.empty(0))
+
+    @property
+    def device(self):
+        return self.device_indicator_param.device
+
+    def populate_modules(self) -> None:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def forward(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """NS Model.forward: collider, then get_outputs."""
+        if self.collider is not None:
+            ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle)
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """NS Model.get_outputs_for_camera_ray_bundle: [H,W] bundle, row-major chunks."""
+        num_rays_per_chunk = self.config.eval_num_rays_per_chunk
+        image_height, image_width = camera_ray_bundle.origins.shape[:2]
+        num_rays = len(camera_ray_bundle)
+        outputs_lists: Dict[str, List[Tensor]] = {}
+        for i in range(0, num_rays, num_rays_per_chunk):
+            ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk).to(self.device)
+            outputs = self.forward(ray_bundle=ray_bundle)
+            for name, out in outputs.items():
+                if not isinstance(out, Tensor):
+                    continue
+                outputs_lists.setdefault(name, []).append(out)
+        return {k: torch.cat(v).view(image_height, image_width, -1) for k, v in outputs_lists.items()}

@@ -1,0 +1,182 @@
+"""Ray samplers with nerfstudio's names (NS model_components.ray_samplers), built at
+[REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:164-179] and run at :222-224 — on MI355X.
+
+  UniformLinDispPiecewiseSampler  -> tn_sample_initial     
+  PDFSampler                      -> tn_sample_pdf         (a11)
+  ProposalNetworkSampler          -> the level loop of SURVEY A.7, same update/anneal bookkeeping
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _hip
+from .rays import RayBundle, RaySamples
+
+_const_cache: Dict[Tuple[str, int, str], Tensor] = {}
+
+
+def linspace_bins(n: int, device) -> Tensor:
+    """torch.linspace(0, 1, n+1) evaluated on the host exactly as nerfstudio does, then kept on the device."""
+    key = ("lin", n, str(device))
+    if key not in _const_cache:
+        _const_cache[key] = torch.linspace(0.0, 1.0, n + 1).to(device)
+    return _const_cache[key]
+
+
+def pdf_positions(num_bins: int, device, training: bool) -> Tensor:
+    """NS PDFSampler's ``u``: eval adds the half-bin offset; training adds the per-ray jitter in the kernel."""
+    key = ("u_train" if training else "u_eval", num_bins, str(device))
+    if key not in _const_cache:
+        u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins)
+        if not training:
+            u = u + 1.0 / (2 * num_bins)
+        _const_cache[key] = u.to(device)
+    return _const_cache[key]
+
+
+def _samples_from_bins(ray_bundle: RayBundle, spacing: Tensor, eucl: Tensor) -> RaySamples:
+    rs = ray_bundle.get_ray_samples(
+        bin_starts=eucl[..., :-1, None], bin_ends=eucl[..., 1:, None],
+        spacing_starts=spacing[..., :-1, None], spacing_ends=spacing[..., 1:, None],
+        spacing_to_euclidean_fn=None,
+    )
+    rs.spacing_bins, rs.eucl_bins = spacing, eucl
+    return rs
+
+
+class UniformLinDispPiecewiseSampler(nn.Module):
+    """NS UniformLinDispPiecewiseSampler (the "piecewise" proposal_initial_sampler default)."""
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False):
+        super().__init__()
+        self.num_samples = num_samples
+        self.train_stratified = train_stratified
+        self.single_jitter = single_jitter
+
+    def forward(self, ray_bundle: RayBundle, num_samples: Optional[int] = None,
+                t_rand: Optional[Tensor] = None) -> RaySamples:
+        n = num_samples or self.num_samples
+        assert n is not None and ray_bundle.nears is not None and ray_bundle.fars is not None
+        o = _hip.require_device_tensor(ray_bundle.origins, "origins")
+        R = o.shape[0]
+        if self.train_stratified and self.training:
+            if not self.single_jitter:
+                raise NotImplementedError("kernels implement single_jitter=True (REF thermal_nerf_model.py:176)")
+            if t_rand is None:
+                t_rand = torch.rand((R, 1), dtype=torch.float32, device=o.device)
+        else:
+            t_rand = None
+        nears = _hip.require_device_tensor(ray_bundle.nears.reshape(-1), "nears")
+        fars = _hip.require_device_tensor(ray_bundle.fars.reshape(-1), "fars")
+        spacing = torch.empty((R, n + 1), dtype=torch.float32, device=o.device)
+        eucl = torch.empty((R, n + 1), dtype=torch.float32, device=o.device)
+        lib = _hip.load()
+        _hip.check(
+            lib.tn_sample_initial(linspace_bins(n, o.device).data_ptr(),
+                                  None if t_rand is None else _hip.require_device_tensor(t_rand.reshape(-1), "t_rand").data_ptr(),
+                                  nears.data_ptr(), fars.data_ptr(), R, n, spacing.data_ptr(), eucl.data_ptr(),
+                                  _hip.current_stream()),
+            "tn_sample_initial",
+        )
+        return _samples_from_bins(ray_bundle, spacing, eucl)
+
+
+class PDFSampler(nn.Module):
+    """NS PDFSampler(include_original=False, histogram_padding=0.01)."""
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False,
+                 include_original: bool = False, histogram_padding: float = 0.01) -> None:
+        super().__init__()
+        if include_original or histogram_padding != 0.01:
+            raise NotImplementedError("kernels implement include_original=False, histogram_padding=0.01 "
+                                      "(how ProposalNetworkSampler builds its PDFSampler)")
+        self.num_samples = num_samples
+        self.train_stratified = train_stratified
+        self.single_jitter = single_jitter
+
+    def forward(self, ray_bundle: RayBundle, ray_samples: RaySamples, weights: Tensor,
+                num_samples: Optional[int] = None, eps: float = 1e-5, u_rand: Optional[Tensor] = None) -> RaySamples:
+        n_out = num_samples or self.num_samples
+        assert n_out is not None and ray_samples.spacing_bins is not None
+        w = _hip.require_device_tensor(weights[..., 0], "weights")
+        R, n_in = w.shape
+        jitter = self.train_stratified and self.training
+        if jitter:
+            if not self.single_jitter:
+                raise NotImplementedError("kernels implement single_jitter=True (REF thermal_nerf_model.py:176)")
+            if u_rand is None:
+                u_rand = torch.rand((R, 1), dtype=torch.float32, device=w.device)
+        else:
+            u_rand = None
+        existing = _hip.require_device_tensor(ray_samples.spacing_bins, "spacing_bins")
+        nears = _hip.require_device_tensor(ray_bundle.nears.reshape(-1), "nears")
+        fars = _hip.require_device_tensor(ray_bundle.fars.reshape(-1), "fars")
+        spacing = torch.empty((R, n_out + 1), dtype=torch.float32, device=w.device)
+        eucl = torch.empty((R, n_out + 1), dtype=torch.float32, device=w.device)
+        lib = _hip.load()
+        _hip.check(
+            lib.tn_sample_pdf(w.data_ptr(), existing.data_ptr(), pdf_positions(n_out + 1, w.device, jitter).data_ptr(),
+                              None if u_rand is None else _hip.require_device_tensor(u_rand.reshape(-1), "u_rand").data_ptr(),
+                              nears.data_ptr(), fars.data_ptr(), R, n_in, n_out, spacing.data_ptr(), eucl.data_ptr(),
+                              _hip.current_stream()),
+            "tn_sample_pdf",
+        )
+        return _samples_from_bins(ray_bundle, spacing, eucl)
+
+
+class ProposalNetworkSampler(nn.Module):
+    """NS ProposalNetworkSampler: piecewise initial sampler, then PDF resampling per level."""
+
+    def __init__(self, num_proposal_samples_per_ray: Tuple[int, ...] = (64,), num_nerf_samples_per_ray: int = 32,
+                 num_proposal_network_iterations: int = 2, single_jitter: bool = False,
+                 update_sched: Callable = lambda x: 1, initial_sampler: Optional[nn.Module] = None,
+                 pdf_sampler: Optional[PDFSampler] = None) -> None:
+        super().__init__()
+        self.num_proposal_samples_per_ray = num_proposal_samples_per_ray
+        self.num_nerf_samples_per_ray = num_nerf_samples_per_ray
+        self.num_proposal_network_iterations = num_proposal_network_iterations
+        self.update_sched = update_sched
+        if self.num_proposal_network_iterations < 1:
+            raise ValueError("num_proposal_network_iterations must be >= 1")
+        self.initial_sampler = initial_sampler or UniformLinDispPiecewiseSampler(single_jitter=single_jitter)
+        self.pdf_sampler = pdf_sampler or PDFSampler(include_original=False, single_jitter=single_jitter)
+        self._anneal = 1.0
+        self._steps_since_update = 0
+        self._step = 0
+
+    def set_anneal(self, anneal: float) -> None:
+        self._anneal = anneal
+
+    def step_cb(self, step: int) -> None:
+        self._step = step
+        self._steps_since_update += 1
+
+    def forward(self, ray_bundle: RayBundle, density_fns: Sequence[Callable],
+                jitter: Optional[Sequence[Tensor]] = None) -> Tuple[RaySamples, List[Tensor], List[RaySamples]]:
+        weights_list: List[Tensor] = []
+        ray_samples_list: List[RaySamples] = []
+        n = self.num_proposal_network_iterations
+        weights = None
+        ray_samples = None
+        updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
+        for i_level in range(n + 1):
+            is_prop = i_level < n
+            num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
+            jit = None if jitter is None else jitter[i_level]
+            if i_level == 0:
+                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples, t_rand=jit)
+            else:
+                annealed = weights if self._anneal == 1.0 else torch.pow(weights, self._anneal)
+                ray_samples = self.pdf_sampler(ray_bundle, ray_samples, annealed, num_samples=num_samples, u_rand=jit)
+            if is_prop:
+                density = density_fns[i_level](ray_samples.frustums.get_positions())
+                weights = ray_samples.get_weights(density)
+                weights_list.append(weights)
+                ray_samples_list.append(ray_samples)
+        if updated:
+            self._steps_since_update = 0
+        assert ray_samples is not None
+        return ray_samples, weights_list, ray_samples_list

@@ -1,0 +1,187 @@
+"""ThermalNerfactoTField — the nerfacto field plus ThermoNeRF's thermal branch, evaluated on MI355X.
+
+Interface mirror of [REF thermo_nerf/thermal_nerf/thermal_field.py:33-201] (constructor arguments, module and
+parameter names, ``get_density`` / ``get_outputs`` / ``forward`` signatures, returned dict keys, error
+behaviour).  The arithmetic is two HIP kernels: ``tn_field_density_fwd`` (NS NerfactoField.get_density) and
+``tn_field_heads_fwd`` (REF :108-181: SH + appearance + mlp_head, and mlp_thermal + ThermalFieldHead).
+"""
+from __future__ import annotations
+
+from typing import Dict, Literal, Optional, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from .. import _hip
+from ..fields import Embedding, FieldHeadNames, MLP, MLPWithHashEncoding
+from ..rays import RaySamples
+from ..scene import SceneContraction
+from .thermal_field_head import FieldHeadNamesT, ThermalFieldHead
+
+
+class ThermalNerfactoTField(nn.Module):
+    def __init__(
+        self,
+        aabb: Tensor,
+        num_images: int,
+        num_layers: int = 2,
+        hidden_dim: int = 64,
+        geo_feat_dim: int = 15,
+        num_levels: int = 16,
+        base_res: int = 16,
+        max_res: int = 2048,
+        log2_hashmap_size: int = 19,
+        num_layers_color: int = 3,
+        num_layers_transient: int = 2,
+        features_per_level: int = 2,
+        hidden_dim_color: int = 64,
+        hidden_dim_transient: int = 64,
+        appearance_embedding_dim: int = 32,
+        transient_embedding_dim: int = 16,
+        use_transient_embedding: bool = False,
+        use_semantics: bool = False,
+        num_semantic_classes: int = 100,
+        pass_semantic_gradients: bool = False,
+        use_pred_normals: bool = False,
+        use_average_appearance_embedding: bool = False,
+        spatial_distortion: Optional[SceneContraction] = None,
+        implementation: Literal["hip", "tcnn", "torch"] = "hip",
+        pass_thermal_gradients: bool = False,
+        sh_input: Literal["shifted", "unit"] = "shifted",
+    ) -> None:
+        super().__init__()
+        if use_transient_embedding or use_semantics or use_pred_normals:
+            # REF thermal_nerf_model.py:50-56,106-112 never enables these on the thermal-nerf path
+            raise NotImplementedError("transient / semantics / predicted-normals heads are off on the ThermoNeRF path")
+        if (num_layers, num_layers_color, num_layers_transient) != (2, 3, 2):
+            raise NotImplementedError("kernels implement mlp_base 2, mlp_head 3, mlp_thermal 2 layers (the defaults)")
+        if hidden_dim != 64 or hidden_dim_color != 64 or hidden_dim_transient != 64:
+            raise NotImplementedError("kernels implement 64-wide mlp_base / mlp_head / mlp_thermal (the defaults)")
+        self.register_buffer("aabb", aabb.clone().float())
+        self.geo_feat_dim = geo_feat_dim
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.spatial_distortion = spatial_distortion
+        self.num_images = num_images
+        self.appearance_embedding_dim = appearance_embedding_dim
+        self.use_average_appearance_embedding = use_average_appearance_embedding
+        self.use_transient_embedding = use_transient_embedding
+        self.use_semantics = use_semantics
+        self.use_pred_normals = use_pred_normals
+        self.pass_semantic_gradients = pass_semantic_gradients
+        # REF thermal_field.py:86 passes average_init_density = 1.0 positionally to NerfactoField
+        self.average_init_density = 1.0
+        self.sh_input = sh_input
+
+        self.embedding_appearance = Embedding(self.num_images, self.appearance_embedding_dim)
+        self.mlp_base = MLPWithHashEncoding(num_levels, base_res, max_res, log2_hashmap_size, features_per_level,
+                                            num_layers, hidden_dim, 1 + self.geo_feat_dim)
+        sh_dim = 16  # SHEncoding(levels=4)
+        self.mlp_head = MLP(sh_dim + self.geo_feat_dim + self.appearance_embedding_dim, num_layers_color,
+                            hidden_dim_color, 3)
+        # REF thermal_field.py:90-98: 15 -> 64 -> 64, ReLU, Sigmoid
+        self.mlp_thermal = MLP(self.geo_feat_dim, 2, 64, hidden_dim_transient)
+        self.field_head_thermal = ThermalFieldHead(in_dim=self.mlp_thermal.get_out_dim())  # REF :100-102
+        self.pass_thermal_gradients = pass_thermal_gradients
+        self.training_iteration = 0
+        self.pass_rgb_gradients = True
+        self.dense_budget_bytes = 0
+        self._prepared: Optional[Tensor] = None
+        self._prepared_key = None
+
+    # ------------------------------------------------------------------------------------------------
+    def c_struct(self, prepare: bool = False) -> _hip.tn_thermal_field:
+        f = _hip.tn_thermal_field()
+        f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes)
+        f.base0 = _hip.make_linear(self.mlp_base.mlp.layers[0])
+        f.base1 = _hip.make_linear(self.mlp_base.mlp.layers[1])
+        f.head0 = _hip.make_linear(self.mlp_head.layers[0])
+        f.head1 = _hip.make_linear(self.mlp_head.layers[1])
+        f.head2 = _hip.make_linear(self.mlp_head.layers[2])
+        f.th0 = _hip.make_linear(self.mlp_thermal.layers[0])
+        f.th1 = _hip.make_linear(self.mlp_thermal.layers[1])
+        f.thead = _hip.make_linear(self.field_head_thermal.net)
+        emb = _hip.require_device_tensor(self.embedding_appearance.embedding.weight.detach(), "embedding_appearance")
+        f.appearance = emb.data_ptr()
+        f.num_images = self.num_images
+        f.app_dim = self.appearance_embedding_dim
+        f.geo_feat_dim = self.geo_feat_dim
+        f.use_average_appearance = 1 if self.use_average_appearance_embedding else 0
+        f.sh_shifted = 1 if self.sh_input == "shifted" else 0
+        f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb)
+        f.average_init_density = float(self.average_init_density)
+        f.prepared = None
+        if prepare:
+            lib = _hip.load()
+            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            if self._prepared_key != key:
+                nbytes = lib.tn_field_prepare_bytes(f)
+                if nbytes > 0:
+                    self._prepared = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
+                    _hip.check(lib.tn_field_prepare(f, self._prepared.data_ptr(), nbytes, _hip.current_stream()),
+                               "tn_field_prepare")
+                else:
+                    self._prepared = None
+                self._prepared_key = key
+            f.prepared = None if self._prepared is None else self._prepared.data_ptr()
+        return f
+
+    # ------------------------------------------------------------------------------------------------
+    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+        """NS NerfactoField.get_density: (density [...,1], geo embedding [...,geo_feat_dim])."""
+        positions = ray_samples.frustums.get_positions()
+        return self.density_at(positions)
+
+    def density_at(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
+        pos = _hip.require_device_tensor(positions, "positions")
+        flat = pos.reshape(-1, 3)
+        n = flat.shape[0]
+        density = torch.empty((n,), dtype=torch.float32, device=flat.device)
+        geo = torch.empty((n, self.geo_feat_dim), dtype=torch.float32, device=flat.device)
+        lib = _hip.load()
+        _hip.check(lib.tn_field_density_fwd(self.c_struct(), flat.data_ptr(), n, density.data_ptr(), geo.data_ptr(),
+                                            _hip.current_stream()), "tn_field_density_fwd")
+        shape = positions.shape[:-1]
+        return density.view(*shape, 1), geo.view(*shape, self.geo_feat_dim)
+
+    def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None
+                    ) -> Dict[Union[FieldHeadNamesT, FieldHeadNames], Tensor]:
+        """REF thermal_field.py:108-181: RGB via mlp_head on [SH(dir), geo, appearance]; THERMAL via
+        mlp_thermal + ThermalFieldHead on geo."""
+        assert density_embedding is not None
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        dirs_src = ray_samples.frustums.directions
+        outputs_shape = dirs_src.shape[:-1]
+        dirs = _hip.require_device_tensor(dirs_src.reshape(-1, 3), "directions")
+        geo = _hip.require_device_tensor(density_embedding.reshape(-1, self.geo_feat_dim), "density_embedding")
+        n = dirs.shape[0]
+        cam = None
+        if self.training:
+            cam = _hip.require_device_tensor(ray_samples.camera_indices.reshape(-1).to(torch.int32), "camera_indices",
+                                             torch.int32)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dirs.device)
+        thermal = torch.empty((n,), dtype=torch.float32, device=dirs.device)
+        lib = _hip.load()
+        _hip.check(
+            lib.tn_field_heads_fwd(self.c_struct(), dirs.data_ptr(), geo.data_ptr(), _hip.ptr(cam), n,
+                                   1 if self.training else 0, rgb.data_ptr(), thermal.data_ptr(),
+                                   _hip.current_stream()),
+            "tn_field_heads_fwd",
+        )
+        return {
+            FieldHeadNames.RGB: rgb.view(*outputs_shape, 3),
+            FieldHeadNamesT.THERMAL: thermal.view(*outputs_shape, 1),
+        }
+
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False
+                ) -> Dict[Union[FieldHeadNamesT, FieldHeadNames], Tensor]:
+        """REF thermal_field.py:183-201."""
+        if compute_normals:
+            raise NotImplementedError("analytic normals need autograd through the density; predict_normals is False "
+                                      "on the ThermoNeRF path (REF thermal_nerf_model.py:225-227)")
+        density, density_embedding = self.get_density(ray_samples)
+        field_outputs = self.get_outputs(ray_samples, density_embedding=density_embedding)
+        field_outputs[FieldHeadNames.DENSITY] = density
+        return field_outputs

@@ -1,0 +1,276 @@
+"""ThermalNerfModel — ThermoNeRF's model with its forward pass on MI355X.
+
+Interface mirror of [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:46-275]: same config class/fields,
+constructor (``metadata`` must hold the "thermal" key), module names (``field``, ``proposal_networks``,
+``proposal_sampler``, ``collider``, ``renderer_*``, ``thermal_renderer``, ``camera_optimizer``) and the same
+``get_outputs`` output dictionary.
+
+Two execution forms of ``get_outputs`` (both HIP only, no PyTorch arithmetic on the path):
+  * ``config.fused=True``  — one C-ABI call, ``tn_render_rays_fwd`` (proposal kernel + main-field kernel);
+  * ``config.fused=False`` — the reference's own call sequence (sampler -> field.forward -> get_weights ->
+    renderers), every step one HIP entry point; used for Field-level callers and as the on-GPU cross-check.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Type
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from .. import _hip
+from ..fields import FieldHeadNames, HashMLPDensityField
+from ..nerfacto_config.thermal_nerfacto import ThermalNerfactoModel, ThermalNerfactoModelConfig
+from ..rays import RayBundle, RaySamples
+from ..rendered_image_modalities import RenderedImageModality
+from ..renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+from ..samplers import ProposalNetworkSampler, linspace_bins, pdf_positions, _samples_from_bins
+from ..scene import NearFarCollider, SceneBox, SceneContraction
+from .thermal_field import ThermalNerfactoTField
+from .thermal_field_head import FieldHeadNamesT
+from .thermal_renderer import ThermalRenderer
+
+
+@dataclass
+class ThermalNerfModelConfig(ThermalNerfactoModelConfig):
+    """[REF thermal_nerf_model.py:46-56]"""
+
+    _target: Type = field(default_factory=lambda: ThermalNerfModel)
+    use_transient_embedding: bool = False
+    thermal_loss_weight: float = 1.0
+    pass_thermal_gradients: bool = True
+
+
+class ThermalNerfModel(ThermalNerfactoModel):
+    config: ThermalNerfModelConfig
+
+    def __init__(self, config: ThermalNerfModelConfig, metadata: dict, scene_box: SceneBox, num_train_data: int,
+                 **kwargs) -> None:
+        if RenderedImageModality.THERMAL.value not in metadata.keys():  # REF :75-76
+            raise ValueError("Thermal images not found in metadata.")
+        super().__init__(config, scene_box, num_train_data, **kwargs)
+        self.config = config
+        self.max_temperature = config.max_temperature
+        self.min_temperature = config.min_temperature
+        self._workspace: Optional[Tensor] = None
+        self._struct_key = None
+        self._structs = None
+
+    # ------------------------------------------------------------------------------------------------
+    def populate_modules(self) -> None:
+        """[REF thermal_nerf_model.py:86-208]"""
+        cfg = self.config
+        if cfg.implementation not in ("hip", "tcnn", "torch"):
+            raise ValueError(cfg.implementation)
+        scene_contraction = None if cfg.disable_scene_contraction else SceneContraction(order=float("inf"))
+        budget = int(cfg.dense_grid_budget_mb) << 20
+
+        self.field = ThermalNerfactoTField(
+            self.scene_box.aabb, hidden_dim=cfg.hidden_dim, num_levels=cfg.num_levels, max_res=cfg.max_res,
+            base_res=cfg.base_res, features_per_level=cfg.features_per_level,
+            log2_hashmap_size=cfg.log2_hashmap_size, hidden_dim_color=cfg.hidden_dim_color,
+            hidden_dim_transient=cfg.hidden_dim_transient, spatial_distortion=scene_contraction,
+            num_images=self.num_train_data, use_pred_normals=cfg.predict_normals,
+            use_average_appearance_embedding=cfg.use_average_appearance_embedding,
+            appearance_embedding_dim=cfg.appearance_embed_dim, implementation="hip",
+            use_transient_embedding=cfg.use_transient_embedding, pass_thermal_gradients=cfg.pass_thermal_gradients,
+            sh_input=cfg.sh_input,
+        )
+        self.field.dense_budget_bytes = budget
+        self.camera_optimizer = cfg.camera_optimizer.setup(num_cameras=self.num_train_data, device="cpu")
+
+        self.density_fns = []
+        num_prop_nets = cfg.num_proposal_iterations
+        self.proposal_networks = nn.ModuleList()
+        if cfg.use_same_proposal_network:
+            assert len(cfg.proposal_net_args_list) == 1, "Only one proposal network is allowed."
+            network = HashMLPDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction,
+                                          **cfg.proposal_net_args_list[0], implementation="hip")
+            network.dense_budget_bytes = budget
+            self.proposal_networks.append(network)
+            self.density_fns.extend([network.density_fn for _ in range(num_prop_nets)])
+        else:
+            for i in range(num_prop_nets):
+                args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+                network = HashMLPDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, **args,
+                                              implementation="hip")
+                network.dense_budget_bytes = budget
+                self.proposal_networks.append(network)
+            self.density_fns.extend([network.density_fn for network in self.proposal_networks])
+
+        def update_schedule(step):  # REF :152-161
+            return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1,
+                           cfg.proposal_update_every)
+
+        if cfg.proposal_initial_sampler == "uniform":
+            raise NotImplementedError('proposal_initial_sampler="uniform" is not implemented; the reference default '
+                                      'is "piecewise" (REF :164-170)')
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray,
+            num_proposal_samples_per_ray=cfg.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=cfg.num_proposal_iterations, single_jitter=cfg.use_single_jitter,
+            update_sched=update_schedule, initial_sampler=None,
+        )
+        self.collider = NearFarCollider(near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+        self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="median")
+        self.renderer_expected_depth = DepthRenderer(method="expected")
+        self.thermal_renderer = ThermalRenderer()
+        self.step = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        """NS NerfactoModel.get_param_groups (+ camera_opt)."""
+        groups = {
+            "proposal_networks": list(self.proposal_networks.parameters()),
+            "fields": list(self.field.parameters()),
+        }
+        cam = list(self.camera_optimizer.parameters())
+        if cam:
+            groups["camera_opt"] = cam
+        return groups
+
+    def set_step(self, step: int) -> None:
+        """The two nerfstudio training callbacks: proposal-weight anneal and the sampler step."""
+        self.step = step
+        cfg = self.config
+        if cfg.use_proposal_weight_anneal:
+            n = cfg.proposal_weights_anneal_max_num_iters
+            frac = float(np.clip(step / n, 0, 1))
+            slope = cfg.proposal_weights_anneal_slope
+            self.proposal_sampler.set_anneal(slope * frac / ((slope - 1) * frac + 1))
+        self.proposal_sampler.step_cb(step)
+
+    # ------------------------------------------------------------------------------------------------
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """[REF thermal_nerf_model.py:210-275]"""
+        if self.training:
+            self.camera_optimizer.apply_to_raybundle(ray_bundle)  # REF :218-219
+        if ray_bundle.nears is None or ray_bundle.fars is None:
+            raise ValueError("ray_bundle.nears/fars are unset: call the model (forward applies the collider)")
+        fusable = (self.config.fused and self.config.num_proposal_iterations == 2
+                   and not self.config.use_same_proposal_network and not self.config.predict_normals
+                   and not self.config.use_gradient_scaling)
+        if fusable:
+            return self._get_outputs_fused(ray_bundle)
+        return self._get_outputs_modular(ray_bundle)
+
+    # --- the reference's call sequence, one HIP entry point per nerfstudio module ----------------------
+    def _get_outputs_modular(self, ray_bundle: RayBundle, jitter: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns,
+                                                                            jitter=jitter)
+        field_outputs = self.field.forward(ray_samples, compute_normals=self.config.predict_normals)
+        if self.config.use_gradient_scaling:
+            raise NotImplementedError("use_gradient_scaling only rescales gradients (backward); forward is unchanged")
+        weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
+        weights_list.append(weights)
+        ray_samples_list.append(ray_samples)
+        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights)
+        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)
+        expected_depth = self.renderer_expected_depth(weights=weights, ray_samples=ray_samples)
+        accumulation = self.renderer_accumulation(weights=weights)
+        outputs = {
+            "rgb": rgb,
+            RenderedImageModality.ACCUMULATION.value: accumulation,
+            RenderedImageModality.DEPTH.value: depth,
+            "expected_depth": expected_depth,
+        }
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+        for i in range(self.config.num_proposal_iterations):
+            outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+        outputs[RenderedImageModality.THERMAL.value] = self.thermal_renderer(field_outputs[FieldHeadNamesT.THERMAL], weights)
+        return outputs
+
+    # --- fused: one C-ABI call ------------------------------------------------------------------------
+    def _c_structs(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.config.use_mfma,)
+        if self._struct_key != key:
+            self._structs = (self.proposal_networks[0].c_struct(), self.proposal_networks[1].c_struct(),
+                             self.field.c_struct(prepare=self.config.use_mfma))
+            self._struct_key = key
+        return self._structs
+
+    def _get_outputs_fused(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None,
+                           want_samples: Optional[bool] = None) -> Dict[str, Tensor]:
+        lib = _hip.load()
+        cfg = self.config
+        training = bool(self.training)
+        want_samples = training if want_samples is None else want_samples
+        o = _hip.require_device_tensor(ray_bundle.origins, "origins")
+        d = _hip.require_device_tensor(ray_bundle.directions, "directions")
+        if o.dim() != 2:
+            raise ValueError("get_outputs expects a flat ray bundle: origins [R,3]")
+        R = o.shape[0]
+        dev = o.device
+        nears = _hip.require_device_tensor(ray_bundle.nears.reshape(-1), "nears")
+        fars = _hip.require_device_tensor(ray_bundle.fars.reshape(-1), "fars")
+        P0, P1 = cfg.num_proposal_samples_per_ray
+        S = cfg.num_nerf_samples_per_ray
+        prop0, prop1, fld = self._c_structs()
+
+        rc = _hip.tn_render_config()
+        rc.num_proposal_samples[0], rc.num_proposal_samples[1] = P0, P1
+        rc.num_nerf_samples = S
+        rc.training = 1 if training else 0
+        rc.pdf_anneal = float(self.proposal_sampler._anneal)
+
+        ins = _hip.tn_render_inputs()
+        ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
+        cam = None
+        if training:
+            if ray_bundle.camera_indices is None:
+                raise AttributeError("Camera indices are not provided.")
+            cam = _hip.require_device_tensor(ray_bundle.camera_indices.reshape(-1).to(torch.int32), "camera_indices",
+                                             torch.int32)
+            if jitter is None:
+                jitter = torch.rand((3, R), dtype=torch.float32, device=dev)
+            jitter = _hip.require_device_tensor(jitter, "jitter")
+        ins.camera_indices = _hip.ptr(cam)
+        ins.jitter = _hip.ptr(jitter) if training else None
+        ins.lin_bins0 = linspace_bins(P0, dev).data_ptr()
+        ins.u1 = pdf_positions(P1 + 1, dev, training).data_ptr()
+        ins.u2 = pdf_positions(S + 1, dev, training).data_ptr()
+
+        buf = torch.empty((9, R), dtype=torch.float32, device=dev)  # 36 B/ray of outputs, one allocation
+        rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        outs = _hip.tn_render_outputs()
+        outs.rgb = rgb.data_ptr()
+        names = ["accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal"]
+        for i, nm in enumerate(names):
+            setattr(outs, nm, buf[i].data_ptr())
+        extra = {}
+        if want_samples:
+            ns = (P0, P1, S)
+            extra["w"] = [torch.empty((R, n), dtype=torch.float32, device=dev) for n in ns]
+            extra["sp"] = [torch.empty((R, n + 1), dtype=torch.float32, device=dev) for n in ns]
+            extra["eu"] = [torch.empty((R, n + 1), dtype=torch.float32, device=dev) for n in ns]
+            for i in range(3):
+                outs.weights[i] = extra["w"][i].data_ptr()
+                outs.spacing_bins[i] = extra["sp"][i].data_ptr()
+                outs.eucl_bins[i] = extra["eu"][i].data_ptr()
+
+        need = lib.tn_render_workspace_bytes(rc, R)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        _hip.check(
+            lib.tn_render_rays_fwd(prop0, prop1, fld, rc, ins, outs, R, self._workspace.data_ptr(),
+                                   self._workspace.numel(), _hip.current_stream()),
+            "tn_render_rays_fwd",
+        )
+        outputs: Dict[str, Tensor] = {
+            "rgb": rgb,
+            RenderedImageModality.ACCUMULATION.value: buf[0][:, None],
+            RenderedImageModality.DEPTH.value: buf[1][:, None],
+            "expected_depth": buf[2][:, None],
+        }
+        if want_samples:
+            outputs["weights_list"] = [w[..., None] for w in extra["w"]]
+            outputs["ray_samples_list"] = [_samples_from_bins(ray_bundle, sp, eu) for sp, eu in zip(extra["sp"], extra["eu"])]
+        outputs["prop_depth_0"] = buf[3][:, None]
+        outputs["prop_depth_1"] = buf[4][:, None]
+        outputs[RenderedImageModality.THERMAL.value] = buf[5][:, None]
+        return outputs
