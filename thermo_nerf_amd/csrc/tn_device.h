@@ -180,6 +180,12 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
     return v;
 }
 
+// exclusive prefix from an inclusive one (robust to inf entries: no inf - inf)
+__device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
+    const float up = __shfl_up(incl, 1, 64);
+    return lane == 0 ? 0.0f : up;
+}
+
 }  // namespace tn
 
 // host-side conversion of the C-ABI grid struct into the by-value kernel argument

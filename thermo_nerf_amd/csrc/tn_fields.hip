@@ -87,6 +87,7 @@ inline unsigned grid_for(long long n) {
 extern "C" {
 
 int tn_density_fwd(const tn_density_field *f, const float *positions, int64_t n, float *density, void *stream) {
+    if (n == 0) return TN_OK;
     if (!f || !positions || !density) return TN_ERR_NULL;
     TN_TRY(tn_check_density_field(f));
     if (n < 0) return TN_ERR_SHAPE;
@@ -107,6 +108,7 @@ int tn_density_fwd(const tn_density_field *f, const float *positions, int64_t n,
 
 int tn_field_density_fwd(const tn_thermal_field *f, const float *positions, int64_t n, float *density, float *geo,
                          void *stream) {
+    if (n == 0) return TN_OK;
     if (!f || !positions || !density || !geo) return TN_ERR_NULL;
     TN_TRY(tn_check_thermal_field(f));
     if (n < 0) return TN_ERR_SHAPE;
@@ -123,6 +125,7 @@ int tn_field_density_fwd(const tn_thermal_field *f, const float *positions, int6
 int tn_field_heads_fwd(const tn_thermal_field *f, const float *directions, const float *geo,
                        const int32_t *camera_indices, int64_t n, int32_t training, float *rgb, float *thermal,
                        void *stream) {
+    if (n == 0) return TN_OK;
     if (!f || !directions || !geo || !rgb || !thermal) return TN_ERR_NULL;
     if (training && !camera_indices) return TN_ERR_NULL;
     TN_TRY(tn_check_thermal_field(f));

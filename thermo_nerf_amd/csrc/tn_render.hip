@@ -71,7 +71,7 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
         const bool ok = i < n;
         const float dd = ok ? wts[i] : 0.0f;
         const float incl = wave_incl_scan(dd, lane);
-        const float excl = carry + (incl - dd);
+        const float excl = carry + wave_excl_from_incl(incl, lane);
         const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
         carry += __shfl(incl, 63, 64);
         const float incl_w = wave_incl_scan(wi, lane) + carry_w;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
                 smax = fmaxf(smax, step);
             }
             const float incl = wave_incl_scan(dd, lane);
-            const float excl = carry + (incl - dd);
+            const float excl = carry + wave_excl_from_incl(incl, lane);
             const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
             carry += __shfl(incl, 63, 64);
             const float incl_w = wave_incl_scan(wi, lane) + carry_w;
@@ -375,6 +375,7 @@ size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays) 
 int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_thermal_field *field,
                        const tn_render_config *cfg, const tn_render_inputs *in, const tn_render_outputs *out,
                        int64_t num_rays, void *workspace, size_t workspace_bytes, void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!prop0 || !prop1 || !field || !cfg || !in || !out || !workspace) return TN_ERR_NULL;
     if (!in->origins || !in->directions || !in->nears || !in->fars || !in->lin_bins0 || !in->u1 || !in->u2) return TN_ERR_NULL;
     if (!out->rgb || !out->accumulation || !out->depth || !out->expected_depth || !out->thermal) return TN_ERR_NULL;

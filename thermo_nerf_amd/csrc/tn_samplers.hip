@@ -65,7 +65,7 @@ __global__ void weights_kernel(const float *__restrict__ deltas, const float *__
         const int i = base + lane;
         const float dd = (i < n) ? mul_rn(dl[i], dn[i]) : 0.0f;
         const float incl = wave_incl_scan(dd, lane);
-        const float excl = carry + (incl - dd);
+        const float excl = carry + wave_excl_from_incl(incl, lane);
         if (i < n) {
             const float alpha = sub_rn(1.0f, expf(-dd));
             w[i] = nan_to_num(mul_rn(alpha, expf(-excl)));
@@ -249,6 +249,7 @@ extern "C" {
 
 int tn_frustum_positions(const float *origins, const float *directions, const float *starts, const float *ends,
                          int64_t num_rays, int32_t n, float *positions, void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!origins || !directions || !starts || !ends || !positions) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     if (num_rays == 0) return TN_OK;
@@ -261,6 +262,7 @@ int tn_frustum_positions(const float *origins, const float *directions, const fl
 
 int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *nears, const float *fars,
                       int64_t num_rays, int32_t n, float *spacing_bins, float *eucl_bins, void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!lin_bins || !nears || !fars || !spacing_bins || !eucl_bins) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     if (num_rays == 0) return TN_OK;
@@ -273,6 +275,7 @@ int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *n
 
 int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays, int32_t n, float *weights,
                    void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!deltas || !densities || !weights) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     if (num_rays == 0) return TN_OK;
@@ -285,6 +288,7 @@ int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays
 int tn_sample_pdf(const float *weights, const float *existing_bins, const float *u, const float *u_rand,
                   const float *nears, const float *fars, int64_t num_rays, int32_t n_in, int32_t n_out,
                   float *spacing_bins, float *eucl_bins, void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!weights || !existing_bins || !u || !nears || !fars || !spacing_bins || !eucl_bins) return TN_ERR_NULL;
     if (num_rays < 0 || n_in < 1 || n_in > kMaxPdfIn || n_out < 1) return TN_ERR_SHAPE;
     if (num_rays == 0) return TN_OK;
@@ -298,6 +302,7 @@ int tn_sample_pdf(const float *weights, const float *existing_bins, const float 
 
 int tn_composite_fwd(const float *values, const float *weights, int64_t num_rays, int32_t n, int32_t channels,
                      int32_t training, float *out, void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!values || !weights || !out) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     if (channels != 1 && channels != 3 && channels != 4) return TN_ERR_UNSUPPORTED;
@@ -316,6 +321,7 @@ int tn_composite_fwd(const float *values, const float *weights, int64_t num_rays
 
 int tn_depth_fwd(const float *weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
                  float *accumulation, float *median, float *expected, float *minmax_scratch, void *stream) {
+    if (num_rays == 0) return TN_OK;
     if (!weights || !starts || !ends) return TN_ERR_NULL;
     if (expected && !minmax_scratch) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
