@@ -1,0 +1,189 @@
+"""bench.py — rays/sec of the ThermoNeRF rendering hot path on MI355X (BASELINE.json metric, config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A *step* is one pass of the hot path over one synthetic 800x800 frame (640 000 rays, forward-only, eval mode:
+proposal sampling 256+96 -> hash-grid+MLP field at S samples/ray -> alpha-composited RGB + thermal + depths),
+processed in chunks of 65 536 rays exactly as Model.get_outputs_for_camera_ray_bundle does.  Rays and weights are
+resident in HBM before the timed region.  With N ranks every rank renders its own frame (view = rank; weak
+scaling, rays shard with no data-path dependency) and the rendered pixels (36 B/ray) are all-gathered over
+RCCL inside the timed region.
+
+The JSON line also carries
+  roofline      the dominant kernel's achieved algorithmic HBM rate (HIP events on the launch stream, timed region)
+  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference path) timed on a bounded sample of the
+                same rays on this box's host cores (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+P0, P1 = 256, 96
+
+
+def algorithmic_bytes_per_ray(S: int):
+    """SURVEY §8d / BASELINE.md §3: hash-grid corner reads (8 B each) + 36 B in + 36 B out."""
+    prop = (P0 + P1) * 5 * 8 * 8
+    main = S * 16 * 8 * 8
+    return prop, main, prop + main + 72
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=64, help="num_nerf_samples_per_ray (config 2: 64)")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--chunk", type=int, default=1 << 16)
+    ap.add_argument("--weights", default="scene", choices=["init", "stress", "scene"])
+    ap.add_argument("--dense-mb", type=int, default=0)
+    ap.add_argument("--no-mfma", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per CPU-baseline repeat")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int):
+    from oracle import hotpath as H
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = min(rays_per_rep, o.shape[0])
+    # spread the sample over the frame (every k-th ray) so it is representative of the workload
+    idx = torch.linspace(0, o.shape[0] - 1, n).long()
+    oc, dc = o[idx].contiguous(), d[idx].contiguous()
+    with torch.no_grad():
+        H.get_outputs(sd, oc[:512], dc[:512], None, ocfg)  # warm-up
+        reps, t_total, out = 0, 0.0, None
+        while reps < 3 or (t_total < 10.0 and reps < 8):
+            t = time.perf_counter()
+            out = H.get_outputs(sd, oc, dc, None, ocfg)
+            t_total += time.perf_counter() - t
+            reps += 1
+    return {"value": n * reps / t_total, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {n} rays strided over the same 800x800 frame, chunk {n}, torch fp32 oracle, "
+                      f"{cores} threads"}, idx, out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback exists in thermo_nerf_amd)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd.engine import OUTPUT_KEYS, RayRenderEngine
+
+    S = args.samples
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=args.chunk,
+                                 dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma)
+    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+    synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box
+    model.eval()
+    sd_cpu = synthetic.model_state_dict_cpu(model) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    model = model.to(dev)
+
+    o_cpu, d_cpu, _ = synthetic.orbit_camera_rays(args.height, args.width, view=rank % 8)
+    o_cpu, d_cpu = o_cpu.reshape(-1, 3).contiguous(), d_cpu.reshape(-1, 3).contiguous()
+    o, d = o_cpu.to(dev), d_cpu.to(dev)
+    n_rays = o.shape[0]
+    engine = RayRenderEngine(model, chunk=args.chunk)
+    out = engine.allocate_outputs(n_rays, dev)
+    packed = torch.empty((n_rays, 9), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * n_rays, 9), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(record: bool):
+        engine.render(o, d, out=out, record_events=record)
+        if world > 1:
+            # the exchange step of the path: rendered pixels (9 floats = 36 B per ray) gathered over RCCL/xGMI
+            torch.cat([out[k] for k in OUTPUT_KEYS], dim=1, out=packed)
+            dist.all_gather_into_tensor(gathered, packed)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prop_ms, main_ms = engine.drain_timings()
+
+    if rank == 0:
+        total_rays = world * n_rays * args.steps
+        value = total_rays / elapsed
+        b_prop, b_main, b_all = algorithmic_bytes_per_ray(S)
+        # per-launch figures: a launch processes `chunk` rays (the last chunk of a frame is shorter; weight by rays)
+        launches = len(main_ms)
+        rays_per_launch = n_rays * args.steps / launches
+        avg_prop, avg_main = sum(prop_ms) / launches, sum(main_ms) / launches
+        dominant = "field_render" if avg_main >= avg_prop else "proposal_sample"
+        dom_ms = max(avg_main, avg_prop)
+        dom_bytes = (b_main + 36 + 24 + 4 * (S + 1)) if dominant == "field_render" else (b_prop + 24 + 4 * (S + 1) + 8)
+        achieved = dom_bytes * rays_per_launch / (dom_ms * 1e-3) / 1e9
+        line = {
+            "metric": "rays/sec (forward-only render) @ 800x800, %d samples/ray" % S,
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 2: synthetic %dx%d RGB+thermal scene, P=(256,96)+%d samples/ray, chunk %d, "
+                                   "forward-only eval, %s weights" % (args.height, args.width, S, args.chunk, args.weights),
+                       "rays_per_step_per_gpu": n_rays, "parallelism": "ray-shard x%d (one frame per rank)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dominant,
+                         "avg_launch_ms": dom_ms, "rays_per_launch": rays_per_launch,
+                         "algorithmic_bytes_per_ray": dom_bytes,
+                         "proposal_ms": avg_prop, "field_ms": avg_main,
+                         "path_bytes_per_ray": b_all, "path_frac": value / world * b_all / 1e9 / HBM_PEAK_GBS},
+        }
+        if sd_cpu is not None:
+            from tests import helpers  # oracle-side plumbing: only imported on the cpu_baseline leg
+
+            ocfg = helpers.oracle_config(cfg)
+            base, idx, want = cpu_baseline(sd_cpu, ocfg, o_cpu, d_cpu, args.cpu_rays)
+            line["cpu_baseline"] = base
+            # matched quality: the GPU frame vs the oracle on the very rays the baseline timed.  NOTE the oracle
+            # clips expected_depth per call, the engine per chunk; rgb/thermal are chunk-independent.
+            got_rgb, got_th = out["rgb"][idx.to(dev)].cpu(), out["thermal"][idx.to(dev)].cpu()
+            line["parity"] = {"rgb_mae": float((got_rgb - want["rgb"]).abs().mean()),
+                              "thermal_mae": float((got_th - want["thermal"]).abs().mean()),
+                              "rgb_psnr_db_vs_oracle": float(10 * torch.log10(1.0 / ((got_rgb - want["rgb"]) ** 2).mean().clamp_min(1e-20)))}
+            line["speedup_vs_cpu"] = value / base["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

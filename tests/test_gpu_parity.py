@@ -244,12 +244,16 @@ def check_outputs(got, want, tag):
     assert set(k for k, v in want.items() if isinstance(v, torch.Tensor)) <= set(got)
 
 
+IMPLS = {"mfma": (True, True), "valu": (True, False), "modular": (False, False)}  # (fused, use_mfma)
+
+
 @pytest.mark.parametrize("kind", ["init", "stress", "scene"])
 @pytest.mark.parametrize("S", [48, 64, 192])
-@pytest.mark.parametrize("fused", [True, False])
-def test_get_outputs_eval(kind, S, fused):
+@pytest.mark.parametrize("impl", list(IMPLS))
+def test_get_outputs_eval(kind, S, impl):
     gm, sd, ocfg = gpu_model(kind, S)
-    gm.config.fused = fused
+    fused = impl
+    gm.config.fused, gm.config.use_mfma = IMPLS[impl]
     o, d = helpers.rays(16, 16, view=S % 8)
     want = H.get_outputs(sd, o, d, None, ocfg)
     with torch.no_grad():
@@ -259,10 +263,11 @@ def test_get_outputs_eval(kind, S, fused):
     check_outputs(got, want, f"{kind}/S{S}/fused={fused}")
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_get_outputs_training_mode(fused):
+@pytest.mark.parametrize("impl", list(IMPLS))
+def test_get_outputs_training_mode(impl):
     """Train-mode forward: near plane 0.05, per-camera appearance, stratified jitter, no nan_to_num/clamp."""
     gm, sd, ocfg = gpu_model("stress", 48)
+    fused, gm.config.use_mfma = IMPLS[impl]
     gm.config.fused = fused
     gm.train()
     o, d = helpers.rays(12, 12, view=3)
@@ -278,7 +283,7 @@ def test_get_outputs_training_mode(fused):
         else:
             got = gm._get_outputs_modular(rb, jitter=[j.to(DEV) for j in jit])
     gm.eval()
-    check_outputs(got, want, f"train fused={fused}")
+    check_outputs(got, want, f"train impl={impl}")
     assert len(got["weights_list"]) == 3 and len(got["ray_samples_list"]) == 3
     for i in range(3):
         assert_close(got["weights_list"][i], want["weights_list"][i], 3e-5, 1e-4, f"weights_list[{i}]")
@@ -322,8 +327,10 @@ def test_camera_ray_bundle_chunking_matches_single_call():
     check_outputs(flat(got), flat(want), "chunked")
 
 
-def test_fused_is_deterministic_and_matches_modular():
+@pytest.mark.parametrize("use_mfma", [True, False])
+def test_fused_is_deterministic_and_matches_modular(use_mfma):
     gm, _, _ = gpu_model("stress", 64)
+    gm.config.use_mfma = use_mfma
     o, d = helpers.rays(24, 24, view=4)
     with torch.no_grad():
         gm.config.fused = True
@@ -334,3 +341,10 @@ def test_fused_is_deterministic_and_matches_modular():
     for k in ("rgb", "thermal", "accumulation", "expected_depth"):
         assert torch.equal(a[k], b[k]), f"{k} not deterministic"
         assert_close(a[k], c[k].cpu(), 2e-5, 1e-4, f"fused vs modular {k}")
+
+
+def test_mfma_path_is_actually_taken():
+    """The prepared blob must exist for the default config, i.e. the MFMA kernel (not the VALU form) runs."""
+    gm, _, _ = gpu_model("stress", 64)
+    _, _, fld = gm._c_structs()
+    assert fld.prepared, "tn_field_prepare produced no blob: the fused path would silently use the VALU kernel"

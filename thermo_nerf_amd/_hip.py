@@ -148,6 +148,16 @@ SIGNATURES = {
         [C.POINTER(tn_density_field), C.POINTER(tn_density_field), C.POINTER(tn_thermal_field),
          C.POINTER(tn_render_config), C.POINTER(tn_render_inputs), C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
     ),
+    "tn_proposal_sample_fwd": (
+        C.c_int,
+        [C.POINTER(tn_density_field), C.POINTER(tn_density_field), C.POINTER(tn_render_config),
+         C.POINTER(tn_render_inputs), C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
+    ),
+    "tn_field_render_fwd": (
+        C.c_int,
+        [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), C.POINTER(tn_render_inputs),
+         C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
+    ),
     "tn_hashgrid_prepare_bytes": (_sz, [C.POINTER(tn_hashgrid), _i64]),
     "tn_hashgrid_prepare": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_hashgrid), _vp, _sz, _vp]),
     "tn_field_prepare_bytes": (_sz, [C.POINTER(tn_thermal_field)]),

@@ -372,28 +372,32 @@ size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays) 
     return align_up((size_t)num_rays * (size_t)(cfg->num_nerf_samples + 1) * sizeof(float), 256) + 256;
 }
 
-int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_thermal_field *field,
-                       const tn_render_config *cfg, const tn_render_inputs *in, const tn_render_outputs *out,
-                       int64_t num_rays, void *workspace, size_t workspace_bytes, void *stream) {
-    if (num_rays == 0) return TN_OK;
-    if (!prop0 || !prop1 || !field || !cfg || !in || !out || !workspace) return TN_ERR_NULL;
-    if (!in->origins || !in->directions || !in->nears || !in->fars || !in->lin_bins0 || !in->u1 || !in->u2) return TN_ERR_NULL;
-    if (!out->rgb || !out->accumulation || !out->depth || !out->expected_depth || !out->thermal) return TN_ERR_NULL;
-    if (cfg->training && (!in->camera_indices || !in->jitter)) return TN_ERR_NULL;
-    TN_TRY(tn_check_density_field(prop0));
-    TN_TRY(tn_check_density_field(prop1));
-    TN_TRY(tn_check_thermal_field(field));
-    if (prop0->l0.out_dim != PH || prop1->l0.out_dim != PH) return TN_ERR_UNSUPPORTED;
-    if (field->geo_feat_dim != GF) return TN_ERR_UNSUPPORTED;
+static int check_render_common(const tn_render_config *cfg, int64_t num_rays, void *workspace, size_t workspace_bytes) {
+    if (!cfg || !workspace) return TN_ERR_NULL;
     const int P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1], S = cfg->num_nerf_samples;
     if (P0 < 1 || P1 < 1 || S < 1 || P0 > 1024 || P1 > 1024 || S > 1024 || num_rays < 0) return TN_ERR_SHAPE;
     if (workspace_bytes < tn_render_workspace_bytes(cfg, num_rays)) return TN_ERR_WORKSPACE;
-    if (num_rays == 0) return TN_OK;
-    hipStream_t s = (hipStream_t)stream;
+    return TN_OK;
+}
 
-    float *ws_spacing = reinterpret_cast<float *>(workspace);
-    unsigned *minmax = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) +
-                                                    align_up((size_t)num_rays * (S + 1) * sizeof(float), 256));
+static inline unsigned *ws_minmax(void *workspace, int64_t num_rays, int S) {
+    return reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) +
+                                        align_up((size_t)num_rays * (S + 1) * sizeof(float), 256));
+}
+
+int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_render_config *cfg,
+                           const tn_render_inputs *in, const tn_render_outputs *out, int64_t num_rays, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!prop0 || !prop1 || !in || !out) return TN_ERR_NULL;
+    TN_TRY(check_render_common(cfg, num_rays, workspace, workspace_bytes));
+    if (!in->origins || !in->directions || !in->nears || !in->fars || !in->lin_bins0 || !in->u1 || !in->u2) return TN_ERR_NULL;
+    if (cfg->training && !in->jitter) return TN_ERR_NULL;
+    TN_TRY(tn_check_density_field(prop0));
+    TN_TRY(tn_check_density_field(prop1));
+    if (prop0->l0.out_dim != PH || prop1->l0.out_dim != PH) return TN_ERR_UNSUPPORTED;
+    const int P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1], S = cfg->num_nerf_samples;
+    hipStream_t s = (hipStream_t)stream;
     PropArgs pa;
     pa.net[0] = make_prop(prop0);
     pa.net[1] = make_prop(prop1);
@@ -401,7 +405,7 @@ int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *pr
     pa.lin0 = in->lin_bins0; pa.u1 = in->u1; pa.u2 = in->u2;
     pa.jitter = cfg->training ? in->jitter : nullptr;
     pa.R = num_rays; pa.P0 = P0; pa.P1 = P1; pa.S = S; pa.training = cfg->training; pa.anneal = cfg->pdf_anneal;
-    pa.ws_spacing = ws_spacing;
+    pa.ws_spacing = reinterpret_cast<float *>(workspace);
     for (int i = 0; i < 3; ++i) { pa.out_spacing[i] = out->spacing_bins[i]; pa.out_eucl[i] = out->eucl_bins[i]; }
     pa.out_w[0] = out->weights[0]; pa.out_w[1] = out->weights[1];
     pa.prop_depth[0] = out->prop_depth_0; pa.prop_depth[1] = out->prop_depth_1;
@@ -417,7 +421,24 @@ int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *pr
         return TN_ERR_LAUNCH;
     hipLaunchKernelGGL(proposal_kernel, dim3(ray_grid(num_rays, 8)), dim3(kBlock), prop_smem, s, pa, nmax, nbmax);
     TN_LAUNCH_CHECK();
+    return TN_OK;
+}
 
+int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                        const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!field || !in || !out) return TN_ERR_NULL;
+    TN_TRY(check_render_common(cfg, num_rays, workspace, workspace_bytes));
+    if (!in->origins || !in->directions || !in->nears || !in->fars) return TN_ERR_NULL;
+    if (!out->rgb || !out->accumulation || !out->depth || !out->expected_depth || !out->thermal) return TN_ERR_NULL;
+    if (cfg->training && !in->camera_indices) return TN_ERR_NULL;
+    TN_TRY(tn_check_thermal_field(field));
+    if (field->geo_feat_dim != GF) return TN_ERR_UNSUPPORTED;
+    const int S = cfg->num_nerf_samples;
+    hipStream_t s = (hipStream_t)stream;
+    const float *ws_spacing = reinterpret_cast<const float *>(workspace);
+    unsigned *minmax = ws_minmax(workspace, num_rays, S);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, minmax);
     if (field->prepared) {
         TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
@@ -446,6 +467,13 @@ int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *pr
                        (long long)num_rays, minmax);
     TN_LAUNCH_CHECK();
     return TN_OK;
+}
+
+int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_thermal_field *field,
+                       const tn_render_config *cfg, const tn_render_inputs *in, const tn_render_outputs *out,
+                       int64_t num_rays, void *workspace, size_t workspace_bytes, void *stream) {
+    TN_TRY(tn_proposal_sample_fwd(prop0, prop1, cfg, in, out, num_rays, workspace, workspace_bytes, stream));
+    return tn_field_render_fwd(field, cfg, in, out, num_rays, workspace, workspace_bytes, stream);
 }
 
 const char *tn_version(void) { return "thermonerf_hip 0.1 gfx950"; }

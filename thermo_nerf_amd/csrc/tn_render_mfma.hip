@@ -1,14 +1,477 @@
-// MFMA form of the main-field kernel (placeholder until the fp32-MFMA kernel lands in this file).
+// main_mfma_kernel — ThermalNerfactoTField.forward + get_weights + renderers for the S final samples of a ray
+// [REF thermo_nerf/thermal_nerf/thermal_field.py:108-201; thermal_nerf_model.py:225-243,271-273] with the
+// five 64-wide MLP layers on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact f32 = an fmaf chain).
+//
+// One wave64 owns one ray; a pass handles 64 samples (lane = sample for the hash-grid phase and for compositing,
+// two 32-sample N-tiles for the MFMA phase).  Every layer is computed TRANSPOSED, H_out^T = W . H_in^T:
+//   A operand = weights      A[i = out feature][k]   lane l holds (i = l&31, k = ks(l>>5))
+//   B operand = activations  B[k][j = sample]        lane l holds (j = l&31, k = ks(l>>5))
+//   C/D                      lane l, reg r holds out feature (r&3) + 8(r>>2) + 4(l>>5), sample l&31
+// so a layer's accumulator registers ARE the next layer's B operands (lane<->sample is preserved; the k order a
+// register carries is baked into the pre-permuted A fragments by tn_field_prepare).  No activation ever goes
+// through LDS; the hash-grid features enter the first layer through 16 v_permlane32_swap.
+//
+// Work per 64 samples: 448 MFMAs (base 32->64: 64, 64->16: 64, geo->colour/thermal hidden: 32+32, 64->64: 128+128)
+// = 28.7 k MFMA cycles per SIMD; SH + appearance fold into a per-RAY bias of the colour layer; the 64->3 and
+// 64->1 output layers are VALU dot products on the accumulator registers.
 #include "tn_field_eval.h"
 
-namespace tn {
-int launch_main_mfma(const tn_thermal_field *, const tn_render_config *, const tn_render_inputs *,
-                     const tn_render_outputs *, long long, const float *, unsigned *, hipStream_t) {
-    return TN_ERR_UNSUPPORTED;
+using namespace tn;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / TN_WAVE;
+constexpr int GF = 15, APP = 32, L16 = 16, IN0 = 16 + GF + APP;
+
+// ---- prepared blob / LDS layout (floats) ---------------------------------------------------------------
+constexpr int A_BASE1 = 0, A_BASE2 = 32, A_C1 = 64, A_T1 = 80, A_C2 = 96, A_T2 = 160, A_COMBOS = 224;
+constexpr int OFF_A = 0;
+constexpr int OFF_B_BASE1 = A_COMBOS * 64;        // [64]
+constexpr int OFF_B_BASE2 = OFF_B_BASE1 + 64;     // [32] rows 0..15 valid
+constexpr int OFF_B_C1_EVAL = OFF_B_BASE2 + 32;   // [64] bias + W_app . mean(appearance)   (eval)
+constexpr int OFF_B_C1_RAW = OFF_B_C1_EVAL + 64;  // [64] bias                              (training)
+constexpr int OFF_B_T1 = OFF_B_C1_RAW + 64;       // [64]
+constexpr int OFF_B_C2 = OFF_B_T1 + 64;           // [64]
+constexpr int OFF_B_T2 = OFF_B_C2 + 64;           // [64]
+constexpr int OFF_W_SH = OFF_B_T2 + 64;           // [16][64]
+constexpr int OFF_W_APP = OFF_W_SH + 16 * 64;     // [32][64]
+constexpr int OFF_W3 = OFF_W_APP + 32 * 64;       // [3][64] + [4] bias
+constexpr int OFF_WTH = OFF_W3 + 3 * 64 + 4;      // [64] + [4] bias
+constexpr int BLOB_FLOATS = OFF_WTH + 64 + 4;     // 18024 floats = 72 096 B
+constexpr int OFF_SCRATCH = BLOB_FLOATS;          // per-wave [64] colour-layer bias of the current ray
+constexpr int LDS_FLOATS = OFF_SCRATCH + kWaves * 64;
+static_assert(BLOB_FLOATS % 4 == 0, "blob must be float4-copyable");
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct RawField {
+    const float *b0w, *b0b, *b1w, *b1b, *h0w, *h0b, *h1w, *h1b, *h2w, *h2b, *t0w, *t0b, *t1w, *t1b, *thw, *thb;
+    const float *appearance;
+    int num_images, use_avg;
+};
+
+__global__ void field_prepare_kernel(RawField w, float *__restrict__ blob) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= BLOB_FLOATS) return;
+    float v = 0.0f;
+    if (idx < A_COMBOS * 64) {
+        const int combo = idx >> 6, lane = idx & 63, i = lane & 31, h = lane >> 5;
+        if (combo < A_BASE2) {  // mlp_base layer 0: [64,32]; k-step s feeds features (2s, 2s+1)
+            const int mt = combo >> 4, s = combo & 15;
+            v = w.b0w[(i + 32 * mt) * 32 + 2 * s + h];
+        } else if (combo < A_C1) {  // mlp_base layer 1: [16,64]
+            const int c = combo - A_BASE2, mi = c >> 4, s = c & 15;
+            v = (i < 1 + GF) ? w.b1w[i * 64 + 32 * mi + crow(s, h)] : 0.0f;
+        } else if (combo < A_T1) {  // mlp_head layer 0, geo columns [16, 16+GF); row 0 of the input is the raw density
+            const int c = combo - A_C1, mt = c >> 3, s = c & 7, row = crow(s, h);
+            v = (row >= 1) ? w.h0w[(i + 32 * mt) * IN0 + 16 + (row - 1)] : 0.0f;
+        } else if (combo < A_C2) {  // mlp_thermal layer 0: [64,15]
+            const int c = combo - A_T1, mt = c >> 3, s = c & 7, row = crow(s, h);
+            v = (row >= 1) ? w.t0w[(i + 32 * mt) * GF + (row - 1)] : 0.0f;
+        } else {  // the two 64->64 layers
+            const bool thermal = combo >= A_T2;
+            const int c = combo - (thermal ? A_T2 : A_C2), mt = c >> 5, mi = (c >> 4) & 1, s = c & 15;
+            const float *m = thermal ? w.t1w : w.h1w;
+            v = m[(i + 32 * mt) * 64 + 32 * mi + crow(s, h)];
+        }
+    } else if (idx < OFF_B_BASE2) {
+        v = w.b0b[idx - OFF_B_BASE1];
+    } else if (idx < OFF_B_C1_EVAL) {
+        const int f = idx - OFF_B_BASE2;
+        v = f < 1 + GF ? w.b1b[f] : 0.0f;
+    } else if (idx < OFF_B_C1_RAW) {
+        const int f = idx - OFF_B_C1_EVAL;
+        v = w.h0b[f];
+        if (w.use_avg) {  // REF thermal_field.py:128-132: ones * mean(embedding)
+            for (int k = 0; k < APP; ++k) {
+                float m = 0.0f;
+                for (int im = 0; im < w.num_images; ++im) m += w.appearance[im * APP + k];
+                v = fmaf(w.h0w[f * IN0 + 16 + GF + k], m / (float)w.num_images, v);
+            }
+        }
+    } else if (idx < OFF_B_T1) {
+        v = w.h0b[idx - OFF_B_C1_RAW];
+    } else if (idx < OFF_B_C2) {
+        v = w.t0b[idx - OFF_B_T1];
+    } else if (idx < OFF_B_T2) {
+        v = w.h1b[idx - OFF_B_C2];
+    } else if (idx < OFF_W_SH) {
+        v = w.t1b[idx - OFF_B_T2];
+    } else if (idx < OFF_W_APP) {
+        const int e = idx - OFF_W_SH, k = e >> 6, f = e & 63;
+        v = w.h0w[f * IN0 + k];
+    } else if (idx < OFF_W3) {
+        const int e = idx - OFF_W_APP, k = e >> 6, f = e & 63;
+        v = w.h0w[f * IN0 + 16 + GF + k];
+    } else if (idx < OFF_WTH) {
+        const int e = idx - OFF_W3;
+        v = e < 192 ? w.h2w[e] : (e < 195 ? w.h2b[e - 192] : 0.0f);
+    } else {
+        const int e = idx - OFF_WTH;
+        v = e < 64 ? w.thw[e] : (e == 64 ? w.thb[0] : 0.0f);
+    }
+    blob[idx] = v;
 }
+
+// ---- kernel --------------------------------------------------------------------------------------------
+struct MfmaArgs {
+    Grid g;
+    tn_space space;
+    const float *blob;
+    const float *appearance;
+    float avg;
+    int sh_shifted;
+    const float *origins, *dirs, *nears, *fars;
+    const int *cam;
+    const float *spacing;  // [R,S+1]
+    long long R;
+    int S, training;
+    float *rgb, *acc, *depth, *expected, *thermal;
+    float *out_w;
+    unsigned *minmax;
+};
+
+#define MFMA32(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
+
+// accumulator init from a natural-order bias vector in LDS: reg r <- bias[32*mt + crow(r,h)]
+__device__ __forceinline__ f32x16 bias_frag(const float *bias, int mt, int h) {
+    f32x16 v;
+    const float4 q0 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 4 * h);
+    const float4 q1 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 8 + 4 * h);
+    const float4 q2 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 16 + 4 * h);
+    const float4 q3 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 24 + 4 * h);
+    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+    v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w;
+    v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
+    return v;
+}
+
+__device__ __forceinline__ void swap32(float a, float b, float &lo, float &hi) {
+    // lo = [a.lanes0-31 | b.lanes0-31 moved up], hi = [a.lanes32-63 moved down | b.lanes32-63]
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
+// one 64 -> 64 layer: out[mt][nt] = bias + sum over (mi, s) A[mt][mi][s] x relu(in[mi][nt][s])
+__device__ __forceinline__ void layer64(const float *A, int combo0, const float *bias, int lane, int h,
+                                        const f32x16 (&in)[2][2], f32x16 (&out)[2][2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        out[mt][0] = bias_frag(bias, mt, h);
+        out[mt][1] = out[mt][0];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float b0 = fmaxf(in[mi][0][s], 0.0f), b1 = fmaxf(in[mi][1][s], 0.0f);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float a = A[(combo0 + mt * 32 + mi * 16 + s) * 64 + lane];
+                MFMA32(out[mt][0], a, b0);
+                MFMA32(out[mt][1], a, b1);
+            }
+        }
+    }
+}
+
+// geo (rows 1..15 of g) -> 64 hidden: out[mt][nt] = bias + sum_s A[mt][s] x g[nt][s], s = 0..7
+__device__ __forceinline__ void layer_geo(const float *A, int combo0, const float *bias, int lane, int h,
+                                          const f32x16 (&g)[2], f32x16 (&out)[2][2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        out[mt][0] = bias_frag(bias, mt, h);
+        out[mt][1] = out[mt][0];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float a = A[(combo0 + mt * 8 + s) * 64 + lane];
+            MFMA32(out[mt][0], a, g[0][s]);
+            MFMA32(out[mt][1], a, g[1][s]);
+        }
+    }
+}
+
+// VALU dot of the lane's 32 hidden features (both M tiles) with one output row, for both N tiles; ACT applied first
+template <int ACT>  // 0 relu, 1 sigmoid
+__device__ __forceinline__ float2 out_dot(const float *wrow, int h, const f32x16 (&x)[2][2]) {
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4 *>(wrow + 32 * mt + 8 * q + 4 * h);
+            const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = x[mt][0][4 * q + e], a1 = x[mt][1][4 * q + e];
+                const float v0 = ACT ? sigmoidf(a0) : fmaxf(a0, 0.0f);
+                const float v1 = ACT ? sigmoidf(a1) : fmaxf(a1, 0.0f);
+                p0 = fmaf(ww[e], v0, p0);
+                p1 = fmaf(ww[e], v1, p1);
+            }
+        }
+    }
+    return make_float2(p0, p1);
+}
+
+// lanes 0-31 <- total of N-tile 0, lanes 32-63 <- total of N-tile 1 (partial sums live in both halves)
+__device__ __forceinline__ float combine_halves(float2 p) {
+    float lo, hi;
+    swap32(p.x, p.y, lo, hi);
+    return lo + hi;
+}
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {   // stage the prepared blob (float4, coalesced)
+        const float4 *src = reinterpret_cast<const float4 *>(a.blob);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *A = lds + OFF_A;
+    const Space sp = make_space(a.space);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    float *scratch = lds + OFF_SCRATCH + wave * 64;
+    const int S = a.S;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
+        const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
+        const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
+        const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
+        const float *sb = a.spacing + r * (S + 1);
+        {   // per-ray colour-layer bias: b + W_sh . SH(dir) (+ W_app . embedding[cam] in training); lane = feature
+            float sx = dx, sy = dy, sz = dz;
+            if (a.sh_shifted) {
+                sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
+            }
+            float c[16];
+            sh16(sx, sy, sz, c);
+            float v = lds[(a.training ? OFF_B_C1_RAW : OFF_B_C1_EVAL) + lane];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v = fmaf(lds[OFF_W_SH + k * 64 + lane], c[k], v);
+            if (a.training) {
+                const float *emb = a.appearance + (long long)a.cam[r] * APP;
+                for (int k = 0; k < APP; ++k) v = fmaf(lds[OFF_W_APP + k * 64 + lane], emb[k], v);
+            }
+            scratch[lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        float carry = 0.0f, carry_w = 0.0f;
+        float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
+        float last_r = 0.0f, last_g = 0.0f, last_b = 0.0f, last_t = 0.0f;
+        float smin = INFINITY, smax = -INFINITY;
+        int med_idx = S;
+        for (int base = 0; base < S; base += 64) {
+            const int i = base + lane;
+            const bool ok = i < S;
+            const int ic = ok ? i : S - 1;  // idle lanes re-evaluate the last sample (masked out below)
+            const float st = spacing_to_eucl(sb[ic], s_near, s_far);
+            const float en = spacing_to_eucl(sb[ic + 1], s_near, s_far);
+            const float step = add_rn(st, en) / 2.0f;
+            float px, py, pz;
+            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                 frustum_pos(oz, dz, st, en), px, py, pz);
+            // ---- hash grid: 32 features of this lane's sample -> B operands of the two N tiles -------------
+            float bt0[16], bt1[16];
+#pragma unroll
+            for (int l = 0; l < L16; ++l) {
+                const float2 f = encode_level_any(a.g, l, px, py, pz);
+                swap32(f.x, f.y, bt0[l], bt1[l]);
+                // keep the scheduler from hoisting all 128 gathers of the 16 levels at once (that spills ~450 VGPRs)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- mlp_base layer 0: 32 -> 64 ---------------------------------------------------------------
+            f32x16 h1[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                h1[mt][0] = bias_frag(lds + OFF_B_BASE1, mt, h);
+                h1[mt][1] = h1[mt][0];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float aw = A[(A_BASE1 + mt * 16 + s) * 64 + lane];
+                    MFMA32(h1[mt][0], aw, bt0[s]);
+                    MFMA32(h1[mt][1], aw, bt1[s]);
+                }
+            }
+            // ---- mlp_base layer 1: 64 -> 16 (rows 0..15 of one M tile) -------------------------------------
+            f32x16 g[2];
+            g[0] = bias_frag(lds + OFF_B_BASE2, 0, h);
+            g[1] = g[0];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float aw = A[(A_BASE2 + mi * 16 + s) * 64 + lane];
+                    MFMA32(g[0], aw, fmaxf(h1[mi][0][s], 0.0f));
+                    MFMA32(g[1], aw, fmaxf(h1[mi][1][s], 0.0f));
+                }
+            }
+            // row 0 (reg 0 of the lower half) is the raw density of sample l&31 of each tile -> lane = sample
+            float raw, unused;
+            swap32(g[0][0], g[1][0], raw, unused);
+            const float dens = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+            // ---- colour branch: geo -> 64 (per-ray bias) -> 64 -> 3 sigmoid --------------------------------
+            float cr, cg, cb, th;
+            {
+                f32x16 x1[2][2], x2[2][2];
+                layer_geo(A, A_C1, scratch, lane, h, g, x1);
+                layer64(A, A_C2, lds + OFF_B_C2, lane, h, x1, x2);
+                const float *w3 = lds + OFF_W3;
+                cr = sigmoidf(combine_halves(out_dot<0>(w3, h, x2)) + w3[192]);
+                cg = sigmoidf(combine_halves(out_dot<0>(w3 + 64, h, x2)) + w3[193]);
+                cb = sigmoidf(combine_halves(out_dot<0>(w3 + 128, h, x2)) + w3[194]);
+            }
+            // ---- thermal branch: geo -> 64 -> 64 sigmoid -> 1 -----------------------------------------------
+            {
+                f32x16 x1[2][2], x2[2][2];
+                layer_geo(A, A_T1, lds + OFF_B_T1, lane, h, g, x1);
+                layer64(A, A_T2, lds + OFF_B_T2, lane, h, x1, x2);
+                const float *wt = lds + OFF_WTH;
+                th = combine_halves(out_dot<1>(wt, h, x2)) + wt[64];
+            }
+            // ---- compositing (lane = sample) ---------------------------------------------------------------
+            if (!a.training) {
+                cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);
+            }
+            const float dd = ok ? mul_rn(sub_rn(en, st), dens) : 0.0f;
+            if (ok) {
+                smin = fminf(smin, step);
+                smax = fmaxf(smax, step);
+            }
+            const float incl = wave_incl_scan(dd, lane);
+            const float excl = carry + wave_excl_from_incl(incl, lane);
+            const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
+            carry += __shfl(incl, 63, 64);
+            const float incl_w = wave_incl_scan(wi, lane) + carry_w;
+            const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
+            if (hit && med_idx == S) med_idx = base + __ffsll((long long)hit) - 1;
+            carry_w = __shfl(incl_w, 63, 64);
+            wsum += wi;
+            wr += mul_rn(wi, cr);
+            wg += mul_rn(wi, cg);
+            wbl += mul_rn(wi, cb);
+            wth += mul_rn(wi, th);
+            wsteps += mul_rn(wi, step);
+            if (a.out_w && ok) a.out_w[r * S + i] = wi;
+            if (base + 64 >= S) {
+                const int src = (S - 1) - base;
+                last_r = __shfl(cr, src, 64);
+                last_g = __shfl(cg, src, 64);
+                last_b = __shfl(cb, src, 64);
+                last_t = __shfl(th, src, 64);
+            }
+        }
+        wsum = wave_sum(wsum);
+        wr = wave_sum(wr); wg = wave_sum(wg); wbl = wave_sum(wbl); wth = wave_sum(wth); wsteps = wave_sum(wsteps);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            smin = fminf(smin, __shfl_xor(smin, o, 64));
+            smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+        }
+        const int idx = min(med_idx, S - 1);
+        if (lane == 0) {
+            const float bg = sub_rn(1.0f, wsum);
+            float c0 = add_rn(wr, mul_rn(last_r, bg)), c1 = add_rn(wg, mul_rn(last_g, bg)), c2 = add_rn(wbl, mul_rn(last_b, bg));
+            float ct = add_rn(wth, mul_rn(last_t, bg));
+            if (!a.training) {
+                c0 = fminf(fmaxf(c0, 0.0f), 1.0f); c1 = fminf(fmaxf(c1, 0.0f), 1.0f); c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
+                ct = fminf(fmaxf(ct, 0.0f), 1.0f);
+            }
+            a.rgb[r * 3 + 0] = c0; a.rgb[r * 3 + 1] = c1; a.rgb[r * 3 + 2] = c2;
+            a.thermal[r] = ct;
+            a.acc[r] = wsum;
+            const float st = spacing_to_eucl(sb[idx], s_near, s_far), en = spacing_to_eucl(sb[idx + 1], s_near, s_far);
+            a.depth[r] = add_rn(st, en) / 2.0f;
+            a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
+            atomicMin(&a.minmax[0], f2key(smin));
+            atomicMax(&a.minmax[1], f2key(smax));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+inline bool mfma_supported(const tn_thermal_field *f) {
+    return f && f->geo_feat_dim == GF && f->app_dim == APP && f->grid.num_levels == L16;
+}
+
+}  // namespace
+
+namespace tn {
+
+int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                     const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                     hipStream_t stream) {
+    if (!mfma_supported(field) || !field->prepared) return TN_ERR_UNSUPPORTED;
+    MfmaArgs a;
+    a.g = tn_make_grid(field->grid);
+    a.space = field->space;
+    a.blob = field->prepared;
+    a.appearance = field->appearance;
+    a.avg = field->average_init_density;
+    a.sh_shifted = field->sh_shifted;
+    a.origins = in->origins; a.dirs = in->directions; a.nears = in->nears; a.fars = in->fars;
+    a.cam = in->camera_indices;
+    a.spacing = spacing_ws;
+    a.R = num_rays; a.S = cfg->num_nerf_samples; a.training = cfg->training;
+    a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
+    a.thermal = out->thermal; a.out_w = out->weights[2]; a.minmax = minmax;
+    const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+        return TN_ERR_LAUNCH;
+    const long long need = (num_rays + kWaves - 1) / kWaves;
+    const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 73 KB each)
+    const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
+    hipLaunchKernelGGL(main_mfma_kernel, dim3(grid), dim3(kBlock), smem, stream, a);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
 }  // namespace tn
 
 extern "C" {
-size_t tn_field_prepare_bytes(const tn_thermal_field *) { return 0; }
-int tn_field_prepare(const tn_thermal_field *, void *, size_t, void *) { return TN_ERR_UNSUPPORTED; }
+
+size_t tn_field_prepare_bytes(const tn_thermal_field *field) {
+    if (!mfma_supported(field) || tn_check_thermal_field(field) != TN_OK) return 0;
+    return (size_t)BLOB_FLOATS * sizeof(float);
 }
+
+int tn_field_prepare(const tn_thermal_field *f, void *prepared_dev, size_t bytes, void *stream) {
+    if (!f || !prepared_dev) return TN_ERR_NULL;
+    TN_TRY(tn_check_thermal_field(f));
+    if (!mfma_supported(f)) return TN_ERR_UNSUPPORTED;
+    if (bytes < (size_t)BLOB_FLOATS * sizeof(float)) return TN_ERR_WORKSPACE;
+    RawField w;
+    w.b0w = f->base0.weight; w.b0b = f->base0.bias; w.b1w = f->base1.weight; w.b1b = f->base1.bias;
+    w.h0w = f->head0.weight; w.h0b = f->head0.bias; w.h1w = f->head1.weight; w.h1b = f->head1.bias;
+    w.h2w = f->head2.weight; w.h2b = f->head2.bias; w.t0w = f->th0.weight; w.t0b = f->th0.bias;
+    w.t1w = f->th1.weight; w.t1b = f->th1.bias; w.thw = f->thead.weight; w.thb = f->thead.bias;
+    w.appearance = f->appearance; w.num_images = f->num_images; w.use_avg = f->use_average_appearance;
+    hipLaunchKernelGGL(field_prepare_kernel, dim3((BLOB_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<float *>(prepared_dev));
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""RayRenderEngine — chunked eval-mode rendering of a resident ray set through the fused C-ABI entry points.
+
+Counterpart of the reference's inference loop ``Renderer.render`` -> ``Model.get_outputs_for_camera_ray_bundle``
+[REF thermo_nerf/render/renderer.py:160-201; SURVEY §8a a14], restructured for throughput: the ray set lives in
+HBM, every chunk writes straight into slices of preallocated [N,C] outputs (no per-chunk ``cat``), all modalities
+come out of ONE pass (the reference re-renders per modality, REF renderer.py:180-183), and the two kernels of a
+chunk can be bracketed by HIP events on the launch stream for roofline accounting.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _hip
+from .samplers import linspace_bins, pdf_positions
+from .thermal_nerf.thermal_nerf_model import ThermalNerfModel
+
+OUTPUT_KEYS = ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal")
+
+
+class RayRenderEngine:
+    def __init__(self, model: ThermalNerfModel, chunk: Optional[int] = None) -> None:
+        if model.training:
+            raise RuntimeError("RayRenderEngine renders in eval mode; call model.eval() first")
+        self.model = model
+        self.chunk = int(chunk or model.config.eval_num_rays_per_chunk)
+        self.lib = _hip.load()
+        cfg = model.config
+        self.P0, self.P1 = cfg.num_proposal_samples_per_ray
+        self.S = cfg.num_nerf_samples_per_ray
+        self.rc = _hip.tn_render_config()
+        self.rc.num_proposal_samples[0], self.rc.num_proposal_samples[1] = self.P0, self.P1
+        self.rc.num_nerf_samples = self.S
+        self.rc.training = 0
+        self.rc.pdf_anneal = float(model.proposal_sampler._anneal)
+        self._ws: Optional[Tensor] = None
+        self._nf: Optional[Tuple[Tensor, Tensor]] = None
+        self.timings: List[Tuple[torch.cuda.Event, torch.cuda.Event, torch.cuda.Event]] = []
+
+    def _buffers(self, dev) -> None:
+        need = self.lib.tn_render_workspace_bytes(self.rc, self.chunk)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if self._nf is None or self._nf[0].device != dev:
+            # NS NearFarCollider in eval: near plane reset to 0
+            col = self.model.collider
+            near = col.near_plane if not col.reset_near_plane else 0.0
+            self._nf = (torch.full((self.chunk,), float(near), dtype=torch.float32, device=dev),
+                        torch.full((self.chunk,), float(col.far_plane), dtype=torch.float32, device=dev))
+
+    def allocate_outputs(self, n: int, dev) -> Dict[str, Tensor]:
+        out = {"rgb": torch.empty((n, 3), dtype=torch.float32, device=dev)}
+        for k in OUTPUT_KEYS[1:]:
+            out[k] = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        return out
+
+    @torch.no_grad()
+    def render(self, origins: Tensor, directions: Tensor, out: Optional[Dict[str, Tensor]] = None,
+               record_events: bool = False) -> Dict[str, Tensor]:
+        """origins/directions [N,3] resident on the device -> dict of [N,C] tensors (keys = OUTPUT_KEYS)."""
+        o = _hip.require_device_tensor(origins, "origins")
+        d = _hip.require_device_tensor(directions, "directions")
+        n, dev = o.shape[0], o.device
+        self._buffers(dev)
+        if out is None:
+            out = self.allocate_outputs(n, dev)
+        prop0, prop1, fld = self.model._c_structs()
+        ins = _hip.tn_render_inputs()
+        ins.nears, ins.fars = self._nf[0].data_ptr(), self._nf[1].data_ptr()
+        ins.camera_indices = None
+        ins.jitter = None
+        ins.lin_bins0 = linspace_bins(self.P0, dev).data_ptr()
+        ins.u1 = pdf_positions(self.P1 + 1, dev, False).data_ptr()
+        ins.u2 = pdf_positions(self.S + 1, dev, False).data_ptr()
+        outs = _hip.tn_render_outputs()
+        stream = _hip.current_stream()
+        ws, wsn = self._ws.data_ptr(), self._ws.numel()
+        for i in range(0, n, self.chunk):
+            r = min(self.chunk, n - i)
+            ins.origins, ins.directions = o.data_ptr() + 12 * i, d.data_ptr() + 12 * i
+            outs.rgb = out["rgb"].data_ptr() + 12 * i
+            for k in OUTPUT_KEYS[1:]:
+                setattr(outs, k, out[k].data_ptr() + 4 * i)
+            if record_events:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            _hip.check(self.lib.tn_proposal_sample_fwd(prop0, prop1, self.rc, ins, outs, r, ws, wsn, stream),
+                       "tn_proposal_sample_fwd")
+            if record_events:
+                e1.record()
+            _hip.check(self.lib.tn_field_render_fwd(fld, self.rc, ins, outs, r, ws, wsn, stream), "tn_field_render_fwd")
+            if record_events:
+                e2.record()
+                self.timings.append((e0, e1, e2))
+        return out
+
+    def drain_timings(self) -> Tuple[List[float], List[float]]:
+        """(proposal ms per launch, field ms per launch); call after a stream/device synchronise."""
+        prop = [a.elapsed_time(b) for a, b, _ in self.timings]
+        main = [b.elapsed_time(c) for _, b, c in self.timings]
+        self.timings = []
+        return prop, main
