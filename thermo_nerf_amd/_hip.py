@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _LIB_NAME = "libthermonerf_hip.so"
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+# THERMONERF_HIP_LIB: load a differently-built copy of the same library (kernel A/B experiments only)
+_LIB_PATH = os.environ.get("THERMONERF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 TN_MAX_LEVELS = 16
 

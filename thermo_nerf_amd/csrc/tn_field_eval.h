@@ -33,30 +33,52 @@ __device__ __forceinline__ TwoLayerLds stage_two_layer(float *smem, const float 
     return r;
 }
 
-template <int H>
+// NL > 0: level count known at compile time -> the level loop unrolls and all 8*NL gathers of a sample are
+// issued before the first one is consumed (latency paid once per sample instead of once per level).
+template <int H, int NL = 0>
 __device__ __forceinline__ void hidden_from_grid(const Grid &g, const TwoLayerLds &w, float px, float py, float pz,
                                                  float (&hid)[H]) {
 #pragma unroll
     for (int h = 0; h < H; ++h) hid[h] = w.B0[h];
-    for (int l = 0; l < g.num_levels; ++l) {
-        const float2 f = encode_level_any(g, l, px, py, pz);
-        const float *wa = w.W0t + (2 * l) * H;
-        const float *wb = wa + H;
+    if (NL > 0) {
+        float2 f[NL > 0 ? NL : 1];
+        if (g.num_dense == 0) {  // uniform branch hoisted out so the unrolled gathers are straight-line code
 #pragma unroll
-        for (int h = 0; h < H; ++h) hid[h] = fmaf(wa[h], f.x, hid[h]);
+            for (int l = 0; l < NL; ++l) f[l] = encode_level<false>(g, l, px, py, pz);
+        } else {
 #pragma unroll
-        for (int h = 0; h < H; ++h) hid[h] = fmaf(wb[h], f.y, hid[h]);
+            for (int l = 0; l < NL; ++l) f[l] = encode_level_any(g, l, px, py, pz);
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float *wa = w.W0t + (2 * l) * H;
+            const float *wb = wa + H;
+#pragma unroll
+            for (int h = 0; h < H; ++h) hid[h] = fmaf(wa[h], f[l].x, hid[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) hid[h] = fmaf(wb[h], f[l].y, hid[h]);
+        }
+    } else {
+        for (int l = 0; l < g.num_levels; ++l) {
+            const float2 f = encode_level_any(g, l, px, py, pz);
+            const float *wa = w.W0t + (2 * l) * H;
+            const float *wb = wa + H;
+#pragma unroll
+            for (int h = 0; h < H; ++h) hid[h] = fmaf(wa[h], f.x, hid[h]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) hid[h] = fmaf(wb[h], f.y, hid[h]);
+        }
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) hid[h] = fmaxf(hid[h], 0.0f);
 }
 
 // HashMLPDensityField: density = avg * exp(mlp(enc(p))) * selector
-template <int H>
+template <int H, int NL = 0>
 __device__ __forceinline__ float proposal_density_eval(const Grid &g, const TwoLayerLds &w, float avg, float px,
                                                        float py, float pz, float sel) {
     float hid[H];
-    hidden_from_grid<H>(g, w, px, py, pz, hid);
+    hidden_from_grid<H, NL>(g, w, px, py, pz, hid);
     float o = w.B1[0];
 #pragma unroll
     for (int h = 0; h < H; ++h) o = fmaf(w.W1[h], hid[h], o);

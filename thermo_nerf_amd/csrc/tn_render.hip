@@ -60,7 +60,10 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
             float px, py, pz;
             const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
-            const float dens = proposal_density_eval<PH>(net.g, w, net.avg, px, py, pz, sel);
+            // proposal_net_args_list uses num_levels 5: unrolled form keeps all 40 gathers of a sample in flight
+            const float dens = (net.g.num_levels == 5)
+                                   ? proposal_density_eval<PH, 5>(net.g, w, net.avg, px, py, pz, sel)
+                                   : proposal_density_eval<PH>(net.g, w, net.avg, px, py, pz, sel);
             wts[i] = mul_rn(sub_rn(en, st), dens);
         }
     }
@@ -240,6 +243,7 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = a.S, A = a.heads.app_dim;
     const long long stride = (long long)gridDim.x * kWaves;
+    float smin = INFINITY, smax = -INFINITY;  // running over every ray this wave renders
     for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
@@ -249,7 +253,6 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
         float carry = 0.0f, carry_w = 0.0f;
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float last_r = 0.0f, last_g = 0.0f, last_b = 0.0f, last_t = 0.0f;
-        float smin = INFINITY, smax = -INFINITY;
         int med_idx = S;
         for (int base = 0; base < S; base += 64) {
             const int i = base + lane;
@@ -308,11 +311,6 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
         }
         wsum = wave_sum(wsum);
         wr = wave_sum(wr); wg = wave_sum(wg); wbl = wave_sum(wbl); wth = wave_sum(wth); wsteps = wave_sum(wsteps);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            smin = fminf(smin, __shfl_xor(smin, o, 64));
-            smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-        }
         const int idx = min(med_idx, S - 1);
         if (lane == 0) {
             const float bg = sub_rn(1.0f, wsum);
@@ -328,9 +326,17 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
             const float st = spacing_to_eucl(sb[idx], s_near, s_far), en = spacing_to_eucl(sb[idx + 1], s_near, s_far);
             a.depth[r] = add_rn(st, en) / 2.0f;
             a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
-            atomicMin(&a.minmax[0], f2key(smin));
-            atomicMax(&a.minmax[1], f2key(smax));
         }
+    }
+    // one atomic pair per wave (see main_mfma_kernel): per-ray returned atomics on one address serialise in L2
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        smin = fminf(smin, __shfl_xor(smin, o, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0 && smin <= smax) {
+        atomicMin(&a.minmax[0], f2key(smin));
+        atomicMax(&a.minmax[1], f2key(smax));
     }
 }
 

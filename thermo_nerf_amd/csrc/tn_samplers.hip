@@ -187,14 +187,14 @@ __global__ void depth_kernel(const float *__restrict__ weights, const float *__r
                              const float *__restrict__ ends, long long num_rays, int n, float *__restrict__ accum,
                              float *__restrict__ median, float *__restrict__ expected, unsigned *mm) {
     const int lane = threadIdx.x & 63;
-    const long long r = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (r >= num_rays) return;
+    float smin = INFINITY, smax = -INFINITY;  // running over every ray this wave handles
+    const long long stride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long r = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); r < num_rays; r += stride) {
     const float *w = weights + r * n;
     const float *st = starts + r * n;
     const float *en = ends + r * n;
     float carry = 0.0f, wsum = 0.0f, wsteps = 0.0f;
     int med_idx = n;  // first index with cumsum >= 0.5 (searchsorted side="left")
-    float smin = INFINITY, smax = -INFINITY;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const bool ok = i < n;
@@ -213,21 +213,23 @@ __global__ void depth_kernel(const float *__restrict__ weights, const float *__r
     }
     wsum = wave_sum(wsum);
     wsteps = wave_sum(wsteps);
-    if (expected) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            smin = fminf(smin, __shfl_xor(smin, o, 64));
-            smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-        }
-    }
     if (lane == 0) {
         if (accum) accum[r] = wsum;
         if (median) {
             const int idx = min(med_idx, n - 1);
             median[r] = add_rn(st[idx], en[idx]) / 2.0f;
         }
-        if (expected) {
-            expected[r] = wsteps / add_rn(wsum, 1e-10f);
+        if (expected) expected[r] = wsteps / add_rn(wsum, 1e-10f);
+    }
+    }  // ray loop
+    if (expected) {
+        // ONE atomic pair per wave: a returned atomic per ray on a single address serialises in L2 (~12 ns each)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            smin = fminf(smin, __shfl_xor(smin, o, 64));
+            smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+        }
+        if (lane == 0 && smin <= smax) {
             atomicMin(&mm[0], f2key(smin));
             atomicMax(&mm[1], f2key(smax));
         }
@@ -329,7 +331,8 @@ int tn_depth_fwd(const float *weights, const float *starts, const float *ends, i
     hipStream_t s = (hipStream_t)stream;
     unsigned *mm = reinterpret_cast<unsigned *>(minmax_scratch);
     if (expected) hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
-    hipLaunchKernelGGL(depth_kernel, dim3(blocks_for(num_rays, kWavesPerBlock)), dim3(kBlock), 0, s, weights, starts,
+    const unsigned depth_blocks = blocks_for(num_rays, kWavesPerBlock);
+    hipLaunchKernelGGL(depth_kernel, dim3(depth_blocks < 2048u ? depth_blocks : 2048u), dim3(kBlock), 0, s, weights, starts,
                        ends, (long long)num_rays, n, accumulation, median, expected, mm);
     if (expected)
         hipLaunchKernelGGL(depth_clip_kernel, dim3(blocks_for(num_rays, kBlock)), dim3(kBlock), 0, s, expected,
