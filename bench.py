@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=64, help="num_nerf_samples_per_ray (config 2: 64)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--chunk", type=int, default=1 << 16)
+    ap.add_argument("--chunk", type=int, default=1 << 16, help="rays per launch (eval_num_rays_per_chunk)")
     ap.add_argument("--weights", default="scene", choices=["init", "stress", "scene"])
     ap.add_argument("--dense-mb", type=int, default=0)
     ap.add_argument("--no-mfma", action="store_true")

@@ -188,6 +188,22 @@ __device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
 
 }  // namespace tn
 
+// Layout of the final S+1 bin edges handed from the proposal kernel to the field kernel through the workspace:
+// ray-tiled [ceil(R/64)][S+1][64], so a wave that owns 64 consecutive rays reads 64 consecutive floats per edge.
+__host__ __device__ static inline size_t tn_ws_bin(long long r, int j, int S) {
+    return ((size_t)(r >> 6) * (size_t)(S + 1) + (size_t)j) * 64 + (size_t)(r & 63);
+}
+__host__ __device__ static inline size_t tn_ws_bin_floats(long long num_rays, int S) {
+    return (size_t)((num_rays + 63) >> 6) * 64 * (size_t)(S + 1);
+}
+
+#ifdef __HIPCC__
+struct WsBins {  // one ray's bin edges inside the ray-tiled workspace: edge j lives 64 floats after edge j-1
+    const float *base;
+    __device__ __forceinline__ float operator[](int j) const { return base[(size_t)j * 64]; }
+};
+#endif
+
 // host-side conversion of the C-ABI grid struct into the by-value kernel argument
 static inline tn::Grid tn_make_grid(const tn_hashgrid &h) {
     tn::Grid g;

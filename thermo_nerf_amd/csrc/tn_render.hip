@@ -40,7 +40,7 @@ struct PropArgs {
     long long R;
     int P0, P1, S, training;
     float anneal;
-    float *ws_spacing;       // [R,S+1] final spacing bins (always)
+    float *ws_spacing;       // final spacing bins, ray-tiled (tn_ws_bin), always written
     float *out_spacing[3];   // optional
     float *out_eucl[3];      // optional
     float *out_w[2];         // optional [R,P0], [R,P1]
@@ -192,7 +192,8 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
         if (a.out_w[1]) for (int i = lane; i < P1; i += 64) a.out_w[1][r * P1 + i] = wts[i];
         pdf_resample(wts, binsB, P1, cdf, a.u2, a.jitter != nullptr, a.jitter ? a.jitter[2 * a.R + r] : 0.0f, a.anneal,
                      S, binsA, lane);
-        store_bins(binsA, S + 1, s_near, s_far, a.ws_spacing, a.out_eucl[2], r, lane);
+        for (int j = lane; j <= S; j += 64) a.ws_spacing[tn_ws_bin(r, j, S)] = binsA[j];
+        store_bins(binsA, S + 1, s_near, s_far, nullptr, a.out_eucl[2], r, lane);
         if (a.out_spacing[2]) for (int j = lane; j <= S; j += 64) a.out_spacing[2][r * (S + 1) + j] = binsA[j];
         if (lane == 0) {
             if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
         const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
         const float *app = a.training ? (a.heads.appearance + (long long)a.cam[r] * A) : wh.APP;
-        const float *sb = a.spacing + r * (S + 1);
+        const WsBins sb{a.spacing + tn_ws_bin(r, 0, S)};  // ray-tiled workspace layout
         float carry = 0.0f, carry_w = 0.0f;
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float last_r = 0.0f, last_g = 0.0f, last_b = 0.0f, last_t = 0.0f;
@@ -375,7 +376,7 @@ extern "C" {
 
 size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays) {
     if (!cfg || num_rays < 0) return 0;
-    return align_up((size_t)num_rays * (size_t)(cfg->num_nerf_samples + 1) * sizeof(float), 256) + 256;
+    return align_up(tn_ws_bin_floats(num_rays, cfg->num_nerf_samples) * sizeof(float), 256) + 256;
 }
 
 static int check_render_common(const tn_render_config *cfg, int64_t num_rays, void *workspace, size_t workspace_bytes) {
@@ -388,7 +389,7 @@ static int check_render_common(const tn_render_config *cfg, int64_t num_rays, vo
 
 static inline unsigned *ws_minmax(void *workspace, int64_t num_rays, int S) {
     return reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) +
-                                        align_up((size_t)num_rays * (S + 1) * sizeof(float), 256));
+                                        align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256));
 }
 
 int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_render_config *cfg,

@@ -31,7 +31,7 @@ constexpr int GF = 15, APP = 32, L16 = 16, IN0 = 16 + GF + APP;
 constexpr int LG = TN_LEVEL_GROUP;  // hash levels whose gathers are in flight together
 
 // ---- prepared blob / LDS layout (floats) ---------------------------------------------------------------
-constexpr int A_BASE1 = 0, A_BASE2 = 32, A_C1 = 64, A_T1 = 80, A_C2 = 96, A_T2 = 160, A_COMBOS = 224;
+constexpr int A_BASE1 = 0, A_BASE2 = 32, A_C1 = 64, A_T1 = 80, A_C2 = 96, A_T2 = 160, A_SH = 224, A_COMBOS = 240;
 constexpr int OFF_A = 0;
 constexpr int OFF_B_BASE1 = A_COMBOS * 64;        // [64]
 constexpr int OFF_B_BASE2 = OFF_B_BASE1 + 64;     // [32] rows 0..15 valid
@@ -75,6 +75,9 @@ __global__ void field_prepare_kernel(RawField w, float *__restrict__ blob) {
         } else if (combo < A_C2) {  // mlp_thermal layer 0: [64,15]
             const int c = combo - A_T1, mt = c >> 3, s = c & 7, row = crow(s, h);
             v = (row >= 1) ? w.t0w[(i + 32 * mt) * GF + (row - 1)] : 0.0f;
+        } else if (combo >= A_SH) {  // mlp_head layer 0, SH columns [0,16): k-step s feeds SH comps (2s, 2s+1)
+            const int c = combo - A_SH, mt = c >> 3, s = c & 7;
+            v = w.h0w[(i + 32 * mt) * IN0 + 2 * s + h];
         } else {  // the two 64->64 layers
             const bool thermal = combo >= A_T2;
             const int c = combo - (thermal ? A_T2 : A_C2), mt = c >> 5, mi = (c >> 4) & 1, s = c & 15;
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
         const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
-        const float *sb = a.spacing + r * (S + 1);
+        const WsBins sb{a.spacing + tn_ws_bin(r, 0, S)};  // ray-tiled workspace layout
         {   // per-ray colour-layer bias: b + W_sh . SH(dir) (+ W_app . embedding[cam] in training); lane = feature
             float sx = dx, sy = dy, sz = dz;
             if (a.sh_shifted) {
@@ -428,6 +431,203 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// main_mfma_rays_kernel (eval): one wave64 owns 64 CONSECUTIVE RAYS and walks their samples in lock-step
+// (lane = ray, loop index = sample).  Adjacent rays at the same sample index land in the same / neighbouring
+// hash-grid cells, so a gather instruction touches a handful of cache lines instead of 64 (the ray-per-wave
+// form spreads its 64 lanes along one ray: every fine-level gather is 64 distinct lines and the kernel was bound
+// by the random-access rate of TCP/L2).  Compositing becomes a per-lane running sum — no cross-lane scan at all.
+// The per-ray SH(dir) contribution of the colour layer rides along as 8 extra k-steps (B operands built once per
+// ray group), so a pass is 480 MFMAs; the appearance term is folded into the bias by tn_field_prepare (eval).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    // v_exp_f32 / v_rcp_f32 (1 ulp each): |error| < 3e-7 absolute on a value in (0,1)
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+template <int ACT>  // 0 relu, 1 fast sigmoid
+__device__ __forceinline__ float2 out_dot_fast(const float *wrow, int h, const f32x16 (&x)[2][2]) {
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4 *>(wrow + 32 * mt + 8 * q + 4 * h);
+            const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = x[mt][0][4 * q + e], a1 = x[mt][1][4 * q + e];
+                const float v0 = ACT ? fast_sigmoid(a0) : fmaxf(a0, 0.0f);
+                const float v1 = ACT ? fast_sigmoid(a1) : fmaxf(a1, 0.0f);
+                p0 = fmaf(ww[e], v0, p0);
+                p1 = fmaf(ww[e], v1, p1);
+            }
+        }
+    }
+    return make_float2(p0, p1);
+}
+
+__global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.blob);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *A = lds + OFF_A;
+    const Space sp = make_space(a.space);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int S = a.S;
+    const long long groups = (a.R + 63) >> 6;
+    const long long stride = (long long)gridDim.x * kWaves;
+    float smin = INFINITY, smax = -INFINITY;
+    for (long long grp = (long long)blockIdx.x * kWaves + wave; grp < groups; grp += stride) {
+        const long long r = grp * 64 + lane;
+        const bool live = r < a.R;
+        const long long rc = live ? r : a.R - 1;  // idle lanes shadow the last ray (stores masked)
+        const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
+        const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
+        const float s_near = spacing_fn(a.nears[rc]), s_far = spacing_fn(a.fars[rc]);
+        const float *tb = a.spacing + tn_ws_bin(grp * 64, 0, S) + (rc - grp * 64);  // edge j at tb[j*64]
+        // SH(dir) of this lane's ray -> B operands of the 8 SH k-steps (constant over the sample loop)
+        float bs0[8], bs1[8];
+        {
+            float sx = dx, sy = dy, sz = dz;
+            if (a.sh_shifted) {
+                sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
+            }
+            float c[16];
+            sh16(sx, sy, sz, c);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) swap32(c[2 * s], c[2 * s + 1], bs0[s], bs1[s]);
+        }
+        float en = spacing_to_eucl(tb[0], s_near, s_far);
+        float accum = 0.0f, cum_w = 0.0f;  // sum of delta*sigma before this sample; running sum of weights
+        float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
+        bool med_found = false;
+        for (int i = 0; i < S; ++i) {
+            const float st = en;
+            en = spacing_to_eucl(tb[(size_t)(i + 1) * 64], s_near, s_far);
+            step = add_rn(st, en) / 2.0f;
+            float px, py, pz;
+            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                 frustum_pos(oz, dz, st, en), px, py, pz);
+            float bt0[16], bt1[16];
+#pragma unroll
+            for (int l0 = 0; l0 < L16; l0 += LG) {
+                float2 f[LG];
+                if (a.g.num_dense == 0) {
+#pragma unroll
+                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false>(a.g, l0 + q, px, py, pz);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < LG; ++q) f[q] = encode_level_any(a.g, l0 + q, px, py, pz);
+                }
+#pragma unroll
+                for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x16 h1[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                h1[mt][0] = bias_frag(lds + OFF_B_BASE1, mt, h);
+                h1[mt][1] = h1[mt][0];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float aw = A[(A_BASE1 + mt * 16 + s) * 64 + lane];
+                    MFMA32(h1[mt][0], aw, bt0[s]);
+                    MFMA32(h1[mt][1], aw, bt1[s]);
+                }
+            }
+            f32x16 g[2];
+            g[0] = bias_frag(lds + OFF_B_BASE2, 0, h);
+            g[1] = g[0];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float aw = A[(A_BASE2 + mi * 16 + s) * 64 + lane];
+                    MFMA32(g[0], aw, fmaxf(h1[mi][0][s], 0.0f));
+                    MFMA32(g[1], aw, fmaxf(h1[mi][1][s], 0.0f));
+                }
+            }
+            float raw, unused;
+            swap32(g[0][0], g[1][0], raw, unused);
+            const float dens = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+            {   // colour: [geo | SH] -> 64 -> 64 -> 3
+                f32x16 x1[2][2], x2[2][2];
+                layer_geo(A, A_C1, lds + OFF_B_C1_EVAL, lane, h, g, x1);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const float aw = A[(A_SH + mt * 8 + s) * 64 + lane];
+                        MFMA32(x1[mt][0], aw, bs0[s]);
+                        MFMA32(x1[mt][1], aw, bs1[s]);
+                    }
+                }
+                layer64(A, A_C2, lds + OFF_B_C2, lane, h, x1, x2);
+                const float *w3 = lds + OFF_W3;
+                cr = fast_sigmoid(combine_halves(out_dot_fast<0>(w3, h, x2)) + w3[192]);
+                cg = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 64, h, x2)) + w3[193]);
+                cb = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 128, h, x2)) + w3[194]);
+            }
+            {   // thermal: geo -> 64 -> 64 sigmoid -> 1
+                f32x16 x1[2][2], x2[2][2];
+                layer_geo(A, A_T1, lds + OFF_B_T1, lane, h, g, x1);
+                layer64(A, A_T2, lds + OFF_B_T2, lane, h, x1, x2);
+                const float *wt = lds + OFF_WTH;
+                th = combine_halves(out_dot_fast<1>(wt, h, x2)) + wt[64];
+            }
+            cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);  // eval renderers
+            // ---- per-lane compositing: NS get_weights + renderers, sequential along the ray ----------------
+            const float dd = mul_rn(sub_rn(en, st), dens);
+            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-accum)));
+            accum += dd;
+            cum_w += wi;
+            if (!med_found && cum_w >= 0.5f) {
+                med_found = true;
+                med = step;
+            }
+            wsum += wi;
+            wr += mul_rn(wi, cr);
+            wg += mul_rn(wi, cg);
+            wbl += mul_rn(wi, cb);
+            wth += mul_rn(wi, th);
+            wsteps += mul_rn(wi, step);
+            smin = fminf(smin, step);
+            smax = fmaxf(smax, step);
+            if (a.out_w && live) a.out_w[r * S + i] = wi;
+        }
+        if (live) {  // cr..th / step now hold the LAST sample: the "last_sample" background
+            const float bg = sub_rn(1.0f, wsum);
+            const float c0 = add_rn(wr, mul_rn(cr, bg)), c1 = add_rn(wg, mul_rn(cg, bg)), c2 = add_rn(wbl, mul_rn(cb, bg));
+            const float ct = add_rn(wth, mul_rn(th, bg));
+            a.rgb[r * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);
+            a.rgb[r * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);
+            a.rgb[r * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);
+            a.thermal[r] = fminf(fmaxf(ct, 0.0f), 1.0f);
+            a.acc[r] = wsum;
+            a.depth[r] = med_found ? med : step;  // searchsorted index clamped to the last sample
+            a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        smin = fminf(smin, __shfl_xor(smin, o, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0 && smin <= smax) {
+        atomicMin(&a.minmax[0], f2key(smin));
+        atomicMax(&a.minmax[1], f2key(smax));
+    }
+}
+
 inline bool mfma_supported(const tn_thermal_field *f) {
     return f && f->geo_feat_dim == GF && f->app_dim == APP && f->grid.num_levels == L16;
 }
@@ -457,8 +657,20 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
         return TN_ERR_LAUNCH;
+    const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 77 KB each)
+    if (!cfg->training && !out->weights[2] && !getenv("TN_FORCE_RAY_PER_WAVE")) {
+        // eval: lane = ray (64 consecutive rays per wave), coherent gathers
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_rays_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return TN_ERR_LAUNCH;
+        const long long groups = (num_rays + 63) / 64;
+        const long long need = (groups + kWaves - 1) / kWaves;
+        const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
+        hipLaunchKernelGGL(main_mfma_rays_kernel, dim3(grid), dim3(kBlock), smem, stream, a);
+        if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+        return TN_OK;
+    }
     const long long need = (num_rays + kWaves - 1) / kWaves;
-    const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 73 KB each)
     const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
     hipLaunchKernelGGL(main_mfma_kernel, dim3(grid), dim3(kBlock), smem, stream, a);
     if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;

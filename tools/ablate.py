@@ -1,0 +1,66 @@
+"""Build ablated copies of libthermonerf_hip.so (timing-only experiments; results are WRONG by construction).
+usage: python tools/ablate.py nohash nomlp coherent ...   -> /root/repo/ab_<name>.so"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "thermo_nerf_amd", "csrc")
+FLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-undefined-internal "
+         "-Wno-pass-failed -Wno-unused-variable -shared").split()
+
+
+def variant(name: str, src: str) -> str:
+    if name == "nohash":
+        return src.replace("f[q] = encode_level<false>(a.g, l0 + q, px, py, pz);",
+                           "f[q] = make_float2(px * (float)(l0 + q), py + pz);")
+    if name == "coherent":
+        return src.replace("            // ---- hash grid: 32 features",
+                           "            px = __shfl(px, 0, 64); py = __shfl(py, 0, 64); pz = __shfl(pz, 0, 64);\n"
+                           "            // ---- hash grid: 32 features")
+    if name == "nomlp":
+        i0 = src.index("            // ---- mlp_base layer 0: 32 -> 64")
+        i1 = src.index("            // ---- compositing (lane = sample)")
+        return src[:i0] + """            float accb = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accb += bt0[q] * 0.01f + bt1[q] * 0.02f;
+            const float dens = mul_rn(mul_rn(a.avg, expf(accb)), sel);
+            float cr = accb, cg = accb * 0.5f, cb = accb * 0.25f, th = accb * 2.0f;
+""" + src[i1:]
+    if name == "nothing":  # neither hash nor MLP: ray setup + compositing only
+        return variant("nomlp", variant("nohash", src))
+    if name == "nomlp_occ":  # no MLP and no LDS blob: 8 blocks/CU instead of 2 -> is the hash phase latency-bound?
+        v = variant("nomlp", src)
+        v = v.replace("for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];",
+                      "for (int i = threadIdx.x; i < 2048 / 4; i += kBlock) dst[i] = src[i];")
+        v = v.replace("lds[(a.training ? OFF_B_C1_RAW : OFF_B_C1_EVAL) + lane]", "lds[lane]")
+        v = v.replace("lds[OFF_W_SH + k * 64 + lane]", "lds[64 + lane]")
+        v = v.replace("lds[OFF_W_APP + k * 64 + lane]", "lds[128 + lane]")
+        v = v.replace("float *scratch = lds + OFF_SCRATCH + wave * 64;", "float *scratch = lds + 1024 + wave * 64;")
+        v = v.replace("const size_t smem = (size_t)LDS_FLOATS * sizeof(float);", "const size_t smem = 8192;")
+        v = v.replace("const long long cap = 256LL * 2;", "const long long cap = 256LL * 8;")
+        v = v.replace("__launch_bounds__(kBlock, 2)", "__launch_bounds__(kBlock, 8)")
+        return v
+    if name == "nomlp_8lv":  # no MLP, only the 8 finest levels hashed
+        v = variant("nomlp", src)
+        return v.replace("for (int l0 = 0; l0 < L16; l0 += LG) {", "for (int l0 = 8; l0 < L16; l0 += LG) {").replace(
+            "float bt0[16], bt1[16];", "float bt0[16] = {}, bt1[16] = {};")
+    if name == "base":
+        return src
+    raise SystemExit(f"unknown variant {name}")
+
+
+def main():
+    src = open(os.path.join(CSRC, "tn_render_mfma.hip")).read().replace(
+        '#include "tn_field_eval.h"', f'#include "{CSRC}/tn_field_eval.h"')
+    for name in sys.argv[1:]:
+        tmp = f"/tmp/abl_{name}.hip"
+        open(tmp, "w").write(variant(name, src))
+        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_prepare.hip")]
+        out = os.path.join(ROOT, f"ab_{name}.so")
+        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)
+        print("built", out)
+
+
+if __name__ == "__main__":
+    main()
