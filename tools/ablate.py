@@ -45,6 +45,22 @@ def variant(name: str, src: str) -> str:
         v = variant("nomlp", src)
         return v.replace("for (int l0 = 0; l0 < L16; l0 += LG) {", "for (int l0 = 8; l0 < L16; l0 += LG) {").replace(
             "float bt0[16], bt1[16];", "float bt0[16] = {}, bt1[16] = {};")
+    if name == "timing":  # per-section wave-cycle sums of main_mfma_rays_kernel -> 8 uint64 counters after minmax[0..1]
+        a = src.index("__global__ void __launch_bounds__(kRBlock, 2) main_mfma_rays_kernel")
+        b = src.index("inline bool mfma_supported")
+        k = src[a:b]
+        k = k.replace("    float smin = INFINITY, smax = -INFINITY;\n",
+                      "    float smin = INFINITY, smax = -INFINITY;\n    unsigned long long ts[8] = {0,0,0,0,0,0,0,0};\n", 1)
+        k = k.replace("            const float st = en;\n", "            long long t0 = clock64();\n            const float st = en;\n", 1)
+        k = k.replace("            f32x16 h1[2][2];\n", "            long long t1 = clock64(); ts[0] += t1 - t0;\n            f32x16 h1[2][2];\n", 1)
+        k = k.replace("            f32x16 g[2];\n", "            long long t2 = clock64(); ts[1] += t2 - t1;\n            f32x16 g[2];\n", 1)
+        k = k.replace("            float raw, unused;\n", "            long long t3 = clock64(); ts[2] += t3 - t2;\n            float raw, unused;\n", 1)
+        k = k.replace("            {   // thermal: geo", "            long long t4 = clock64(); ts[3] += t4 - t3;\n            {   // thermal: geo", 1)
+        k = k.replace("            cr = nan_to_num(cr); cg = nan_to_num(cg);", "            long long t5 = clock64(); ts[4] += t5 - t4;\n            cr = nan_to_num(cr); cg = nan_to_num(cg);", 1)
+        k = k.replace("            if (a.out_w && live) a.out_w[r * S + i] = wi;\n", "            if (a.out_w && live) a.out_w[r * S + i] = wi;\n            ts[5] += clock64() - t5; ts[6] += 1;\n", 1)
+        k = k.replace("    if (lane == 0 && smin <= smax) {", "    if (lane == 0) { for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<unsigned long long *>(a.minmax + 2) + q, ts[q]); }\n    if (lane == 0 && smin <= smax) {", 1)
+        assert k.count("ts[") >= 9, k.count("ts[")
+        return src[:a] + k + src[b:]
     if name == "base":
         return src
     raise SystemExit(f"unknown variant {name}")
