@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--weights", default="scene", choices=["init", "stress", "scene"])
     ap.add_argument("--dense-mb", type=int, default=0)
     ap.add_argument("--no-mfma", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+                    help="MLP product arithmetic of the field kernel (f16x3 = three f16 MFMA products per fp32 product)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per CPU-baseline repeat")
     return ap.parse_args()
@@ -114,7 +116,8 @@ def main():
     if args.chunk <= 0:
         args.chunk = args.height * args.width
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=args.chunk,
-                                 dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma)
+                                 dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma,
+                                 mlp_precision=args.precision)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box
     model.eval()
@@ -172,7 +175,8 @@ def main():
             "metric": "rays/sec (forward-only render) @ 800x800, %d samples/ray" % S,
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via 3xf16-split MFMA products",
+            "data": "synthetic",
             "config": {"workload": "config 2: synthetic %dx%d RGB+thermal scene, P=(256,96)+%d samples/ray, chunk %d, "
                                    "forward-only eval, %s weights" % (args.height, args.width, S, args.chunk, args.weights),
                        "rays_per_step_per_gpu": n_rays, "parallelism": "ray-shard x%d (one frame per rank)" % world},

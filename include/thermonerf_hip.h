@@ -101,6 +101,10 @@ typedef struct tn_thermal_field {
     float average_init_density; /* 1.0, REF thermal_field.py:86 */
     /* optional blob produced by tn_field_prepare (MFMA-fragment-ordered MLP weights); NULL = raw path */
     const float *prepared;
+    /* optional blob produced by tn_field_prepare_f16x3: every fp32 weight split into two f16 halves so that the eval
+     * field kernel can evaluate each fp32 product as three f16 MFMA products accumulated in fp32 (~2^-22 relative
+     * product error, needs |activation| < 65504).  Takes precedence over `prepared` for eval calls when non-NULL. */
+    const float *prepared_f16x3;
 } tn_thermal_field;
 
 /* ------------------------------------------------------------------------------------------------------
@@ -235,6 +239,10 @@ int tn_hashgrid_prepare(const tn_hashgrid *grid_in, tn_hashgrid *grid_out, void 
 /* MFMA-fragment-ordered copy of the main field's MLP weights. */
 size_t tn_field_prepare_bytes(const tn_thermal_field *field);
 int tn_field_prepare(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
+
+/* split-precision variant of the above (see tn_thermal_field.prepared_f16x3). */
+size_t tn_field_prepare_f16x3_bytes(const tn_thermal_field *field);
+int tn_field_prepare_f16x3(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
 
 /* library identification: returns a static string "thermonerf_hip <version> gfx950". */
 const char *tn_version(void);

@@ -254,6 +254,7 @@ def test_get_outputs_eval(kind, S, impl):
     gm, sd, ocfg = gpu_model(kind, S)
     fused = impl
     gm.config.fused, gm.config.use_mfma = IMPLS[impl]
+    gm.config.mlp_precision = "f32"
     o, d = helpers.rays(16, 16, view=S % 8)
     want = H.get_outputs(sd, o, d, None, ocfg)
     with torch.no_grad():
@@ -261,6 +262,28 @@ def test_get_outputs_eval(kind, S, impl):
     for k in ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal"):
         assert got[k].shape == want[k].shape, k
     check_outputs(got, want, f"{kind}/S{S}/fused={fused}")
+
+
+@pytest.mark.parametrize("kind", ["init", "stress", "scene"])
+@pytest.mark.parametrize("S", [48, 64, 192])
+def test_get_outputs_eval_f16x3_split(kind, S):
+    """Opt-in split-precision field kernel (each fp32 product = three f16 MFMA products, fp32 accumulate): held to
+    the SAME tolerances as the exact-fp32 kernels, and compared against the fp32 MFMA kernel on the same rays."""
+    gm, sd, ocfg = gpu_model(kind, S)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f16x3"
+    _, _, fld = gm._c_structs()
+    assert fld.prepared_f16x3, "tn_field_prepare_f16x3 produced no blob"
+    o, d = helpers.rays(20, 20, view=(S + 3) % 8)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+        gm.config.mlp_precision = "f32"
+        ref = gm(bundle(o, d))
+    check_outputs(got, want, f"f16x3 {kind}/S{S}")
+    for k in ("rgb", "thermal"):
+        d_split = (got[k].cpu() - want[k]).abs().max().item()
+        d_f32 = (ref[k].cpu() - want[k]).abs().max().item()
+        assert d_split <= max(8 * d_f32, 5e-6), f"{k}: split {d_split:.2e} vs fp32 kernel {d_f32:.2e}"
 
 
 @pytest.mark.parametrize("impl", list(IMPLS))

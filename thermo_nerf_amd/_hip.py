@@ -89,6 +89,7 @@ class tn_thermal_field(C.Structure):
         ("space", tn_space),
         ("average_init_density", C.c_float),
         ("prepared", C.c_void_p),
+        ("prepared_f16x3", C.c_void_p),
     ]
 
 
@@ -163,6 +164,8 @@ SIGNATURES = {
     "tn_hashgrid_prepare": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_hashgrid), _vp, _sz, _vp]),
     "tn_field_prepare_bytes": (_sz, [C.POINTER(tn_thermal_field)]),
     "tn_field_prepare": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _sz, _vp]),
+    "tn_field_prepare_f16x3_bytes": (_sz, [C.POINTER(tn_thermal_field)]),
+    "tn_field_prepare_f16x3": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _sz, _vp]),
     "tn_version": (C.c_char_p, []),
 }
 

@@ -18,6 +18,10 @@ namespace tn {
 int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                      const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
                      hipStream_t stream);
+// implemented in tn_render_h3.hip
+int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                   hipStream_t stream);
 }
 
 namespace {
@@ -447,7 +451,9 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
     const float *ws_spacing = reinterpret_cast<const float *>(workspace);
     unsigned *minmax = ws_minmax(workspace, num_rays, S);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, minmax);
-    if (field->prepared) {
+    if (field->prepared_f16x3 && !cfg->training && !out->weights[2]) {
+        TN_TRY(launch_main_h3(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
+    } else if (field->prepared) {
         TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
     } else {
         MainArgs ma;

@@ -1,0 +1,503 @@
+// main_h3_rays_kernel — the eval field kernel (lane = ray, see tn_render_mfma.hip) with every fp32 product of the
+// five MLP layers evaluated as THREE f16 MFMA products, accumulated in fp32:
+//
+//     a = a_h + a_l,  w = w_h + w_l   (a_h = f16(a), a_l = f16(a - a_h); weights split once in tn_field_prepare_f16x3)
+//     a.w ~= a_h.w_h + a_l.w_h + a_h.w_l            (the dropped a_l.w_l term is <= 2^-22 |a.w|)
+//
+// Each f16 x f16 product is exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in fp32, so the result carries a
+// ~2^-22 relative product error (fp32 MFMA: 2^-24) — "f32 via 3 x f16 split", NOT an f16 network.  It needs
+// |activation| < 65504 (f16 range).  Matrix-pipe time per 64 samples drops from 480 x 64 = 30.7 k cycles
+// (v_mfma_f32_32x32x2_f32) to 180 x 32 = 5.8 k cycles; the price is ~3 VALU ops per activation for the split.
+//
+// Same transposed chain as the fp32 kernel: weights are the A operand, activations the B operand (lane <-> ray), a
+// layer's accumulator registers feed the next layer's B operand directly (8 consecutive registers = one K=16 step:
+// lane (j,h) register 8q+e holds feature 32*mi + 16q + (e&3) + 8(e>>2) + 4h, the order baked into the A fragments).
+#include "tn_field_eval.h"
+
+using namespace tn;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / TN_WAVE;
+constexpr int GF = 15, APP = 32, L16 = 16, IN0 = 16 + GF + APP;
+constexpr int LG = 4;
+
+// ---- blob / LDS layout ------------------------------------------------------------------------------------
+// A fragments: [30 combos][64 lanes][hi: 8 x f16 | lo: 8 x f16] = 32 B per lane
+constexpr int C_BASE1 = 0, C_BASE2 = 4, C_C1 = 8, C_T1 = 12, C_C2 = 14, C_T2 = 22, N_COMBOS = 30;
+constexpr int H_A_FLOATS = N_COMBOS * 64 * 8;  // 32 B = 8 floats per lane
+constexpr int HOFF_B_BASE1 = H_A_FLOATS;        // [64]
+constexpr int HOFF_B_BASE2 = HOFF_B_BASE1 + 64; // [32]
+constexpr int HOFF_B_C1 = HOFF_B_BASE2 + 32;    // [64] eval bias incl. the folded appearance term
+constexpr int HOFF_B_T1 = HOFF_B_C1 + 64;
+constexpr int HOFF_B_C2 = HOFF_B_T1 + 64;
+constexpr int HOFF_B_T2 = HOFF_B_C2 + 64;
+constexpr int HOFF_W3 = HOFF_B_T2 + 64;         // [3][64] + [4]
+constexpr int HOFF_WTH = HOFF_W3 + 196;         // [64] + [4]
+constexpr int H_BLOB_FLOATS = HOFF_WTH + 68;    // 15976 floats = 63 904 B
+static_assert(H_BLOB_FLOATS % 4 == 0, "blob must be float4-copyable");
+
+__host__ __device__ inline int krow(int q, int e, int h) { return 16 * q + (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+struct RawField {
+    const float *b0w, *b0b, *b1w, *b1b, *h0w, *h0b, *h1w, *h1b, *h2w, *h2b, *t0w, *t0b, *t1w, *t1b, *thw, *thb;
+    const float *appearance;
+    int num_images, use_avg;
+};
+
+__device__ __forceinline__ float frag_weight(const RawField &w, int combo, int i, int h, int e) {
+    if (combo < C_BASE2) {  // mlp_base layer 0 [64,32]: natural feature order 16ks + 8h + e
+        const int mt = combo >> 1, ks = combo & 1;
+        return w.b0w[(i + 32 * mt) * 32 + 16 * ks + 8 * h + e];
+    }
+    if (combo < C_C1) {  // mlp_base layer 1 [16,64]
+        const int ks = combo - C_BASE2;
+        return i < 1 + GF ? w.b1w[i * 64 + 32 * (ks >> 1) + krow(ks & 1, e, h)] : 0.0f;
+    }
+    if (combo < C_T1) {  // mlp_head layer 0: ks 0 = geo (accumulator rows, row 0 = raw density -> 0), ks 1 = SH comps
+        const int c = combo - C_C1, mt = c >> 1, ks = c & 1;
+        if (ks == 0) {
+            const int row = krow(0, e, h);
+            return row >= 1 ? w.h0w[(i + 32 * mt) * IN0 + 16 + row - 1] : 0.0f;
+        }
+        return w.h0w[(i + 32 * mt) * IN0 + 8 * h + e];
+    }
+    if (combo < C_C2) {  // mlp_thermal layer 0 [64,15]
+        const int mt = combo - C_T1, row = krow(0, e, h);
+        return row >= 1 ? w.t0w[(i + 32 * mt) * GF + row - 1] : 0.0f;
+    }
+    const bool thermal = combo >= C_T2;
+    const int c = combo - (thermal ? C_T2 : C_C2), mt = c >> 2, ks = c & 3;
+    const float *m = thermal ? w.t1w : w.h1w;
+    return m[(i + 32 * mt) * 64 + 32 * (ks >> 1) + krow(ks & 1, e, h)];
+}
+
+__global__ void field_prepare_h3_kernel(RawField w, float *__restrict__ blob) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < N_COMBOS * 64 * 8) {  // one thread per (combo, lane, e): writes the hi and the lo half
+        const int e = idx & 7, lane = (idx >> 3) & 63, combo = idx >> 9;
+        const float v = frag_weight(w, combo, lane & 31, lane >> 5, e);
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16 *dst = reinterpret_cast<_Float16 *>(blob) + ((size_t)(combo * 64 + lane)) * 16;
+        dst[e] = hi;
+        dst[8 + e] = lo;
+        return;
+    }
+    const int j = idx - N_COMBOS * 64 * 8 + H_A_FLOATS;
+    if (j >= H_BLOB_FLOATS) return;
+    float v = 0.0f;
+    if (j < HOFF_B_BASE2) v = w.b0b[j - HOFF_B_BASE1];
+    else if (j < HOFF_B_C1) { const int f = j - HOFF_B_BASE2; v = f < 1 + GF ? w.b1b[f] : 0.0f; }
+    else if (j < HOFF_B_T1) {
+        const int f = j - HOFF_B_C1;
+        v = w.h0b[f];
+        if (w.use_avg) {  // REF thermal_field.py:128-132
+            for (int k = 0; k < APP; ++k) {
+                float m = 0.0f;
+                for (int im = 0; im < w.num_images; ++im) m += w.appearance[im * APP + k];
+                v = fmaf(w.h0w[f * IN0 + 16 + GF + k], m / (float)w.num_images, v);
+            }
+        }
+    }
+    else if (j < HOFF_B_C2) v = w.t0b[j - HOFF_B_T1];
+    else if (j < HOFF_B_T2) v = w.h1b[j - HOFF_B_C2];
+    else if (j < HOFF_W3) v = w.t1b[j - HOFF_B_T2];
+    else if (j < HOFF_WTH) { const int e = j - HOFF_W3; v = e < 192 ? w.h2w[e] : (e < 195 ? w.h2b[e - 192] : 0.0f); }
+    else { const int e = j - HOFF_WTH; v = e < 64 ? w.thw[e] : (e == 64 ? w.thb[0] : 0.0f); }
+    blob[j] = v;
+}
+
+// ---- device helpers ------------------------------------------------------------------------------------------
+struct HL {
+    v8h hi, lo;
+};
+
+#define MFMAH(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (acc), 0, 0, 0)
+
+__device__ __forceinline__ void mma3(f32x16 &acc, const HL &a, const HL &b) {
+    MFMAH(acc, a.lo, b.hi);
+    MFMAH(acc, a.hi, b.lo);
+    MFMAH(acc, a.hi, b.hi);
+}
+
+__device__ __forceinline__ HL load_a(const float *lds, int combo, int lane) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(lds) + (size_t)(combo * 64 + lane) * 2;
+    HL a;
+    a.hi = __builtin_bit_cast(v8h, p[0]);
+    a.lo = __builtin_bit_cast(v8h, p[1]);
+    return a;
+}
+
+template <bool RELU>
+__device__ __forceinline__ HL split8(const f32x16 &x, int q) {
+    HL r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = x[8 * q + e];
+        if (RELU) v = fmaxf(v, 0.0f);
+        const _Float16 hh = (_Float16)v;
+        r.hi[e] = hh;
+        r.lo[e] = (_Float16)(v - (float)hh);
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 bias_frag(const float *bias, int mt, int h) {
+    f32x16 v;
+    const float4 q0 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 4 * h);
+    const float4 q1 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 8 + 4 * h);
+    const float4 q2 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 16 + 4 * h);
+    const float4 q3 = *reinterpret_cast<const float4 *>(bias + 32 * mt + 24 + 4 * h);
+    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+    v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w;
+    v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
+    return v;
+}
+
+__device__ __forceinline__ void swap32u(unsigned a, unsigned b, unsigned &lo, unsigned &hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    lo = r[0];
+    hi = r[1];
+}
+__device__ __forceinline__ void swap32(float a, float b, float &lo, float &hi) {
+    unsigned l, hh;
+    swap32u(__float_as_uint(a), __float_as_uint(b), l, hh);
+    lo = __uint_as_float(l);
+    hi = __uint_as_float(hh);
+}
+
+// 16 per-lane values (this lane's ray) -> B operands of one K=16 step for both N tiles.
+// in: natural order v[0..15]; lane (j,h) of tile t ends up holding v[8h + e] of ray (32t + j).
+__device__ __forceinline__ void pack_step(const float (&v)[16], HL &t0, HL &t1) {
+    unsigned ph[8], pl[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const _Float16 h0 = (_Float16)v[2 * m], h1 = (_Float16)v[2 * m + 1];
+        const _Float16 l0 = (_Float16)(v[2 * m] - (float)h0), l1 = (_Float16)(v[2 * m + 1] - (float)h1);
+        ph[m] = __builtin_bit_cast(unsigned, v2h{h0, h1});
+        pl[m] = __builtin_bit_cast(unsigned, v2h{l0, l1});
+    }
+    unsigned a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // lower half keeps packs 0..3 (features 0..7), upper half gets packs 4..7 (8..15)
+        swap32u(ph[q], ph[4 + q], a0[q], a1[q]);
+        swap32u(pl[q], pl[4 + q], b0[q], b1[q]);
+    }
+    t0.hi = __builtin_bit_cast(v8h, uint4{a0[0], a0[1], a0[2], a0[3]});
+    t1.hi = __builtin_bit_cast(v8h, uint4{a1[0], a1[1], a1[2], a1[3]});
+    t0.lo = __builtin_bit_cast(v8h, uint4{b0[0], b0[1], b0[2], b0[3]});
+    t1.lo = __builtin_bit_cast(v8h, uint4{b1[0], b1[1], b1[2], b1[3]});
+}
+
+// one 64 -> 64 layer from relu(in): out[mt][nt] = bias + sum_ks A[mt][ks] x B[nt][ks]
+__device__ __forceinline__ void layer64(const float *lds, int combo0, const float *bias, int lane, int h,
+                                        const f32x16 (&in)[2][2], f32x16 (&out)[2][2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        out[mt][0] = bias_frag(bias, mt, h);
+        out[mt][1] = out[mt][0];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const HL b0 = split8<true>(in[ks >> 1][0], ks & 1), b1 = split8<true>(in[ks >> 1][1], ks & 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const HL a = load_a(lds, combo0 + mt * 4 + ks, lane);
+            mma3(out[mt][0], a, b0);
+            mma3(out[mt][1], a, b1);
+        }
+    }
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+template <int ACT>
+__device__ __forceinline__ float2 out_dot_fast(const float *wrow, int h, const f32x16 (&x)[2][2]) {
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4 *>(wrow + 32 * mt + 8 * q + 4 * h);
+            const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = x[mt][0][4 * q + e], a1 = x[mt][1][4 * q + e];
+                const float v0 = ACT ? fast_sigmoid(a0) : fmaxf(a0, 0.0f);
+                const float v1 = ACT ? fast_sigmoid(a1) : fmaxf(a1, 0.0f);
+                p0 = fmaf(ww[e], v0, p0);
+                p1 = fmaf(ww[e], v1, p1);
+            }
+        }
+    }
+    return make_float2(p0, p1);
+}
+
+__device__ __forceinline__ float combine_halves(float2 p) {
+    float lo, hi;
+    swap32(p.x, p.y, lo, hi);
+    return lo + hi;
+}
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct H3Args {
+    Grid g;
+    tn_space space;
+    const float *blob;
+    float avg;
+    int sh_shifted;
+    const float *origins, *dirs, *nears, *fars;
+    const float *spacing;
+    long long R;
+    int S;
+    float *rgb, *acc, *depth, *expected, *thermal;
+    unsigned *minmax;
+};
+
+__global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.blob);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < H_BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const Space sp = make_space(a.space);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int S = a.S;
+    const long long groups = (a.R + 63) >> 6;
+    const long long stride = (long long)gridDim.x * kWaves;
+    float smin = INFINITY, smax = -INFINITY;
+    for (long long grp = (long long)blockIdx.x * kWaves + wave; grp < groups; grp += stride) {
+        const long long r = grp * 64 + lane;
+        const bool live = r < a.R;
+        const long long rc = live ? r : a.R - 1;
+        const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
+        const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
+        const float s_near = spacing_fn(a.nears[rc]), s_far = spacing_fn(a.fars[rc]);
+        const float *tb = a.spacing + tn_ws_bin(grp * 64, 0, S) + (rc - grp * 64);
+        HL sh0, sh1;  // SH(dir) of this lane's ray as the K=16 step of the colour layer (constant over samples)
+        {
+            float sx = dx, sy = dy, sz = dz;
+            if (a.sh_shifted) {
+                sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
+            }
+            float c[16];
+            sh16(sx, sy, sz, c);
+            pack_step(c, sh0, sh1);
+        }
+        float en = spacing_to_eucl(tb[0], s_near, s_far);
+        float accum = 0.0f, cum_w = 0.0f;
+        float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
+        bool med_found = false;
+        for (int i = 0; i < S; ++i) {
+            const float st = en;
+            en = spacing_to_eucl(tb[(size_t)(i + 1) * 64], s_near, s_far);
+            step = add_rn(st, en) / 2.0f;
+            float px, py, pz;
+            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                 frustum_pos(oz, dz, st, en), px, py, pz);
+            // ---- hash grid -> two K=16 steps of B operands per N tile --------------------------------------
+            HL e0[2], e1[2];  // [ks] for tile 0 / tile 1
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[16];
+#pragma unroll
+                for (int l0 = 0; l0 < 8; l0 += LG) {
+                    float2 f[LG];
+                    if (a.g.num_dense == 0) {
+#pragma unroll
+                        for (int q = 0; q < LG; ++q) f[q] = encode_level<false>(a.g, 8 * ks + l0 + q, px, py, pz);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < LG; ++q) f[q] = encode_level_any(a.g, 8 * ks + l0 + q, px, py, pz);
+                    }
+#pragma unroll
+                    for (int q = 0; q < LG; ++q) {
+                        v[2 * (l0 + q)] = f[q].x;
+                        v[2 * (l0 + q) + 1] = f[q].y;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pack_step(v, e0[ks], e1[ks]);
+            }
+            // ---- mlp_base layer 0: 32 -> 64 ---------------------------------------------------------------
+            f32x16 h1[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                h1[mt][0] = bias_frag(lds + HOFF_B_BASE1, mt, h);
+                h1[mt][1] = h1[mt][0];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const HL aw = load_a(lds, C_BASE1 + mt * 2 + ks, lane);
+                    mma3(h1[mt][0], aw, e0[ks]);
+                    mma3(h1[mt][1], aw, e1[ks]);
+                }
+            }
+            // ---- mlp_base layer 1: 64 -> 16 ---------------------------------------------------------------
+            f32x16 g[2];
+            g[0] = bias_frag(lds + HOFF_B_BASE2, 0, h);
+            g[1] = g[0];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const HL aw = load_a(lds, C_BASE2 + ks, lane);
+                mma3(g[0], aw, split8<true>(h1[ks >> 1][0], ks & 1));
+                mma3(g[1], aw, split8<true>(h1[ks >> 1][1], ks & 1));
+            }
+            float raw, unused;
+            swap32(g[0][0], g[1][0], raw, unused);
+            const float dens = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+            const HL g0 = split8<false>(g[0], 0), g1 = split8<false>(g[1], 0);  // geo rows (row 0 has zero weight)
+            {   // colour: [geo | SH] -> 64 -> 64 -> 3
+                f32x16 x1[2][2], x2[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    x1[mt][0] = bias_frag(lds + HOFF_B_C1, mt, h);
+                    x1[mt][1] = x1[mt][0];
+                    const HL ag = load_a(lds, C_C1 + mt * 2, lane), as = load_a(lds, C_C1 + mt * 2 + 1, lane);
+                    mma3(x1[mt][0], ag, g0);
+                    mma3(x1[mt][1], ag, g1);
+                    mma3(x1[mt][0], as, sh0);
+                    mma3(x1[mt][1], as, sh1);
+                }
+                layer64(lds, C_C2, lds + HOFF_B_C2, lane, h, x1, x2);
+                const float *w3 = lds + HOFF_W3;
+                cr = fast_sigmoid(combine_halves(out_dot_fast<0>(w3, h, x2)) + w3[192]);
+                cg = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 64, h, x2)) + w3[193]);
+                cb = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 128, h, x2)) + w3[194]);
+            }
+            {   // thermal: geo -> 64 -> 64 sigmoid -> 1
+                f32x16 x1[2][2], x2[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    x1[mt][0] = bias_frag(lds + HOFF_B_T1, mt, h);
+                    x1[mt][1] = x1[mt][0];
+                    const HL ag = load_a(lds, C_T1 + mt, lane);
+                    mma3(x1[mt][0], ag, g0);
+                    mma3(x1[mt][1], ag, g1);
+                }
+                layer64(lds, C_T2, lds + HOFF_B_T2, lane, h, x1, x2);
+                const float *wt = lds + HOFF_WTH;
+                th = combine_halves(out_dot_fast<1>(wt, h, x2)) + wt[64];
+            }
+            cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);
+            const float dd = mul_rn(sub_rn(en, st), dens);
+            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-accum)));
+            accum += dd;
+            cum_w += wi;
+            if (!med_found && cum_w >= 0.5f) {
+                med_found = true;
+                med = step;
+            }
+            wsum += wi;
+            wr += mul_rn(wi, cr);
+            wg += mul_rn(wi, cg);
+            wbl += mul_rn(wi, cb);
+            wth += mul_rn(wi, th);
+            wsteps += mul_rn(wi, step);
+            smin = fminf(smin, step);
+            smax = fmaxf(smax, step);
+        }
+        if (live) {
+            const float bg = sub_rn(1.0f, wsum);
+            const float c0 = add_rn(wr, mul_rn(cr, bg)), c1 = add_rn(wg, mul_rn(cg, bg)), c2 = add_rn(wbl, mul_rn(cb, bg));
+            const float ct = add_rn(wth, mul_rn(th, bg));
+            a.rgb[r * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);
+            a.rgb[r * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);
+            a.rgb[r * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);
+            a.thermal[r] = fminf(fmaxf(ct, 0.0f), 1.0f);
+            a.acc[r] = wsum;
+            a.depth[r] = med_found ? med : step;
+            a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        smin = fminf(smin, __shfl_xor(smin, o, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0 && smin <= smax) {
+        atomicMin(&a.minmax[0], f2key(smin));
+        atomicMax(&a.minmax[1], f2key(smax));
+    }
+}
+
+inline bool h3_supported(const tn_thermal_field *f) {
+    return f && f->geo_feat_dim == GF && f->app_dim == APP && f->grid.num_levels == L16;
+}
+
+}  // namespace
+
+namespace tn {
+
+int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                   hipStream_t stream) {
+    if (!h3_supported(field) || !field->prepared_f16x3 || cfg->training) return TN_ERR_UNSUPPORTED;
+    H3Args a;
+    a.g = tn_make_grid(field->grid);
+    a.space = field->space;
+    a.blob = field->prepared_f16x3;
+    a.avg = field->average_init_density;
+    a.sh_shifted = field->sh_shifted;
+    a.origins = in->origins; a.dirs = in->directions; a.nears = in->nears; a.fars = in->fars;
+    a.spacing = spacing_ws;
+    a.R = num_rays; a.S = cfg->num_nerf_samples;
+    a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
+    a.thermal = out->thermal; a.minmax = minmax;
+    const size_t smem = (size_t)H_BLOB_FLOATS * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_h3_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+        return TN_ERR_LAUNCH;
+    const long long groups = (num_rays + 63) / 64;
+    const long long need = (groups + kWaves - 1) / kWaves;
+    const long long cap = 256LL * 2;
+    const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
+    hipLaunchKernelGGL(main_h3_rays_kernel, dim3(grid), dim3(kBlock), smem, stream, a);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
+}  // namespace tn
+
+extern "C" {
+
+size_t tn_field_prepare_f16x3_bytes(const tn_thermal_field *field) {
+    if (!h3_supported(field) || tn_check_thermal_field(field) != TN_OK) return 0;
+    return (size_t)H_BLOB_FLOATS * sizeof(float);
+}
+
+int tn_field_prepare_f16x3(const tn_thermal_field *f, void *prepared_dev, size_t bytes, void *stream) {
+    if (!f || !prepared_dev) return TN_ERR_NULL;
+    TN_TRY(tn_check_thermal_field(f));
+    if (!h3_supported(f)) return TN_ERR_UNSUPPORTED;
+    if (bytes < (size_t)H_BLOB_FLOATS * sizeof(float)) return TN_ERR_WORKSPACE;
+    RawField w;
+    w.b0w = f->base0.weight; w.b0b = f->base0.bias; w.b1w = f->base1.weight; w.b1b = f->base1.bias;
+    w.h0w = f->head0.weight; w.h0b = f->head0.bias; w.h1w = f->head1.weight; w.h1b = f->head1.bias;
+    w.h2w = f->head2.weight; w.h2b = f->head2.bias; w.t0w = f->th0.weight; w.t0b = f->th0.bias;
+    w.t1w = f->th1.weight; w.t1b = f->th1.bias; w.thw = f->thead.weight; w.thb = f->thead.bias;
+    w.appearance = f->appearance; w.num_images = f->num_images; w.use_avg = f->use_average_appearance;
+    const int threads = N_COMBOS * 64 * 8 + (H_BLOB_FLOATS - H_A_FLOATS);
+    hipLaunchKernelGGL(field_prepare_h3_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<float *>(prepared_dev));
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
+}  // extern "C"

@@ -74,6 +74,9 @@ class NerfactoModelConfig:
     """>0: re-lay the coarse hash levels densely within this budget (layout only, bit-identical)."""
     use_mfma: bool = True
     """Use the MFMA form of the main-field kernel when the library provides it."""
+    mlp_precision: Literal["f32", "f16x3"] = "f32"
+    """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "f16x3": eval-only, every fp32 product evaluated as three f16
+    MFMA products accumulated in fp32 (~2^-22 relative product error; activations must stay below 65504)."""
 
     def setup(self, **kwargs) -> Any:
         return self._target(self, **kwargs)

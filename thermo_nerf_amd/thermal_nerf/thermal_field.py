@@ -88,10 +88,11 @@ class ThermalNerfactoTField(nn.Module):
         self.pass_rgb_gradients = True
         self.dense_budget_bytes = 0
         self._prepared: Optional[Tensor] = None
+        self._prepared_h3: Optional[Tensor] = None
         self._prepared_key = None
 
     # ------------------------------------------------------------------------------------------------
-    def c_struct(self, prepare: bool = False) -> _hip.tn_thermal_field:
+    def c_struct(self, prepare: bool = False, precision: str = "f32") -> _hip.tn_thermal_field:
         f = _hip.tn_thermal_field()
         f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes)
         f.base0 = _hip.make_linear(self.mlp_base.mlp.layers[0])
@@ -112,19 +113,26 @@ class ThermalNerfactoTField(nn.Module):
         f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb)
         f.average_init_density = float(self.average_init_density)
         f.prepared = None
+        f.prepared_f16x3 = None
         if prepare:
             lib = _hip.load()
             key = tuple((p.data_ptr(), p._version) for p in self.parameters())
             if self._prepared_key != key:
+                self._prepared, self._prepared_h3 = None, None
                 nbytes = lib.tn_field_prepare_bytes(f)
                 if nbytes > 0:
                     self._prepared = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
                     _hip.check(lib.tn_field_prepare(f, self._prepared.data_ptr(), nbytes, _hip.current_stream()),
                                "tn_field_prepare")
-                else:
-                    self._prepared = None
+                nbytes = lib.tn_field_prepare_f16x3_bytes(f)
+                if nbytes > 0:
+                    self._prepared_h3 = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
+                    _hip.check(lib.tn_field_prepare_f16x3(f, self._prepared_h3.data_ptr(), nbytes, _hip.current_stream()),
+                               "tn_field_prepare_f16x3")
                 self._prepared_key = key
             f.prepared = None if self._prepared is None else self._prepared.data_ptr()
+            if precision == "f16x3":
+                f.prepared_f16x3 = None if self._prepared_h3 is None else self._prepared_h3.data_ptr()
         return f
 
     # ------------------------------------------------------------------------------------------------

@@ -187,10 +187,11 @@ class ThermalNerfModel(ThermalNerfactoModel):
 
     # --- fused: one C-ABI call ------------------------------------------------------------------------
     def _c_structs(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.config.use_mfma,)
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.config.use_mfma,
+                                                                              self.config.mlp_precision)
         if self._struct_key != key:
             self._structs = (self.proposal_networks[0].c_struct(), self.proposal_networks[1].c_struct(),
-                             self.field.c_struct(prepare=self.config.use_mfma))
+                             self.field.c_struct(prepare=self.config.use_mfma, precision=self.config.mlp_precision))
             self._struct_key = key
         return self._structs
 
