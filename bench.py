@@ -200,6 +200,30 @@ def main():
                               "thermal_mae": float((got_th - want["thermal"]).abs().mean()),
                               "rgb_psnr_db_vs_oracle": float(10 * torch.log10(1.0 / ((got_rgb - want["rgb"]) ** 2).mean().clamp_min(1e-20)))}
             line["speedup_vs_cpu"] = value / base["value"]
+            if args.precision == "f32":
+                # secondary line: the opt-in split-precision field kernel on the same frame (NOT the headline value)
+                model.config.mlp_precision = "f16x3"
+                engine.render(o, d, out=out)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    engine.render(o, d, out=out)
+                torch.cuda.synchronize()
+                v = 3 * n_rays / (time.perf_counter() - t1)
+                g_rgb, g_th = out["rgb"][idx.to(dev)].cpu(), out["thermal"][idx.to(dev)].cpu()
+                line["variants"] = {"f16x3": {
+                    "what": "field MLP products as 3 f16 MFMA products each, fp32 accumulate (mlp_precision=f16x3)",
+                    "value": v, "unit": "rays/s", "rgb_mae": float((g_rgb - want["rgb"]).abs().mean()),
+                    "thermal_mae": float((g_th - want["thermal"]).abs().mean())}}
+                model.config.mlp_precision = "f32"
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command (FETCH_SIZE +
+            # WRITE_SIZE of the dominant kernel, scaled to this launch size); see profiles/ for the raw counters
+            t = json.load(open(pmc)).get(dominant if args.precision == "f32" else dominant + "_f16x3")
+            if t:
+                line["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1024.0 * rays_per_launch / t["rays_per_launch"]
+                line["roofline"]["traffic_source"] = t["source"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
