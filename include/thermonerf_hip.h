@@ -111,6 +111,14 @@ typedef struct tn_thermal_field {
  * Per-sample entry points (the Field plugin surface)
  * ---------------------------------------------------------------------------------------------------- */
 
+/* NS Cameras.generate_rays for one perspective camera, as called by the reference's harnesses
+ * [REF thermo_nerf/render/renderer.py:182-184; thermo_nerf/evaluator/evaluator.py:68-70]: pixels
+ * [first_pixel, first_pixel + num_pixels) of the row-major H x W image (pixel centres at +0.5) ->
+ * origins [n,3], unit directions [n,3], pixel_area [n] (may be NULL).  c2w_host = 12 HOST floats, row-major [3,4]. */
+int tn_generate_rays(const float *c2w_host, float fx, float fy, float cx, float cy, int32_t height, int32_t width,
+                     int64_t first_pixel, int64_t num_pixels, float *origins, float *directions, float *pixel_area,
+                     void *stream);
+
 /* NS Frustums.get_positions: pos = origins + directions * (starts + ends) / 2.
  * origins/directions [R,3]; starts/ends [R,n]; positions out [R,n,3]. */
 int tn_frustum_positions(const float *origins, const float *directions, const float *starts, const float *ends,

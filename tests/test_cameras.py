@@ -1,0 +1,76 @@
+"""Camera path loading (CPU, against the reference's own trajectory fixture) and on-device ray generation (GPU,
+against the oracle restatement of nerfstudio's Cameras.generate_rays)."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import cameras as OC
+from thermo_nerf_amd import cameras as C
+
+
+def test_camera_path_fixture_loads_96_cameras(golden_dir):
+    """The reference's own assertion on this file: 96 cameras [REF tests/test_renderer.py:65-69]."""
+    cams = C.load_cameras(os.path.join(golden_dir, "camera_path_facade_2.json"))
+    assert cams.size == 96 and len(cams) == 96
+    assert (cams.height, cams.width) == (1080, 1920)
+    assert cams.camera_to_worlds.shape == (96, 3, 4)
+    want_f = 540.0 / math.tan(math.radians(50.0) / 2.0)
+    assert abs(float(cams.fx[0]) - want_f) < 1e-3 and float(cams.fx[0]) == float(cams.fy[0])
+    assert (cams.cx, cams.cy) == (960.0, 540.0)
+    half = C.load_cameras(os.path.join(golden_dir, "camera_path_facade_2.json"), 0.5)
+    assert (half.height, half.width) == (540, 960) and abs(float(half.fx[0]) - want_f / 2) < 1e-3
+
+
+def test_frame_metrics_uses_reference_mae(golden_dir):
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "mae_thermal.npz"))
+    gt, pred = torch.from_numpy(g["gt"])[0, 0, :, :, None], torch.from_numpy(g["pred"])[0, 0, :, :, None]
+    m = C.frame_metrics({"rgb": pred.repeat(1, 1, 3), "thermal": pred}, gt.repeat(1, 1, 3), gt, float(g["tmax"]),
+                        float(g["tmin"]), cold=False, threshold=0.5)
+    assert abs(m["mae_thermal"] - float(g["cold0_thrNone"])) < 1e-5
+    assert abs(m["mae_thermal_foreground"] - float(g["cold0_thr0.5"])) < 1e-5
+    assert abs(m["psnr"] - m["psnr_thermal"]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 37, 95])
+def test_generate_rays_matches_oracle(golden_dir, idx):
+    cams = C.load_cameras(os.path.join(golden_dir, "camera_path_facade_2.json"), 0.125)  # 135 x 240
+    rb = cams.generate_rays(idx, device="cuda:0")
+    o, d, a = OC.generate_rays(cams.camera_to_worlds[idx], float(cams.fx[idx]), float(cams.fy[idx]), cams.cx, cams.cy,
+                               cams.height, cams.width)
+    assert rb.origins.shape == (cams.height, cams.width, 3)
+    assert torch.equal(rb.origins.cpu(), o.contiguous())
+    assert (rb.directions.cpu() - d).abs().max().item() < 2e-7
+    assert ((rb.pixel_area.cpu() - a).abs() / a).max().item() < 2e-3  # difference of nearly equal unit vectors
+    assert (rb.directions.norm(dim=-1) - 1).abs().max().item() < 1e-6
+    assert int(rb.camera_indices[0, 0, 0]) == idx
+    # a row block equals the same rows of the full frame (what each rank generates when a frame is sharded)
+    part = cams.generate_rays(idx, device="cuda:0", rows=(40, 77))
+    assert torch.equal(part.directions, rb.directions[40:77])
+
+
+@pytest.mark.gpu
+def test_render_camera_path_frame_end_to_end(golden_dir):
+    """cameras -> rays on device -> model.get_outputs_for_camera_ray_bundle == oracle on the same camera."""
+    import copy
+    from oracle import hotpath as H
+    from tests import helpers
+
+    cams = C.load_cameras(os.path.join(golden_dir, "camera_path_facade_2.json"), 1.0 / 30)  # 36 x 64
+    model, sd, ocfg = helpers.build("scene", 48)
+    gm = copy.deepcopy(model).to("cuda:0").eval()
+    gm.config.eval_num_rays_per_chunk = 1000
+    rb = cams.generate_rays(5, device="cuda:0")
+    got = gm.get_outputs_for_camera_ray_bundle(rb)
+    o, d, _ = OC.generate_rays(cams.camera_to_worlds[5], float(cams.fx[5]), float(cams.fy[5]), cams.cx, cams.cy,
+                               cams.height, cams.width)
+    want = H.get_outputs_for_camera_ray_bundle(sd, o.contiguous(), d.contiguous(), ocfg, chunk=1000)
+    assert got["rgb"].shape == (cams.height, cams.width, 3)
+    assert (got["rgb"].cpu() - want["rgb"]).abs().mean().item() < 1e-4
+    assert (got["thermal"].cpu() - want["thermal"]).abs().mean().item() < 1e-4
+    m = C.frame_metrics(got, want["rgb"], want["thermal"], 33.085, 13.896)
+    assert m["psnr"] > 60 and m["mae_thermal"] < 2e-3  # degrees C over a 19.2 C span

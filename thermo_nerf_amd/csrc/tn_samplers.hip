@@ -243,11 +243,72 @@ __global__ void depth_clip_kernel(float *__restrict__ expected, long long num_ra
     expected[r] = fminf(fmaxf(expected[r], lo), hi);
 }
 
+// NS Cameras.generate_rays for a perspective camera: pixel centres at +0.5,
+// d = ((x-cx)/fx, -(y-cy)/fy, -1) rotated by c2w[:3,:3] and normalised, origin = c2w[:3,3],
+// pixel_area = |d - d(x+1)| * |d - d(y+1)| (the two neighbouring directions, each normalised).
+struct CamArgs {
+    float c2w[12];
+    float fx, fy, cx, cy;
+    int H, W;
+};
+__device__ __forceinline__ void cam_dir(const CamArgs &c, float u, float v, float &dx, float &dy, float &dz) {
+    // sum_j dir_j * R[i][j] in torch's left-to-right order, dir = (u, v, -1)
+    const float x = add_rn(add_rn(mul_rn(u, c.c2w[0]), mul_rn(v, c.c2w[1])), mul_rn(-1.0f, c.c2w[2]));
+    const float y = add_rn(add_rn(mul_rn(u, c.c2w[4]), mul_rn(v, c.c2w[5])), mul_rn(-1.0f, c.c2w[6]));
+    const float z = add_rn(add_rn(mul_rn(u, c.c2w[8]), mul_rn(v, c.c2w[9])), mul_rn(-1.0f, c.c2w[10]));
+    const float n = fmaxf(sqrtf(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z))), 1.1920928955078125e-07f);
+    dx = x / n;
+    dy = y / n;
+    dz = z / n;
+}
+__global__ void generate_rays_kernel(CamArgs c, long long first, long long count, float *__restrict__ origins,
+                                     float *__restrict__ dirs, float *__restrict__ area) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const long long p = first + i;
+    const float px = (float)(p % c.W) + 0.5f, py = (float)(p / c.W) + 0.5f;
+    const float u = sub_rn(px, c.cx) / c.fx, v = -(sub_rn(py, c.cy) / c.fy);
+    const float ux = add_rn(sub_rn(px, c.cx), 1.0f) / c.fx;  // (x - cx + 1) / fx, torch's left-to-right order
+    const float vy = -(add_rn(sub_rn(py, c.cy), 1.0f) / c.fy);
+    float d0, d1, d2, a0, a1, a2, b0, b1, b2;
+    cam_dir(c, u, v, d0, d1, d2);
+    cam_dir(c, ux, v, a0, a1, a2);
+    cam_dir(c, u, vy, b0, b1, b2);
+    origins[i * 3 + 0] = c.c2w[3];
+    origins[i * 3 + 1] = c.c2w[7];
+    origins[i * 3 + 2] = c.c2w[11];
+    dirs[i * 3 + 0] = d0;
+    dirs[i * 3 + 1] = d1;
+    dirs[i * 3 + 2] = d2;
+    if (area) {
+        const float ex = sqrtf((d0 - a0) * (d0 - a0) + (d1 - a1) * (d1 - a1) + (d2 - a2) * (d2 - a2));
+        const float ey = sqrtf((d0 - b0) * (d0 - b0) + (d1 - b1) * (d1 - b1) + (d2 - b2) * (d2 - b2));
+        area[i] = ex * ey;
+    }
+}
+
 inline unsigned blocks_for(long long items, int per_block) { return (unsigned)((items + per_block - 1) / per_block); }
 
 }  // namespace
 
 extern "C" {
+
+int tn_generate_rays(const float *c2w_host, float fx, float fy, float cx, float cy, int32_t height, int32_t width,
+                     int64_t first_pixel, int64_t num_pixels, float *origins, float *directions, float *pixel_area,
+                     void *stream) {
+    if (num_pixels == 0) return TN_OK;
+    if (!c2w_host || !origins || !directions) return TN_ERR_NULL;
+    if (height < 1 || width < 1 || first_pixel < 0 || num_pixels < 0 ||
+        first_pixel + num_pixels > (int64_t)height * width || !(fx > 0.0f) || !(fy > 0.0f))
+        return TN_ERR_SHAPE;
+    CamArgs c;
+    for (int i = 0; i < 12; ++i) c.c2w[i] = c2w_host[i];
+    c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.H = height; c.W = width;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for(num_pixels, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, c,
+                       (long long)first_pixel, (long long)num_pixels, origins, directions, pixel_area);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
 
 int tn_frustum_positions(const float *origins, const float *directions, const float *starts, const float *ends,
                          int64_t num_rays, int32_t n, float *positions, void *stream) {
