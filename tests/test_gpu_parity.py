@@ -371,3 +371,34 @@ def test_mfma_path_is_actually_taken():
     gm, _, _ = gpu_model("stress", 64)
     _, _, fld = gm._c_structs()
     assert fld.prepared, "tn_field_prepare produced no blob: the fused path would silently use the VALU kernel"
+
+
+# --------------------------------------------------------------------------------------------------
+# config surface: the switches the reference's config exposes must change BOTH sides the same way
+# --------------------------------------------------------------------------------------------------
+VARIANTS = {
+    "aabb_no_contraction": dict(disable_scene_contraction=True),          # REF thermal_nerf_model.py:91-94
+    "zero_appearance": dict(use_average_appearance_embedding=False),      # REF thermal_field.py:133-137
+    "sh_unit_dirs": dict(sh_input="unit"),                                # SURVEY A.6 switch
+    "short_far_plane": dict(far_plane=6.0, near_plane=0.2),
+    "other_sample_counts": dict(num_proposal_samples_per_ray=(128, 64)),
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("impl", ["mfma", "f16x3", "modular"])
+def test_config_variants(variant, impl):
+    S = 40 if variant == "other_sample_counts" else 48
+    gm, sd, ocfg = gpu_model("stress", S, **VARIANTS[variant])
+    if impl == "f16x3":
+        gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f16x3"
+    else:
+        gm.config.fused, gm.config.use_mfma = IMPLS[impl]
+        gm.config.mlp_precision = "f32"
+    o, d = helpers.rays(14, 14, view=6)
+    if variant == "aabb_no_contraction":
+        o = o * 0.6  # start inside the +-1 box so that part of every ray is inside and part outside
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    check_outputs(got, want, f"{variant}/{impl}")
