@@ -25,14 +25,37 @@ __device__ __forceinline__ float nan_to_num(float x) {
     return x;
 }
 
+// ---- arithmetic flavour -------------------------------------------------------------------------------
+// FAST = false (default; every plugin-surface kernel): IEEE division, full-precision expf, torch's three-rounding
+// interpolation — the op order of the torch reference.
+// FAST = true (the fused throughput kernels): v_rcp_f32 / v_exp_f32 based reciprocal, quotient and exp (<= 2 ulp)
+// and the two-instruction fma form of the interpolation.  Same formulas, ulp-level different rounding.
+template <bool FAST>
+__device__ __forceinline__ float t_rcp(float x) {
+    if (FAST) return __builtin_amdgcn_rcpf(x);
+    return 1.0f / x;
+}
+template <bool FAST>
+__device__ __forceinline__ float t_div(float a, float b) {
+    if (FAST) return a * __builtin_amdgcn_rcpf(b);
+    return a / b;
+}
+template <bool FAST>
+__device__ __forceinline__ float t_exp(float x) {
+    if (FAST) return __expf(x);
+    return expf(x);
+}
+
 // ---- NS UniformLinDispPiecewiseSampler spacing functions ---------------------------------
 __device__ __forceinline__ float spacing_fn(float x) { return x < 1.0f ? x / 2.0f : sub_rn(1.0f, 1.0f / mul_rn(2.0f, x)); }
+template <bool FAST = false>
 __device__ __forceinline__ float spacing_fn_inv(float x) {
-    return x < 0.5f ? mul_rn(2.0f, x) : 1.0f / sub_rn(2.0f, mul_rn(2.0f, x));
+    return x < 0.5f ? mul_rn(2.0f, x) : t_rcp<FAST>(sub_rn(2.0f, mul_rn(2.0f, x)));
 }
 // spacing_to_euclidean_fn(x) = s_inv(x * s_far + (1 - x) * s_near)
+template <bool FAST = false>
 __device__ __forceinline__ float spacing_to_eucl(float x, float s_near, float s_far) {
-    return spacing_fn_inv(add_rn(mul_rn(x, s_far), mul_rn(sub_rn(1.0f, x), s_near)));
+    return spacing_fn_inv<FAST>(add_rn(mul_rn(x, s_far), mul_rn(sub_rn(1.0f, x), s_near)));
 }
 
 // ---- NS Frustums.get_positions: o + d * (s + e) / 2 ---------------------------------------------------
@@ -57,15 +80,17 @@ __device__ __forceinline__ Space make_space(const tn_space &s) {
 }
 
 // returns selector (0/1) and writes p (already multiplied by the selector) in [0,1]
+template <bool FAST = false>
 __device__ __forceinline__ float normalize_position(const Space &sp, float x, float y, float z, float &px, float &py,
                                                     float &pz) {
     if (sp.contraction) {
         const float mag = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
         if (!(mag < 1.0f)) {
-            const float k = sub_rn(2.0f, 1.0f / mag);
-            x = mul_rn(k, x / mag);
-            y = mul_rn(k, y / mag);
-            z = mul_rn(k, z / mag);
+            const float rinv = t_rcp<FAST>(mag);
+            const float k = sub_rn(2.0f, rinv);
+            x = mul_rn(k, FAST ? x * rinv : x / mag);
+            y = mul_rn(k, FAST ? y * rinv : y / mag);
+            z = mul_rn(k, FAST ? z * rinv : z / mag);
         }
         px = add_rn(x, 2.0f) / 4.0f;
         py = add_rn(y, 2.0f) / 4.0f;
@@ -100,12 +125,14 @@ struct Grid {
 #define TN_P1 2654435761u
 #define TN_P2 805459861u
 
+template <bool FAST = false>
 __device__ __forceinline__ float lerp_t(float a, float b, float o) {
+    if (FAST) return fmaf(o, a - b, b);  // b + o (a - b): two instructions
     // torch order: a*o + b*(1-o), three roundings
     return add_rn(mul_rn(a, o), mul_rn(b, sub_rn(1.0f, o)));
 }
 
-template <bool DENSE>
+template <bool DENSE, bool FAST = false>
 __device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, float py, float pz) {
     const float s = g.scal[l];
     const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
@@ -152,23 +179,24 @@ __device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, f
     }
     float2 r;
     {
-        const float f03 = lerp_t(f0.x, f3.x, ox), f12 = lerp_t(f1.x, f2.x, ox);
-        const float f56 = lerp_t(f5.x, f6.x, ox), f47 = lerp_t(f4.x, f7.x, ox);
-        const float f0312 = lerp_t(f03, f12, oy), f4756 = lerp_t(f47, f56, oy);
-        r.x = lerp_t(f0312, f4756, oz);
+        const float f03 = lerp_t<FAST>(f0.x, f3.x, ox), f12 = lerp_t<FAST>(f1.x, f2.x, ox);
+        const float f56 = lerp_t<FAST>(f5.x, f6.x, ox), f47 = lerp_t<FAST>(f4.x, f7.x, ox);
+        const float f0312 = lerp_t<FAST>(f03, f12, oy), f4756 = lerp_t<FAST>(f47, f56, oy);
+        r.x = lerp_t<FAST>(f0312, f4756, oz);
     }
     {
-        const float f03 = lerp_t(f0.y, f3.y, ox), f12 = lerp_t(f1.y, f2.y, ox);
-        const float f56 = lerp_t(f5.y, f6.y, ox), f47 = lerp_t(f4.y, f7.y, ox);
-        const float f0312 = lerp_t(f03, f12, oy), f4756 = lerp_t(f47, f56, oy);
-        r.y = lerp_t(f0312, f4756, oz);
+        const float f03 = lerp_t<FAST>(f0.y, f3.y, ox), f12 = lerp_t<FAST>(f1.y, f2.y, ox);
+        const float f56 = lerp_t<FAST>(f5.y, f6.y, ox), f47 = lerp_t<FAST>(f4.y, f7.y, ox);
+        const float f0312 = lerp_t<FAST>(f03, f12, oy), f4756 = lerp_t<FAST>(f47, f56, oy);
+        r.y = lerp_t<FAST>(f0312, f4756, oz);
     }
     return r;
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ float2 encode_level_any(const Grid &g, int l, float px, float py, float pz) {
-    if (l < g.num_dense) return encode_level<true>(g, l, px, py, pz);
-    return encode_level<false>(g, l, px, py, pz);
+    if (l < g.num_dense) return encode_level<true, FAST>(g, l, px, py, pz);
+    return encode_level<false, FAST>(g, l, px, py, pz);
 }
 
 // ---- wave64 collectives ------------------------------------------------------------------------------

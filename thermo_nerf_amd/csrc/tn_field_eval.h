@@ -35,7 +35,7 @@ __device__ __forceinline__ TwoLayerLds stage_two_layer(float *smem, const float 
 
 // NL > 0: level count known at compile time -> the level loop unrolls and all 8*NL gathers of a sample are
 // issued before the first one is consumed (latency paid once per sample instead of once per level).
-template <int H, int NL = 0>
+template <int H, int NL = 0, bool FAST = false>
 __device__ __forceinline__ void hidden_from_grid(const Grid &g, const TwoLayerLds &w, float px, float py, float pz,
                                                  float (&hid)[H]) {
 #pragma unroll
@@ -44,10 +44,10 @@ __device__ __forceinline__ void hidden_from_grid(const Grid &g, const TwoLayerLd
         float2 f[NL > 0 ? NL : 1];
         if (g.num_dense == 0) {  // uniform branch hoisted out so the unrolled gathers are straight-line code
 #pragma unroll
-            for (int l = 0; l < NL; ++l) f[l] = encode_level<false>(g, l, px, py, pz);
+            for (int l = 0; l < NL; ++l) f[l] = encode_level<false, FAST>(g, l, px, py, pz);
         } else {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) f[l] = encode_level_any(g, l, px, py, pz);
+            for (int l = 0; l < NL; ++l) f[l] = encode_level_any<FAST>(g, l, px, py, pz);
         }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -60,7 +60,7 @@ __device__ __forceinline__ void hidden_from_grid(const Grid &g, const TwoLayerLd
         }
     } else {
         for (int l = 0; l < g.num_levels; ++l) {
-            const float2 f = encode_level_any(g, l, px, py, pz);
+            const float2 f = encode_level_any<FAST>(g, l, px, py, pz);
             const float *wa = w.W0t + (2 * l) * H;
             const float *wb = wa + H;
 #pragma unroll
@@ -74,15 +74,15 @@ __device__ __forceinline__ void hidden_from_grid(const Grid &g, const TwoLayerLd
 }
 
 // HashMLPDensityField: density = avg * exp(mlp(enc(p))) * selector
-template <int H, int NL = 0>
+template <int H, int NL = 0, bool FAST = false>
 __device__ __forceinline__ float proposal_density_eval(const Grid &g, const TwoLayerLds &w, float avg, float px,
                                                        float py, float pz, float sel) {
     float hid[H];
-    hidden_from_grid<H, NL>(g, w, px, py, pz, hid);
+    hidden_from_grid<H, NL, FAST>(g, w, px, py, pz, hid);
     float o = w.B1[0];
 #pragma unroll
     for (int h = 0; h < H; ++h) o = fmaf(w.W1[h], hid[h], o);
-    return mul_rn(mul_rn(avg, expf(o)), sel);
+    return mul_rn(mul_rn(avg, t_exp<FAST>(o)), sel);
 }
 
 // ---- SH degree-3 basis (16 comps), NS components_from_spherical_harmonics -----------------------------

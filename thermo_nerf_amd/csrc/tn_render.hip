@@ -1,6 +1,8 @@
 // Fused forward of Model.forward (collider output in) + ThermalNerfModel.get_outputs
 // [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:210-275], one wave64 per ray.
 //
+//   (the fused kernels use the FAST arithmetic flavour of tn_device.h: v_rcp/v_exp reciprocal, quotient, exp and the
+//    fma-form interpolation, <= 2 ulp from the torch op order the plugin-surface kernels keep)
 //   proposal_kernel   NS ProposalNetworkSampler.generate_ray_samples, both proposal levels fused:
 //                     piecewise bins -> prop net 0 -> weights -> PDF -> prop net 1 -> weights -> PDF -> S+1 bins
 //                     (SURVEY §8a a4,a5,a6,a11) + the two prop_depth_i medians [REF :267-270].  Per-ray state
@@ -59,15 +61,15 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         if (i < n) {
-            const float st = spacing_to_eucl(bins[i], s_near, s_far);
-            const float en = spacing_to_eucl(bins[i + 1], s_near, s_far);
+            const float st = spacing_to_eucl<true>(bins[i], s_near, s_far);
+            const float en = spacing_to_eucl<true>(bins[i + 1], s_near, s_far);
             float px, py, pz;
-            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+            const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // proposal_net_args_list uses num_levels 5: unrolled form keeps all 40 gathers of a sample in flight
             const float dens = (net.g.num_levels == 5)
-                                   ? proposal_density_eval<PH, 5>(net.g, w, net.avg, px, py, pz, sel)
-                                   : proposal_density_eval<PH>(net.g, w, net.avg, px, py, pz, sel);
+                                   ? proposal_density_eval<PH, 5, true>(net.g, w, net.avg, px, py, pz, sel)
+                                   : proposal_density_eval<PH, 0, true>(net.g, w, net.avg, px, py, pz, sel);
             wts[i] = mul_rn(sub_rn(en, st), dens);
         }
     }
@@ -79,7 +81,7 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
         const float dd = ok ? wts[i] : 0.0f;
         const float incl = wave_incl_scan(dd, lane);
         const float excl = carry + wave_excl_from_incl(incl, lane);
-        const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
+        const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-excl))) : 0.0f;
         carry += __shfl(incl, 63, 64);
         const float incl_w = wave_incl_scan(wi, lane) + carry_w;
         const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
@@ -88,8 +90,8 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
         if (ok) wts[i] = wi;
     }
     const int idx = min(med_idx, n - 1);
-    const float st = spacing_to_eucl(bins[idx], s_near, s_far);
-    const float en = spacing_to_eucl(bins[idx + 1], s_near, s_far);
+    const float st = spacing_to_eucl<true>(bins[idx], s_near, s_far);
+    const float en = spacing_to_eucl<true>(bins[idx + 1], s_near, s_far);
     return add_rn(st, en) / 2.0f;
 }
 
@@ -113,7 +115,7 @@ __device__ __forceinline__ void pdf_resample(const float *wts, const float *bins
         float pdf = 0.0f;
         if (i < n_in) {
             const float wa = (anneal == 1.0f) ? wts[i] : powf(wts[i], anneal);
-            pdf = add_rn(add_rn(wa, 0.01f), pad_each) / ws;
+            pdf = t_div<true>(add_rn(add_rn(wa, 0.01f), pad_each), ws);
         }
         const float incl = wave_incl_scan(pdf, lane) + carry;
         if (i < n_in) cdf[i + 1] = fminf(1.0f, incl);
@@ -135,7 +137,7 @@ __device__ __forceinline__ void pdf_resample(const float *wts, const float *bins
         const int above = min(max(lo, 0), n_in);
         const float c0 = cdf[below], c1 = cdf[above];
         const float b0 = bins[below], b1 = bins[above];
-        float t = nan_to_num(sub_rn(uu, c0) / sub_rn(c1, c0));
+        float t = nan_to_num(t_div<true>(sub_rn(uu, c0), sub_rn(c1, c0)));
         t = fminf(fmaxf(t, 0.0f), 1.0f);
         new_bins[j] = add_rn(b0, mul_rn(t, sub_rn(b1, b0)));
     }
@@ -149,7 +151,7 @@ __device__ __forceinline__ void store_bins(const float *bins, int nb, float s_ne
     if (spacing)
         for (int j = lane; j < nb; j += 64) spacing[r * nb + j] = bins[j];
     if (eucl)
-        for (int j = lane; j < nb; j += 64) eucl[r * nb + j] = spacing_to_eucl(bins[j], s_near, s_far);
+        for (int j = lane; j < nb; j += 64) eucl[r * nb + j] = spacing_to_eucl<true>(bins[j], s_near, s_far);
 }
 
 __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, int nbmax) {

@@ -297,17 +297,17 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             sh16(sx, sy, sz, c);
             pack_step(c, sh0, sh1);
         }
-        float en = spacing_to_eucl(tb[0], s_near, s_far);
+        float en = spacing_to_eucl<true>(tb[0], s_near, s_far);
         float accum = 0.0f, cum_w = 0.0f;
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
         bool med_found = false;
         for (int i = 0; i < S; ++i) {
             const float st = en;
-            en = spacing_to_eucl(tb[(size_t)(i + 1) * 64], s_near, s_far);
+            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far);
             step = add_rn(st, en) / 2.0f;
             float px, py, pz;
-            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+            const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // ---- hash grid -> two K=16 steps of B operands per N tile --------------------------------------
             HL e0[2], e1[2];  // [ks] for tile 0 / tile 1
@@ -319,10 +319,10 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                     float2 f[LG];
                     if (a.g.num_dense == 0) {
 #pragma unroll
-                        for (int q = 0; q < LG; ++q) f[q] = encode_level<false>(a.g, 8 * ks + l0 + q, px, py, pz);
+                        for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, 8 * ks + l0 + q, px, py, pz);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < LG; ++q) f[q] = encode_level_any(a.g, 8 * ks + l0 + q, px, py, pz);
+                        for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, 8 * ks + l0 + q, px, py, pz);
                     }
 #pragma unroll
                     for (int q = 0; q < LG; ++q) {
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             }
             float raw, unused;
             swap32(g[0][0], g[1][0], raw, unused);
-            const float dens = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+            const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
             const HL g0 = split8<false>(g[0], 0), g1 = split8<false>(g[1], 0);  // geo rows (row 0 has zero weight)
             {   // colour: [geo | SH] -> 64 -> 64 -> 3
                 f32x16 x1[2][2], x2[2][2];
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             }
             cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);
             const float dd = mul_rn(sub_rn(en, st), dens);
-            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-accum)));
+            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
             accum += dd;
             cum_w += wi;
             if (!med_found && cum_w >= 0.5f) {

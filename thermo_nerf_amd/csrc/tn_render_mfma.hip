@@ -288,11 +288,11 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             const int i = base + lane;
             const bool ok = i < S;
             const int ic = ok ? i : S - 1;  // idle lanes re-evaluate the last sample (masked out below)
-            const float st = spacing_to_eucl(sb[ic], s_near, s_far);
-            const float en = spacing_to_eucl(sb[ic + 1], s_near, s_far);
+            const float st = spacing_to_eucl<true>(sb[ic], s_near, s_far);
+            const float en = spacing_to_eucl<true>(sb[ic + 1], s_near, s_far);
             const float step = add_rn(st, en) / 2.0f;
             float px, py, pz;
-            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+            const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // ---- hash grid: 32 features of this lane's sample -> B operands of the two N tiles -------------
             float bt0[16], bt1[16];
@@ -303,10 +303,10 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
                 float2 f[LG];
                 if (a.g.num_dense == 0) {
 #pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false>(a.g, l0 + q, px, py, pz);
+                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level_any(a.g, l0 + q, px, py, pz);
+                    for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, l0 + q, px, py, pz);
                 }
 #pragma unroll
                 for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             // row 0 (reg 0 of the lower half) is the raw density of sample l&31 of each tile -> lane = sample
             float raw, unused;
             swap32(g[0][0], g[1][0], raw, unused);
-            const float dens = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+            const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
             // ---- colour branch: geo -> 64 (per-ray bias) -> 64 -> 3 sigmoid --------------------------------
             float cr, cg, cb, th;
             {
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             }
             const float incl = wave_incl_scan(dd, lane);
             const float excl = carry + wave_excl_from_incl(incl, lane);
-            const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
+            const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-excl))) : 0.0f;
             carry += __shfl(incl, 63, 64);
             const float incl_w = wave_incl_scan(wi, lane) + carry_w;
             const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             a.rgb[r * 3 + 0] = c0; a.rgb[r * 3 + 1] = c1; a.rgb[r * 3 + 2] = c2;
             a.thermal[r] = ct;
             a.acc[r] = wsum;
-            const float st = spacing_to_eucl(sb[idx], s_near, s_far), en = spacing_to_eucl(sb[idx + 1], s_near, s_far);
+            const float st = spacing_to_eucl<true>(sb[idx], s_near, s_far), en = spacing_to_eucl<true>(sb[idx + 1], s_near, s_far);
             a.depth[r] = add_rn(st, en) / 2.0f;
             a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
         }
@@ -502,17 +502,17 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) swap32(c[2 * s], c[2 * s + 1], bs0[s], bs1[s]);
         }
-        float en = spacing_to_eucl(tb[0], s_near, s_far);
+        float en = spacing_to_eucl<true>(tb[0], s_near, s_far);
         float accum = 0.0f, cum_w = 0.0f;  // sum of delta*sigma before this sample; running sum of weights
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
         bool med_found = false;
         for (int i = 0; i < S; ++i) {
             const float st = en;
-            en = spacing_to_eucl(tb[(size_t)(i + 1) * 64], s_near, s_far);
+            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far);
             step = add_rn(st, en) / 2.0f;
             float px, py, pz;
-            const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+            const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             float bt0[16], bt1[16];
 #pragma unroll
@@ -520,10 +520,10 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
                 float2 f[LG];
                 if (a.g.num_dense == 0) {
 #pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false>(a.g, l0 + q, px, py, pz);
+                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level_any(a.g, l0 + q, px, py, pz);
+                    for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, l0 + q, px, py, pz);
                 }
 #pragma unroll
                 for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             }
             float raw, unused;
             swap32(g[0][0], g[1][0], raw, unused);
-            const float dens = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+            const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
             {   // colour: [geo | SH] -> 64 -> 64 -> 3
                 f32x16 x1[2][2], x2[2][2];
                 layer_geo(A, A_C1, lds + OFF_B_C1_EVAL, lane, h, g, x1);
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);  // eval renderers
             // ---- per-lane compositing: NS get_weights + renderers, sequential along the ray ----------------
             const float dd = mul_rn(sub_rn(en, st), dens);
-            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-accum)));
+            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
             accum += dd;
             cum_w += wi;
             if (!med_found && cum_w >= 0.5f) {
