@@ -12,7 +12,7 @@ FLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unus
 
 def variant(name: str, src: str) -> str:
     if name == "nohash":
-        return src.replace("f[q] = encode_level<false>(a.g, l0 + q, px, py, pz);",
+        return src.replace("f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);",
                            "f[q] = make_float2(px * (float)(l0 + q), py + pz);")
     if name == "coherent":
         return src.replace("            // ---- hash grid: 32 features",
@@ -61,6 +61,17 @@ def variant(name: str, src: str) -> str:
         k = k.replace("    if (lane == 0 && smin <= smax) {", "    if (lane == 0) { for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<unsigned long long *>(a.minmax + 2) + q, ts[q]); }\n    if (lane == 0 && smin <= smax) {", 1)
         assert k.count("ts[") >= 9, k.count("ts[")
         return src[:a] + k + src[b:]
+    if name == "mlponly":  # rays kernel: no hash gathers, no VALU output layers: the bare MFMA chain + relu operands
+        v = variant("nohash", src)
+        a = v.index("__global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel")
+        b = v.index("// ------------------------------------------------------------------------------------------------------\n// main_mfma_t32_kernel")
+        k = v[a:b]
+        k = k.replace("cr = fast_sigmoid(combine_halves(out_dot_fast<0>(w3, h, x2)) + w3[192]);", "cr = x2[0][0][0] + x2[1][1][3];")
+        k = k.replace("cg = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 64, h, x2)) + w3[193]);", "cg = x2[0][1][1];")
+        k = k.replace("cb = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 128, h, x2)) + w3[194]);", "cb = x2[1][0][2];")
+        k = k.replace("th = combine_halves(out_dot_fast<1>(wt, h, x2)) + wt[64];", "th = x2[0][0][5] + x2[1][1][7] + x2[0][1][9] + x2[1][0][11];")
+        assert k.count("x2[1][1][7]") == 1
+        return v[:a] + k + v[b:]
     if name == "base":
         return src
     raise SystemExit(f"unknown variant {name}")
@@ -72,7 +83,7 @@ def main():
     for name in sys.argv[1:]:
         tmp = f"/tmp/abl_{name}.hip"
         open(tmp, "w").write(variant(name, src))
-        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_prepare.hip")]
+        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_h3.hip", "tn_prepare.hip")]
         out = os.path.join(ROOT, f"ab_{name}.so")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)
         print("built", out)
