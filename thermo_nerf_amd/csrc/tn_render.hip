@@ -211,6 +211,192 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// proposal_rays_kernel: the same two fused proposal levels with lane = RAY (one wave64 owns 64 consecutive rays and
+// walks their samples in lock-step), like the field kernel:
+//   * adjacent rays at one sample index share hash-grid cells -> coherent gathers;
+//   * get_weights / median / sums become per-lane running values: no wave scans, no LDS;
+//   * PDFSampler's searchsorted + gathers become a per-lane MERGE WALK over the (sorted) cdf and the (sorted)
+//     sample positions u: no cdf array, no binary search;
+//   * exactly P0 + P1 density evaluations per ray (the wave-per-ray form pads 96 samples to 128 lanes).
+// Per-ray arrays that must survive between the passes (the level's weights, the 97 resampled edges) live in a
+// ray-tiled global scratch [tile][index][64 lanes] (coalesced, L2-resident), part of the caller's workspace.
+// ------------------------------------------------------------------------------------------------------
+struct PropRaysArgs {
+    PropArgs p;
+    float *w_scratch;   // [tiles][nmax][64]
+    float *b1_scratch;  // [tiles][P1+1][64]
+    int nmax;
+};
+
+// PDFSampler (histogram_padding 0.01, eps 1e-5) for one lane: inputs w[i] (scratch), existing edges via `edge(i)`,
+// total = sum(w^anneal + 0.01) over the level; emits n_out+1 new edges through `emit(j, value)`.
+template <typename EdgeFn, typename EmitFn>
+__device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, float anneal, const float *u, bool jittered,
+                                         float jit, int n_out, EdgeFn edge, EmitFn emit) {
+    const float padding = fmaxf(sub_rn(1e-5f, total), 0.0f);
+    const float pad_each = padding / (float)n_in;
+    const float ws = add_rn(total, padding);
+    const float rws = __builtin_amdgcn_rcpf(ws);
+    const int nb = n_out + 1;
+    int j = 0;
+    float run = 0.0f, c0 = 0.0f;          // running cumsum(pdf); cdf[i] = min(1, run) before adding bin i
+    float b0 = edge(0);
+    float uj = jittered ? add_rn(u[0], jit) : u[0];
+    for (int i = 0; i < n_in; ++i) {
+        const float wi = w[(size_t)i * 64];
+        const float wa = (anneal == 1.0f) ? wi : powf(wi, anneal);
+        run += add_rn(add_rn(wa, 0.01f), pad_each) * rws;
+        const float c1 = fminf(1.0f, run);
+        const float b1 = edge(i + 1);
+        // searchsorted(cdf, u, side="right") lands in bin i  <=>  cdf[i] <= u < cdf[i+1]
+        while (j < nb && uj < c1) {
+            float t = nan_to_num(t_div<true>(sub_rn(uj, c0), sub_rn(c1, c0)));
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            emit(j, add_rn(b0, mul_rn(t, sub_rn(b1, b0))));
+            ++j;
+            if (j < nb) uj = jittered ? add_rn(u[j], jit) : u[j];
+        }
+        c0 = c1;
+        b0 = b1;
+    }
+    // u >= cdf[n_in]: below == above == n_in -> t * 0 -> the last edge
+    for (; j < nb; ++j) emit(j, b0);
+}
+
+__global__ void __launch_bounds__(kBlock, 2) proposal_rays_kernel(PropRaysArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const PropArgs &a = ra.p;
+    const int in0 = 2 * a.net[0].g.num_levels, in1 = 2 * a.net[1].g.num_levels;
+    const int P0 = a.P0, P1 = a.P1, S = a.S;
+    float *wbase0 = smem;
+    float *wbase1 = wbase0 + two_layer_floats(in0, PH, 1);
+    float *lin0 = wbase1 + two_layer_floats(in1, PH, 1);  // [P0+1]
+    float *u1 = lin0 + (P0 + 1);                           // [P1+1]
+    float *u2 = u1 + (P1 + 1);                             // [S+1]
+    const TwoLayerLds w0 = stage_two_layer<PH>(wbase0, a.net[0].w0, a.net[0].b0, a.net[0].w1, a.net[0].b1, in0, 1);
+    const TwoLayerLds w1 = stage_two_layer<PH>(wbase1, a.net[1].w0, a.net[1].b0, a.net[1].w1, a.net[1].b1, in1, 1);
+    for (int i = threadIdx.x; i <= P0; i += blockDim.x) lin0[i] = a.lin0[i];
+    for (int i = threadIdx.x; i <= P1; i += blockDim.x) u1[i] = a.u1[i];
+    for (int i = threadIdx.x; i <= S; i += blockDim.x) u2[i] = a.u2[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Space sp0 = make_space(a.net[0].space), sp1 = make_space(a.net[1].space);
+    const bool fast0 = a.net[0].g.num_levels == 5, fast1 = a.net[1].g.num_levels == 5;
+    const bool jittered = a.jitter != nullptr;
+    const long long tiles = (a.R + 63) >> 6;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += stride) {
+        const long long r = tile * 64 + lane;
+        const bool live = r < a.R;
+        const long long rc = live ? r : a.R - 1;
+        const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
+        const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
+        const float s_near = spacing_fn(a.nears[rc]), s_far = spacing_fn(a.fars[rc]);
+        float *wsc = ra.w_scratch + (size_t)tile * ra.nmax * 64 + lane;       // w[i] at wsc[i*64]
+        float *b1sc = ra.b1_scratch + (size_t)tile * (P1 + 1) * 64 + lane;   // edge j at b1sc[j*64]
+        float *fin = a.ws_spacing + tn_ws_bin(tile * 64, 0, S) + lane;       // final edge j at fin[j*64]
+        const float t0 = jittered ? a.jitter[rc] : 0.0f;
+        // level-0 spacing edge j: linspace, or its stratified jitter
+        auto edge0 = [&](int j) -> float {
+            float b = lin0[j];
+            if (jittered) {
+                const float lo = (j == 0) ? lin0[0] : add_rn(lin0[j], lin0[j - 1]) / 2.0f;
+                const float hi = (j == P0) ? lin0[P0] : add_rn(lin0[j + 1], lin0[j]) / 2.0f;
+                b = add_rn(lo, mul_rn(sub_rn(hi, lo), t0));
+            }
+            return b;
+        };
+        // ================= level 0: P0 samples through proposal net 0 =====================================
+        float total = 0.0f, med0 = 0.0f;
+        {
+            float accum = 0.0f, cum_w = 0.0f, step = 0.0f;
+            bool found = false;
+            float sb = edge0(0);
+            float en = spacing_to_eucl<true>(sb, s_near, s_far);
+            if (live && a.out_spacing[0]) a.out_spacing[0][r * (P0 + 1)] = sb;
+            if (live && a.out_eucl[0]) a.out_eucl[0][r * (P0 + 1)] = en;
+            for (int i = 0; i < P0; ++i) {
+                const float st = en;
+                sb = edge0(i + 1);
+                en = spacing_to_eucl<true>(sb, s_near, s_far);
+                step = add_rn(st, en) / 2.0f;
+                float px, py, pz;
+                const float sel = normalize_position<true>(sp0, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                           frustum_pos(oz, dz, st, en), px, py, pz);
+                const float dens = fast0 ? proposal_density_eval<PH, 5, true>(a.net[0].g, w0, a.net[0].avg, px, py, pz, sel)
+                                         : proposal_density_eval<PH, 0, true>(a.net[0].g, w0, a.net[0].avg, px, py, pz, sel);
+                const float dd = mul_rn(sub_rn(en, st), dens);
+                const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
+                accum += dd;
+                cum_w += wi;
+                if (!found && cum_w >= 0.5f) {
+                    found = true;
+                    med0 = step;
+                }
+                wsc[(size_t)i * 64] = wi;
+                total += add_rn((a.anneal == 1.0f) ? wi : powf(wi, a.anneal), 0.01f);
+                if (live && a.out_w[0]) a.out_w[0][r * P0 + i] = wi;
+                if (live && a.out_spacing[0]) a.out_spacing[0][r * (P0 + 1) + i + 1] = sb;
+                if (live && a.out_eucl[0]) a.out_eucl[0][r * (P0 + 1) + i + 1] = en;
+            }
+            if (!found) med0 = step;
+        }
+        // ================= PDF resample 0 -> P1 + 1 edges ===================================================
+        pdf_walk(wsc, P0, total, a.anneal, u1, jittered, jittered ? a.jitter[a.R + rc] / (float)(P1 + 1) : 0.0f, P1,
+                 edge0, [&](int j, float v) { b1sc[(size_t)j * 64] = v; });
+        // ================= level 1: P1 samples through proposal net 1 =====================================
+        float med1 = 0.0f;
+        total = 0.0f;
+        {
+            float accum = 0.0f, cum_w = 0.0f, step = 0.0f;
+            bool found = false;
+            float sb = b1sc[0];
+            float en = spacing_to_eucl<true>(sb, s_near, s_far);
+            if (live && a.out_spacing[1]) a.out_spacing[1][r * (P1 + 1)] = sb;
+            if (live && a.out_eucl[1]) a.out_eucl[1][r * (P1 + 1)] = en;
+            for (int i = 0; i < P1; ++i) {
+                const float st = en;
+                sb = b1sc[(size_t)(i + 1) * 64];
+                en = spacing_to_eucl<true>(sb, s_near, s_far);
+                step = add_rn(st, en) / 2.0f;
+                float px, py, pz;
+                const float sel = normalize_position<true>(sp1, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                           frustum_pos(oz, dz, st, en), px, py, pz);
+                const float dens = fast1 ? proposal_density_eval<PH, 5, true>(a.net[1].g, w1, a.net[1].avg, px, py, pz, sel)
+                                         : proposal_density_eval<PH, 0, true>(a.net[1].g, w1, a.net[1].avg, px, py, pz, sel);
+                const float dd = mul_rn(sub_rn(en, st), dens);
+                const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
+                accum += dd;
+                cum_w += wi;
+                if (!found && cum_w >= 0.5f) {
+                    found = true;
+                    med1 = step;
+                }
+                wsc[(size_t)i * 64] = wi;
+                total += add_rn((a.anneal == 1.0f) ? wi : powf(wi, a.anneal), 0.01f);
+                if (live && a.out_w[1]) a.out_w[1][r * P1 + i] = wi;
+                if (live && a.out_spacing[1]) a.out_spacing[1][r * (P1 + 1) + i + 1] = sb;
+                if (live && a.out_eucl[1]) a.out_eucl[1][r * (P1 + 1) + i + 1] = en;
+            }
+            if (!found) med1 = step;
+        }
+        // ================= PDF resample 1 -> S + 1 final edges (ray-tiled workspace) ========================
+        pdf_walk(wsc, P1, total, a.anneal, u2, jittered, jittered ? a.jitter[2 * a.R + rc] / (float)(S + 1) : 0.0f, S,
+                 [&](int j) -> float { return b1sc[(size_t)j * 64]; },
+                 [&](int j, float v) {
+                     fin[(size_t)j * 64] = v;
+                     if (live && a.out_spacing[2]) a.out_spacing[2][r * (S + 1) + j] = v;
+                     if (live && a.out_eucl[2]) a.out_eucl[2][r * (S + 1) + j] = spacing_to_eucl<true>(v, s_near, s_far);
+                 });
+        if (live) {
+            if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
+            if (a.prop_depth[1]) a.prop_depth[1][r] = med1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // main field + composite, lane per sample (reference form)
 // ------------------------------------------------------------------------------------------------------
@@ -382,7 +568,12 @@ extern "C" {
 
 size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays) {
     if (!cfg || num_rays < 0) return 0;
-    return align_up(tn_ws_bin_floats(num_rays, cfg->num_nerf_samples) * sizeof(float), 256) + 256;
+    // [final edges, ray-tiled] [256 B: depth min/max + spare] [proposal scratch: level weights + level-1 edges, ray-tiled]
+    const size_t tiles = (size_t)((num_rays + 63) >> 6);
+    const int P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1];
+    const size_t nmax = (size_t)(P0 > P1 ? P0 : P1);
+    return align_up(tn_ws_bin_floats(num_rays, cfg->num_nerf_samples) * sizeof(float), 256) + 256 +
+           tiles * 64 * (nmax + (size_t)P1 + 1) * sizeof(float);
 }
 
 static int check_render_common(const tn_render_config *cfg, int64_t num_rays, void *workspace, size_t workspace_bytes) {
@@ -432,6 +623,24 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)prop_smem) != hipSuccess)
         return TN_ERR_LAUNCH;
+    if (!getenv("TN_PROPOSAL_PER_RAY")) {
+        // default: lane = ray
+        PropRaysArgs ra;
+        ra.p = pa;
+        ra.nmax = nmax;
+        char *scratch = reinterpret_cast<char *>(workspace) + align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256) + 256;
+        const size_t tiles = (size_t)((num_rays + 63) >> 6);
+        ra.w_scratch = reinterpret_cast<float *>(scratch);
+        ra.b1_scratch = ra.w_scratch + tiles * 64 * (size_t)nmax;
+        const size_t rsmem = (size_t)(two_layer_floats(2 * prop0->grid.num_levels, PH, 1) +
+                                      two_layer_floats(2 * prop1->grid.num_levels, PH, 1) + (P0 + 1) + (P1 + 1) + (S + 1)) *
+                             sizeof(float);
+        const long long need = ((long long)tiles + kWaves - 1) / kWaves;
+        const unsigned grid = (unsigned)(need < 512 ? (need < 1 ? 1 : need) : 512);
+        hipLaunchKernelGGL(proposal_rays_kernel, dim3(grid), dim3(kBlock), rsmem, s, ra);
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
     hipLaunchKernelGGL(proposal_kernel, dim3(ray_grid(num_rays, 8)), dim3(kBlock), prop_smem, s, pa, nmax, nbmax);
     TN_LAUNCH_CHECK();
     return TN_OK;
