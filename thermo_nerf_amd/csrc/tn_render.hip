@@ -265,7 +265,7 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     for (; j < nb; ++j) emit(j, b0);
 }
 
-__global__ void __launch_bounds__(kBlock, 2) proposal_rays_kernel(PropRaysArgs ra) {
+__global__ void __launch_bounds__(kBlock, 3) proposal_rays_kernel(PropRaysArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PropArgs &a = ra.p;
     const int in0 = 2 * a.net[0].g.num_levels, in1 = 2 * a.net[1].g.num_levels;
@@ -636,7 +636,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
                                       two_layer_floats(2 * prop1->grid.num_levels, PH, 1) + (P0 + 1) + (P1 + 1) + (S + 1)) *
                              sizeof(float);
         const long long need = ((long long)tiles + kWaves - 1) / kWaves;
-        const unsigned grid = (unsigned)(need < 512 ? (need < 1 ? 1 : need) : 512);
+        const unsigned grid = (unsigned)(need < 768 ? (need < 1 ? 1 : need) : 768);  // 3 workgroups (12 waves) per CU
         hipLaunchKernelGGL(proposal_rays_kernel, dim3(grid), dim3(kBlock), rsmem, s, ra);
         TN_LAUNCH_CHECK();
         return TN_OK;
