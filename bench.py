@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="MLP product arithmetic of the field kernel (f16x3 = three f16 MFMA products per fp32 product)")
+    ap.add_argument("--early-eps", type=float, default=0.0,
+                    help="early ray termination threshold (0 = off = the reference's arithmetic; NOT used for `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per CPU-baseline repeat")
     return ap.parse_args()
@@ -117,7 +119,7 @@ def main():
         args.chunk = args.height * args.width
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=args.chunk,
                                  dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma,
-                                 mlp_precision=args.precision)
+                                 mlp_precision=args.precision, early_termination_eps=args.early_eps)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box
     model.eval()
@@ -178,7 +180,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via 3xf16-split MFMA products",
             "data": "synthetic",
             "config": {"workload": "config 2: synthetic %dx%d RGB+thermal scene, P=(256,96)+%d samples/ray, chunk %d, "
-                                   "forward-only eval, %s weights" % (args.height, args.width, S, args.chunk, args.weights),
+                                   "forward-only eval, %s weights%s" % (args.height, args.width, S, args.chunk, args.weights,
+                                                                         "" if args.early_eps <= 0 else
+                                                                         ", early ray termination eps=%g" % args.early_eps),
                        "rays_per_step_per_gpu": n_rays, "parallelism": "ray-shard x%d (one frame per rank)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dominant,

@@ -189,7 +189,10 @@ typedef struct tn_render_config {
     int32_t num_nerf_samples;        /* 48 | 64 | 192 ... (<= 256)    */
     int32_t training;                /* eval == 0                     */
     float pdf_anneal;                /* ProposalNetworkSampler._anneal (1.0 at inference) */
-    int32_t _pad;
+    /* eval only, 0 = off (exact): a wave of 64 rays stops marching once EVERY ray's transmittance is below this value
+     * (wave-wide vote).  Skipped samples carry weights < eps each; rgb/thermal/accumulation move by <= eps, the
+     * expected depth by <= eps * far.  The reference has no such switch: 0 reproduces it. */
+    float early_stop_transmittance;
 } tn_render_config;
 
 typedef struct tn_render_inputs {

@@ -402,3 +402,36 @@ def test_config_variants(variant, impl):
     with torch.no_grad():
         got = gm(bundle(o, d))
     check_outputs(got, want, f"{variant}/{impl}")
+
+
+# --------------------------------------------------------------------------------------------------
+# early ray termination (opt-in; the reference has none, so 0 must be exact and eps > 0 bounded by eps)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_early_ray_termination_is_bounded_by_eps(precision):
+    gm, _, _ = gpu_model("scene", 64)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, precision
+    with torch.no_grad():
+        gm.field.mlp_base.mlp.layers[1].bias[0] += 5.0  # dense fog: every ray saturates within a few samples
+    o, d = helpers.rays(24, 24, view=2)
+    eps = 1e-3
+    with torch.no_grad():
+        gm.config.early_termination_eps = 0.0
+        exact = {k: v.clone() for k, v in gm(bundle(o, d)).items()}
+        again = gm(bundle(o, d))
+        for k in exact:
+            assert torch.equal(exact[k], again[k]), k
+        gm.config.early_termination_eps = eps
+        early = gm(bundle(o, d))
+    assert (exact["accumulation"] > 1 - eps).float().mean().item() > 0.9, "test scene does not saturate"
+    for k in ("rgb", "thermal", "accumulation"):
+        diff = (early[k] - exact[k]).abs().max().item()
+        assert diff <= 2 * eps, f"{k}: {diff:.2e} > 2*eps"
+    # the median crossing (cumulative weight 0.5) always precedes termination (eps <= 0.25)
+    assert torch.equal(early["depth"], exact["depth"])
+    # expected depth: the skipped tail carries < eps of weight spread over [last step, far]
+    far = gm.config.far_plane
+    assert (early["expected_depth"] - exact["expected_depth"]).abs().max().item() <= eps * far
+    # proposal outputs are untouched by the switch
+    for k in ("prop_depth_0", "prop_depth_1"):
+        assert torch.equal(early[k], exact[k]), k

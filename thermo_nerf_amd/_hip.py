@@ -99,7 +99,7 @@ class tn_render_config(C.Structure):
         ("num_nerf_samples", C.c_int32),
         ("training", C.c_int32),
         ("pdf_anneal", C.c_float),
-        ("_pad", C.c_int32),
+        ("early_stop_transmittance", C.c_float),
     ]
 
 

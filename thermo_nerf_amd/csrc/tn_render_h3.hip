@@ -263,6 +263,7 @@ struct H3Args {
     int S;
     float *rgb, *acc, *depth, *expected, *thermal;
     unsigned *minmax;
+    float early_eps;  // 0 = never stop early
 };
 
 __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
@@ -412,6 +413,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             wsteps += mul_rn(wi, step);
             smin = fminf(smin, step);
             smax = fmaxf(smax, step);
+            // early ray termination (eval, opt-in): wave-wide vote on the transmittance left after this sample
+            if (a.early_eps > 0.0f && i + 1 < S && __all(__expf(-accum) < a.early_eps)) {
+                // keep the call-global depth bounds exact: they only miss the last mid-point
+                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far);
+                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far);
+                smax = fmaxf(smax, add_rn(e0, e1) / 2.0f);
+                break;
+            }
         }
         if (live) {
             const float bg = sub_rn(1.0f, wsum);
@@ -460,6 +469,7 @@ int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, c
     a.R = num_rays; a.S = cfg->num_nerf_samples;
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.minmax = minmax;
+    a.early_eps = fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
     const size_t smem = (size_t)H_BLOB_FLOATS * sizeof(float);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_h3_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)

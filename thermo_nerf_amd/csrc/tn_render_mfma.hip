@@ -139,6 +139,7 @@ struct MfmaArgs {
     float *rgb, *acc, *depth, *expected, *thermal;
     float *out_w;
     unsigned *minmax;
+    float early_eps;  // eval only; 0 = never stop early
 };
 
 #define MFMA32(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
@@ -603,6 +604,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             smin = fminf(smin, step);
             smax = fmaxf(smax, step);
             if (a.out_w && live) a.out_w[r * S + i] = wi;
+            // early ray termination (eval, opt-in): wave-wide vote on the transmittance left after this sample
+            if (a.early_eps > 0.0f && i + 1 < S && __all(__expf(-accum) < a.early_eps)) {
+                // keep the call-global depth bounds exact: they only miss the last mid-point
+                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far);
+                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far);
+                smax = fmaxf(smax, add_rn(e0, e1) / 2.0f);
+                break;
+            }
         }
         if (live) {  // cr..th / step now hold the LAST sample: the "last_sample" background
             const float bg = sub_rn(1.0f, wsum);
@@ -653,6 +662,7 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     a.R = num_rays; a.S = cfg->num_nerf_samples; a.training = cfg->training;
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.out_w = out->weights[2]; a.minmax = minmax;
+    a.early_eps = cfg->training ? 0.0f : fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)

@@ -35,6 +35,7 @@ class RayRenderEngine:
         self.rc.num_nerf_samples = self.S
         self.rc.training = 0
         self.rc.pdf_anneal = float(model.proposal_sampler._anneal)
+        self.rc.early_stop_transmittance = float(cfg.early_termination_eps)
         self._ws: Optional[Tensor] = None
         self._nf: Optional[Tuple[Tensor, Tensor]] = None
         self.timings: List[Tuple[torch.cuda.Event, torch.cuda.Event, torch.cuda.Event]] = []

@@ -74,6 +74,9 @@ class NerfactoModelConfig:
     """>0: re-lay the coarse hash levels densely within this budget (layout only, bit-identical)."""
     use_mfma: bool = True
     """Use the MFMA form of the main-field kernel when the library provides it."""
+    early_termination_eps: float = 0.0
+    """eval only; > 0: a wave of 64 rays stops marching once every ray's transmittance is below this value
+    (outputs move by <= eps; 0 = off = the reference's behaviour)."""
     mlp_precision: Literal["f32", "f16x3"] = "f32"
     """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "f16x3": eval-only, every fp32 product evaluated as three f16
     MFMA products accumulated in fp32 (~2^-22 relative product error; activations must stay below 65504)."""

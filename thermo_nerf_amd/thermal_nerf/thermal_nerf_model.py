@@ -218,6 +218,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         rc.num_nerf_samples = S
         rc.training = 1 if training else 0
         rc.pdf_anneal = float(self.proposal_sampler._anneal)
+        rc.early_stop_transmittance = 0.0 if training else float(cfg.early_termination_eps)
 
         ins = _hip.tn_render_inputs()
         ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()

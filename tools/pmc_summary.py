@@ -1,0 +1,59 @@
+"""Summarise rocprofv3 --pmc csv passes into profiles/<name>.txt and refresh profiles/pmc_traffic.json.
+
+usage: python tools/pmc_summary.py <dir with pass sub-dirs a/ b/ c/> <out.txt> <f32|f16x3> "<title>"
+Each pass dir holds *_counter_collection.csv written by
+    rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir>/<pass> -o <pass> -- python bench.py ...
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are reported in KB, and on gfx950
+FETCH_SIZE counts 64-byte units as 32 -> the fetched bytes are 2 x FETCH_SIZE KB.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KEEP = ("main_mfma_rays_kernel", "main_h3_rays_kernel", "proposal_rays_kernel", "main_mfma_kernel", "proposal_kernel")
+KEY = {"main_mfma_rays_kernel": "field_render", "main_h3_rays_kernel": "field_render", "proposal_rays_kernel": "proposal_sample"}
+
+
+def short(name):
+    for k in KEEP:
+        if k + "(" in name:
+            return k
+    return None
+
+
+def main():
+    d, dst, prec, title = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    acc = defaultdict(list)  # (kernel, counter) -> per-dispatch values
+    for p in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))):
+        per = defaultdict(float)  # (dispatch, kernel, counter) -> summed over instances
+        for row in csv.DictReader(open(p)):
+            k = short(row["Kernel_Name"])
+            if k:
+                per[(row["Dispatch_Id"], k, row["Counter_Name"])] += float(row["Counter_Value"])
+        for (_, k, c), v in per.items():
+            acc[(k, c)].append(v)
+    with open(dst, "w") as out:
+        out.write(f"# {title}\n")
+        out.write("# separate --pmc passes (one sub-directory each); mean per dispatch.  GRBM_GUI_ACTIVE is summed over the 8 XCDs;\n"
+                  "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles; FETCH_SIZE / WRITE_SIZE in KB as reported.\n")
+        out.write("kernel,counter,dispatches,mean_per_dispatch\n")
+        for (k, c), v in sorted(acc.items()):
+            out.write(f"{k},{c},{len(v)},{sum(v) / len(v):.6g}\n")
+    tj = os.path.join(os.path.dirname(os.path.abspath(dst)), "pmc_traffic.json")
+    traffic = json.load(open(tj)) if os.path.exists(tj) else {}
+    for k, name in KEY.items():
+        f, w = acc.get((k, "FETCH_SIZE")), acc.get((k, "WRITE_SIZE"))
+        if f and w:
+            traffic[name + ("" if prec == "f32" else "_f16x3")] = {
+                "fetch_kb": 2.0 * sum(f) / len(f), "write_kb": sum(w) / len(w), "rays_per_launch": 640000,
+                "source": f"profiles/{os.path.basename(dst)} (2 x FETCH_SIZE per the MI355X_MICROARCH.md gfx950 note + "
+                          "WRITE_SIZE, KB; 8-byte gathers, uncalibrated)"}
+    json.dump(traffic, open(tj, "w"), indent=1)
+    print(open(dst).read())
+
+
+if __name__ == "__main__":
+    main()
