@@ -435,3 +435,23 @@ def test_early_ray_termination_is_bounded_by_eps(precision):
     # proposal outputs are untouched by the switch
     for k in ("prop_depth_0", "prop_depth_1"):
         assert torch.equal(early[k], exact[k]), k
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_checkpoint_load_invalidates_prepared_weights(tmp_path, precision):
+    """Render, load a nerfstudio-layout checkpoint holding other weights into the SAME device model, render again:
+    the prepared MFMA blobs must be rebuilt (outputs follow the oracle on the new weights)."""
+    from thermo_nerf_amd import checkpoint as C
+
+    gm, _, _ = gpu_model("init", 48)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, precision
+    src, sd_new, ocfg = helpers.build("stress", 48)
+    o, d = helpers.rays(12, 12, view=5)
+    with torch.no_grad():
+        before = gm(bundle(o, d))["rgb"].clone()
+        path = C.save_nerfstudio_checkpoint(src, tmp_path, 123)
+        rep = C.load_nerfstudio_checkpoint(gm, path)
+        assert rep.step == 123 and not rep.unexpected
+        got = gm(bundle(o, d))
+    assert not torch.equal(before, got["rgb"])
+    check_outputs(got, H.get_outputs(sd_new, o, d, None, ocfg), f"after checkpoint load ({precision})")
