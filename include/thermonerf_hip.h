@@ -255,6 +255,73 @@ int tn_field_prepare(const tn_thermal_field *field, void *prepared_dev, size_t b
 size_t tn_field_prepare_f16x3_bytes(const tn_thermal_field *field);
 int tn_field_prepare_f16x3(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Training step: forward with a tape of per-sample activations, losses, backward.
+ * The reference gets all of this from torch autograd over nerfstudio's modules
+ * [REF thermal_nerf_model.py:210-326; nerfstudio model_components/losses.py]; here each differentiable stage
+ * is one entry point on [N, width] fp32 row-major matrices (N = rays * samples of the level), the binding chains
+ * them inside a torch.autograd.Function.  Gradient outputs marked (+=) are accumulated with atomics: zero them first.
+ * ---------------------------------------------------------------------------------------------------- */
+
+#define TN_ACT_NONE 0
+#define TN_ACT_RELU 1
+#define TN_ACT_SIGMOID 2
+
+/* NS get_density position normalisation + HashEncoding.pytorch_fwd: positions [N,3] (world) ->
+ * enc [N, 2*num_levels], selector [N] (0/1; the encoding is evaluated at p * selector like the reference). */
+int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, int64_t n, float *enc,
+                       float *selector, void *stream);
+/* its backward w.r.t. the table: d_enc [N, 2*num_levels] -> d_table [num_levels << log2_hashmap_size, 2] (+=). */
+int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                       int64_t n, float *d_table, void *stream);
+
+/* torch.nn.Linear (+ activation): y[n, :out] = act(x[n, :in] W^T + b); x rows are ldx floats apart, y rows ldy.
+ * in_dim, out_dim <= 64. */
+int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act, int64_t n, float *y, int32_t ldy,
+                  void *stream);
+/* backward: g = dy * act'(y) (y = the forward OUTPUT, rows ldy apart like dy);  dx[n,:in] (= or += when
+ * accumulate_dx) = g W;  d_weight [out,in] (+=) = g^T x;  d_bias [out] (+=) = sum_n g.  dx / d_weight / d_bias
+ * may be NULL. */
+int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, int32_t ldy, const tn_linear *lin,
+                  int32_t act, int64_t n, float *dx, int32_t lddx, int32_t accumulate_dx, float *d_weight,
+                  float *d_bias, void *stream);
+
+/* density = average_init_density * trunc_exp(raw) * selector (NS get_density); raw rows ld_raw floats apart.
+ * backward: d_raw = d_density * average_init_density * exp(min(raw, 15)) * selector (NS trunc_exp.backward). */
+int tn_density_act_fwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density, int64_t n,
+                       float *density, void *stream);
+int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density,
+                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, void *stream);
+
+/* backward of tn_weights_fwd: d_weights [R,n] -> d_densities [R,n]. */
+int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
+                   float *d_densities, void *stream);
+
+/* backward of tn_composite_fwd in training mode (no nan_to_num / clamp): d_out [R,C], accumulation [R] ->
+ * d_values [R,n,C] (=), d_weights [R,n] (+=). */
+int tn_composite_bwd(const float *values, const float *weights, const float *accumulation, const float *d_out,
+                     int64_t num_rays, int32_t n, int32_t channels, float *d_values, float *d_weights, void *stream);
+
+/* input of mlp_head [REF thermal_field.py:160-167]: cin [R*n, 64] = [SH16(dir) | geo | appearance | 0];
+ * geo rows ld_geo floats apart; training != 0: embedding[camera_indices[r]], else mean / zeros [REF :124-137]. */
+int tn_color_input_fwd(const tn_thermal_field *field, const float *directions, const float *geo, int32_t ld_geo,
+                       const int32_t *camera_indices, int32_t training, int64_t num_rays, int32_t n, float *cin,
+                       void *stream);
+/* backward: d_cin [R*n,64] -> d_geo (+=, rows ld_d_geo apart), d_appearance [num_images, app_dim] (+=; training). */
+int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const int32_t *camera_indices,
+                       int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
+                       float *d_appearance, void *stream);
+
+/* NS losses.distortion_loss on one level: spacing bins [R,n+1], weights [R,n] -> loss_sum[0] (+=) = sum over rays
+ * of lossfun_distortion (divide by R for the mean), d_weights [R,n] (=) = d(sum)/dw.  O(n) per ray. */
+int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float *loss_sum,
+                       float *d_weights, void *stream);
+/* NS losses.interlevel_loss, one proposal level: final bins c [R,n+1] / weights w [R,n] (constants), proposal bins
+ * cp [R,p+1] / weights wp [R,p] -> loss_sum[0] (+=) = sum over rays and samples of lossfun_outer (divide by R*n),
+ * d_wp [R,p] (=) = d(sum)/dwp.  p <= 1024. */
+int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
+                       int32_t p, float *loss_sum, float *d_wp, void *stream);
+
 /* library identification: returns a static string "thermonerf_hip <version> gfx950". */
 const char *tn_version(void);
 

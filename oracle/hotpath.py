@@ -193,6 +193,23 @@ def sh4(d: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------------------------
 
 
+class _TruncExp(torch.autograd.Function):
+    """NS field_components.activations.trunc_exp: forward exp(x), backward g * exp(clamp(x, max=15))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, max=15.0))
+
+
+trunc_exp = _TruncExp.apply
+
+
 def proposal_density(sd: Dict[str, Tensor], level: int, positions: Tensor, cfg: OracleConfig) -> Tensor:
     """NS HashMLPDensityField.density_fn/get_density (a5), built at [REF thermal_nerf_model.py:136-149].
     positions [...,3] -> density [...,1]."""
@@ -205,7 +222,7 @@ def proposal_density(sd: Dict[str, Tensor], level: int, positions: Tensor, cfg: 
         args["log2_hashmap_size"],
     )
     raw = mlp(enc, _layers(sd, f"{pre}.mlp_base.mlp", 2), None).view(*shape, -1)
-    density = 1.0 * torch.exp(raw)  # trunc_exp forward == exp; average_init_density default 1.0
+    density = 1.0 * trunc_exp(raw)  # average_init_density default 1.0
     return density * selector[..., None]
 
 
@@ -219,7 +236,7 @@ def field_density(sd: Dict[str, Tensor], positions: Tensor, cfg: OracleConfig) -
     )
     h = mlp(enc, _layers(sd, "field.mlp_base.mlp", 2), None).view(*shape, -1)
     raw, geo = torch.split(h, [1, cfg.geo_feat_dim], dim=-1)
-    density = cfg.average_init_density * torch.exp(raw)
+    density = cfg.average_init_density * trunc_exp(raw)
     density = density * selector[..., None]
     return density, geo
 
@@ -337,6 +354,7 @@ def sample_pdf(prev: Samples, weights: Tensor, num_samples: int, rand: Optional[
     bins_g1 = torch.gather(existing, -1, above)
     t = torch.clip(torch.nan_to_num((u - cdf_g0) / (cdf_g1 - cdf_g0), 0), 0, 1)
     bins = bins_g0 + t * (bins_g1 - bins_g0)
+    bins = bins.detach()  # NS PDFSampler: "Stop gradients" — sample positions never carry gradient
     return _samples_from_bins(bins, prev.s_near, prev.s_far)
 
 
@@ -422,8 +440,11 @@ def positions_of(origins: Tensor, directions: Tensor, s: Samples) -> Tensor:
 def proposal_sampler(
     sd: Dict[str, Tensor], origins: Tensor, directions: Tensor, nears: Tensor, fars: Tensor,
     cfg: OracleConfig, jitter: Optional[Sequence[Tensor]] = None, anneal: float = 1.0,
+    proposal_requires_grad: bool = True,
 ) -> Tuple[Samples, List[Tensor], List[Samples]]:
-    """NS ProposalNetworkSampler.generate_ray_samples, invoked at [REF thermal_nerf_model.py:222-224]."""
+    """NS ProposalNetworkSampler.generate_ray_samples, invoked at [REF thermal_nerf_model.py:222-224].
+    ``proposal_requires_grad`` = NS's ``updated`` flag (steps_since_update > update_sched(step) or step < 10):
+    when False the proposal densities are evaluated under no_grad."""
     weights_list: List[Tensor] = []
     samples_list: List[Samples] = []
     n = len(cfg.num_proposal_samples_per_ray)
@@ -438,7 +459,11 @@ def proposal_sampler(
         else:
             s = sample_pdf(s, torch.pow(weights, anneal), num, jit)
         if is_prop:
-            density = proposal_density(sd, lvl, positions_of(origins, directions, s), cfg)
+            if proposal_requires_grad:
+                density = proposal_density(sd, lvl, positions_of(origins, directions, s), cfg)
+            else:
+                with torch.no_grad():
+                    density = proposal_density(sd, lvl, positions_of(origins, directions, s), cfg)
             weights = get_weights(s.deltas, density)
             weights_list.append(weights)
             samples_list.append(s)
@@ -448,12 +473,13 @@ def proposal_sampler(
 def get_outputs(
     sd: Dict[str, Tensor], origins: Tensor, directions: Tensor, camera_indices: Optional[Tensor],
     cfg: OracleConfig, training: bool = False, jitter: Optional[Sequence[Tensor]] = None,
-    anneal: float = 1.0, return_intermediates: bool = False,
+    anneal: float = 1.0, return_intermediates: bool = False, proposal_requires_grad: bool = True,
 ) -> Dict[str, Tensor]:
     """Model.forward (collider) + ThermalNerfModel.get_outputs [REF thermal_nerf_model.py:210-275].
     All inputs CPU fp32: origins/directions [R,3]; camera_indices [R,1] int64 (training only)."""
     nears, fars = collider(origins, cfg, training)
-    s, weights_list, samples_list = proposal_sampler(sd, origins, directions, nears, fars, cfg, jitter, anneal)
+    s, weights_list, samples_list = proposal_sampler(sd, origins, directions, nears, fars, cfg, jitter, anneal,
+                                                     proposal_requires_grad)
     pos = positions_of(origins, directions, s)
     density, geo = field_density(sd, pos, cfg)  # [REF thermal_field.py:186-190]
     dirs = directions[:, None, :].expand(-1, pos.shape[1], -1)

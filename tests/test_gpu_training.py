@@ -1,0 +1,299 @@
+"""GPU parity of the TRAINING step: every taped stage and its adjoint against torch autograd over the
+CPU oracle (oracle/hotpath.py + oracle/training.py), then the whole step (outputs, losses, every parameter gradient).
+
+Tolerances (written per test): the kernels are fp32 with a different summation order than torch's (tiled dots, atomics),
+so gradients are compared in relative L2 norm per tensor; values pointwise."""
+import copy
+
+import pytest
+import torch
+
+from oracle import hotpath as H
+from oracle import training as T
+from tests import helpers
+from thermo_nerf_amd import _hip
+from thermo_nerf_amd import training as TR
+from thermo_nerf_amd.rays import RayBundle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def lin_struct(w: torch.Tensor, b: torch.Tensor) -> _hip.tn_linear:
+    return _hip.tn_linear(w.data_ptr(), b.data_ptr(), w.shape[1], w.shape[0])
+
+
+# --------------------------------------------------------------------------------------------------
+# stages
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("IN,OUT,ldx,off,act", [
+    (32, 64, 32, 0, 1), (64, 16, 64, 0, 0), (63, 64, 64, 0, 1), (15, 64, 16, 1, 1), (64, 64, 64, 0, 2),
+    (64, 3, 64, 0, 2), (64, 1, 64, 0, 0), (10, 16, 10, 0, 1), (16, 1, 16, 0, 0)])
+@pytest.mark.parametrize("n", [1000, 64, 1])
+def test_linear_fwd_bwd(IN, OUT, ldx, off, act, n):
+    g = torch.Generator().manual_seed(IN * 100 + OUT + n)
+    xfull = torch.randn(n, ldx, generator=g)
+    w = (torch.randn(OUT, IN, generator=g) / IN**0.5).requires_grad_(True)
+    b = torch.randn(OUT, generator=g).requires_grad_(True)
+    x = xfull[:, off:off + IN].clone().requires_grad_(True)
+    y = torch.nn.functional.linear(x, w, b)
+    y = torch.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y
+    dy = torch.randn(n, OUT, generator=g)
+    y.backward(dy)
+
+    xd, wd, bd, dyd = xfull.to(DEV), w.detach().to(DEV), b.detach().to(DEV), dy.to(DEV)
+    lin = lin_struct(wd, bd)
+    yd = TR.linear_fwd(xd, off, ldx, lin, act, n)
+    assert (yd.cpu() - y.detach()).abs().max().item() <= 2e-5
+    dx = torch.full((n, ldx), 7.0, device=DEV)
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    TR.linear_bwd(xd, off, ldx, yd, dyd, OUT, lin, act, n, dx, off, ldx, False, dw, db)
+    assert rel(dx[:, off:off + IN], x.grad) <= 1e-5
+    if off:
+        assert torch.all(dx[:, :off] == 7.0), "columns outside the layer's input were touched"
+    assert rel(dw, w.grad) <= 1e-5 and rel(db, b.grad) <= 1e-5
+    # accumulate_dx adds on top; weight/bias gradients accumulate (+=)
+    TR.linear_bwd(xd, off, ldx, yd, dyd, OUT, lin, act, n, dx, off, ldx, True, dw, db)
+    assert rel(dx[:, off:off + IN], 2 * x.grad) <= 1e-5 and rel(dw, 2 * w.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("contraction", [True, False])
+def test_hash_encode_fwd_bwd(contraction):
+    L, log2T = 16, 15
+    g = torch.Generator().manual_seed(3)
+    table = (torch.rand(L << log2T, 2, generator=g) * 2 - 1).requires_grad_(True)
+    scal = H.hash_scalings(L, 16, 2048)
+    pos = (torch.rand(3000, 3, generator=g) * 2 - 1) * (3.0 if contraction else 1.3)
+    cfg = H.OracleConfig(disable_scene_contraction=not contraction)
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    p, sel = H.normalized_positions(pos, cfg, aabb)
+    enc = H.hash_encode(p, table, scal, log2T)
+    d_enc = torch.randn(enc.shape, generator=g)
+    enc.backward(d_enc)
+
+    grid = _hip.tn_hashgrid()
+    td = table.detach().to(DEV)
+    grid.table, grid.num_levels, grid.log2_hashmap_size = td.data_ptr(), L, log2T
+    for i, s in enumerate(scal.tolist()):
+        grid.scalings[i] = s
+    space = _hip.make_space(contraction, aabb)
+    e, s = TR.hash_encode_fwd(grid, space, pos.to(DEV))
+    assert torch.equal(s.cpu(), sel.float())
+    assert (e.cpu() - enc.detach()).abs().max().item() <= 1e-6
+    d_table = torch.zeros_like(td)
+    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), d_table)
+    assert rel(d_table, table.grad) <= 1e-5
+    # untouched entries stay exactly zero
+    assert torch.all(d_table.cpu()[table.grad == 0] == 0)
+
+
+@pytest.mark.parametrize("n", [48, 64, 96, 256, 300])
+def test_weights_bwd(n):
+    g = torch.Generator().manual_seed(n)
+    R = 37
+    deltas = torch.rand(R, n, generator=g) * 0.2
+    dens = (torch.rand(R, n, generator=g) * 4).requires_grad_(True)
+    dens.data[3, : n // 2] = 0.0
+    dens.data[5] *= 40.0  # saturates early: tiny transmittance behind
+    w = H.get_weights(deltas[..., None], dens[..., None])[..., 0]
+    gw = torch.randn(R, n, generator=g)
+    w.backward(gw)
+    got = TR.weights_bwd(deltas.to(DEV), dens.detach().to(DEV), gw.to(DEV))
+    assert rel(got, dens.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("C", [3, 1])
+def test_composite_bwd(C):
+    g = torch.Generator().manual_seed(C)
+    R, n = 41, 48
+    v = torch.rand(R, n, C, generator=g).requires_grad_(True)
+    w = (torch.rand(R, n, 1, generator=g) / n).requires_grad_(True)
+    out = H.render_rgb(v, w, True) if C == 3 else H.render_thermal(v, w, True)
+    go = torch.randn(R, C, generator=g)
+    out.backward(go)
+    lib = _hip.load()
+    vd, wd, god = v.detach().to(DEV), w.detach().reshape(R, n).to(DEV), go.to(DEV)
+    acc = wd.sum(dim=1).contiguous()
+    gv = torch.empty(R, n, C, device=DEV)
+    gw = torch.full((R, n), 0.5, device=DEV)  # (+=) on top of what is there
+    _hip.check(lib.tn_composite_bwd(vd.data_ptr(), wd.data_ptr(), acc.data_ptr(), god.data_ptr(), R, n, C, gv.data_ptr(),
+                                    gw.data_ptr(), _hip.current_stream()), "tn_composite_bwd")
+    assert rel(gv, v.grad) <= 1e-6
+    assert rel(gw - 0.5, w.grad[..., 0]) <= 1e-5
+
+
+def _levels(R, ns, seed):
+    """monotone spacing bins + positive weights per level, CPU"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for n in ns:
+        edges = torch.sort(torch.rand(R, n + 1, generator=g), dim=1).values
+        edges[:, 0], edges[:, -1] = 0.0, 1.0
+        w = torch.rand(R, n, generator=g)
+        w = w / w.sum(dim=1, keepdim=True) * torch.rand(R, 1, generator=g)
+        s = H.Samples(None, None, edges[:, :-1, None], edges[:, 1:, None], None, None)
+        out.append((s, w[..., None]))
+    return out
+
+
+@pytest.mark.parametrize("n", [48, 64, 192])
+def test_distortion_loss_and_gradient(n):
+    (s, w), = _levels(29, [n], n)
+    w = w.clone().requires_grad_(True)
+    want = T.distortion_loss([w], [s])
+    want.backward()
+
+    class RS:  # what training.distortion_loss reads from a RaySamples
+        spacing_bins = torch.cat([s.spacing_starts[..., 0], s.spacing_ends[:, -1:, 0]], dim=1).to(DEV)
+
+    wd = w.detach().to(DEV).requires_grad_(True)
+    got = TR.distortion_loss([wd], [RS])
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-8
+    assert rel(wd.grad, w.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("ns", [(256, 96, 48), (64, 300, 192), (5, 7, 3)])
+def test_interlevel_loss_and_gradient(ns):
+    lv = _levels(23, ns, sum(ns))
+    ws = [w.clone().requires_grad_(True) for _, w in lv]
+    want = T.interlevel_loss(ws, [s for s, _ in lv])
+    want.backward()
+
+    def rs(s):
+        class RS:
+            spacing_bins = torch.cat([s.spacing_starts[..., 0], s.spacing_ends[:, -1:, 0]], dim=1).to(DEV)
+        return RS
+
+    wd = [w.detach().to(DEV).requires_grad_(True) for w in ws]
+    got = TR.interlevel_loss(wd, [rs(s) for s, _ in lv])
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-9
+    for a, b in zip(wd[:-1], ws[:-1]):
+        assert rel(a.grad, b.grad) <= 2e-5
+    assert wd[-1].grad is None and ws[-1].grad is None  # the final level is detached in this loss
+
+
+# --------------------------------------------------------------------------------------------------
+# the whole step
+# --------------------------------------------------------------------------------------------------
+def _train_setup(kind, S, R_hw=(12, 12), seed=11, **over):
+    cm, sd, ocfg = helpers.build(kind, S, camera_optimizer_mode="off", **over)
+    gm = copy.deepcopy(cm).to(DEV)
+    gm.train()
+    o, d = helpers.rays(*R_hw, view=3)
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(seed)
+    jit = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    cam = torch.randint(0, 8, (R, 1), generator=g)
+    batch = {"image": torch.rand(R, 3, generator=g), "thermal": torch.rand(R, 1, generator=g)}
+    return gm, sd, ocfg, o, d, jit, cam, batch
+
+
+def _gpu_step(gm, o, d, jit, cam, batch):
+    rb = RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV))
+    rb = gm.collider(rb)
+    out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    metrics = gm.get_metrics_dict(out, b)
+    loss_dict = gm.get_loss_dict(out, b, metrics)
+    gm.zero_grad(set_to_none=True)
+    sum(loss_dict.values()).backward()
+    return out, loss_dict
+
+
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+@pytest.mark.parametrize("S", [48, 64])
+def test_training_step_matches_autograd_oracle(kind, S):
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S)
+    out, loss_dict = _gpu_step(gm, o, d, jit, cam, batch)
+    want_out, want_loss, want_grads = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit)
+    # forward values: same tolerances as the forward parity tests
+    for k in ("rgb", "thermal", "accumulation"):
+        assert (out[k].detach().cpu() - want_out[k].detach()).abs().max().item() <= 2e-5, k
+    for i in range(3):
+        assert (out["weights_list"][i].detach().cpu() - want_out["weights_list"][i].detach()).abs().max().item() <= 2e-5
+    for k, v in want_loss.items():
+        assert abs(loss_dict[k].item() - v.item()) <= 2e-5 * abs(v.item()) + 1e-8, (k, loss_dict[k].item(), v.item())
+    # every parameter gradient, relative L2 per tensor (fp32, different summation order, atomics)
+    named = dict(gm.named_parameters())
+    checked = 0
+    for name, gw in want_grads.items():
+        if gw.numel() == 0 or name.startswith("camera_optimizer"):
+            continue
+        gg = named[name].grad
+        if gw.norm().item() == 0.0:
+            assert gg is None or gg.abs().max().item() == 0.0, name
+            continue
+        assert gg is not None, f"{name}: no gradient"
+        assert rel(gg, gw) <= 2e-3, f"{name}: rel {rel(gg, gw):.2e} (|g| {gw.norm().item():.2e})"
+        checked += 1
+    assert checked >= 25
+
+
+def test_proposal_networks_frozen_between_updates():
+    """NS ProposalNetworkSampler: off the update schedule the proposal densities are evaluated under no_grad."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48)
+    gm.set_step(2000)          # update_sched(2000) = 2 > steps_since_update = 1, step >= 10 -> not updated
+    assert gm.proposal_sampler._steps_since_update == 1
+    _gpu_step(gm, o, d, jit, cam, batch)
+    for n, p in gm.named_parameters():
+        if n.startswith("proposal_networks"):
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, n
+    assert gm.field.mlp_base.encoder.hash_table.grad.abs().max().item() > 0
+    _, _, want = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit, anneal=gm.proposal_sampler._anneal,
+                                  proposal_requires_grad=False)
+    assert rel(gm.field.mlp_head.layers[1].weight.grad, want["field.mlp_head.layers.1.weight"]) <= 2e-3
+
+
+def test_pass_thermal_gradients_false_detaches_geo():
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48)
+    _gpu_step(gm, o, d, jit, cam, batch)
+    g_on = gm.field.mlp_base.mlp.layers[1].weight.grad.clone()
+    gm.field.pass_thermal_gradients = False  # REF thermal_field.py:171-172 detaches; REF model :319 drops the loss too
+    _, ld = _gpu_step(gm, o, d, jit, cam, batch)
+    assert "thermal" not in ld
+    assert not torch.equal(g_on, gm.field.mlp_base.mlp.layers[1].weight.grad)
+    assert gm.field.mlp_thermal.layers[0].weight.grad is None
+
+
+def test_adam_steps_reduce_the_loss_and_eval_follows():
+    """A few optimizer steps on one batch lower the loss; the eval path then renders with the UPDATED weights
+    (prepared MFMA blobs are rebuilt when parameter versions change)."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("init", 48)
+    batch = {"image": torch.full_like(batch["image"], 0.85), "thermal": torch.full_like(batch["thermal"], 0.2)}
+    groups = gm.get_param_groups()
+    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}], lr=1e-2, eps=1e-15)
+    losses = []
+    for step in range(20):
+        gm.set_step(step)
+        _, ld = _gpu_step(gm, o, d, jit, cam, batch)
+        losses.append(sum(v.item() for v in ld.values()))
+        opt.step()
+    assert losses[-1] < 0.5 * losses[0], losses
+    gm.eval()
+    rb = RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=torch.zeros_like(cam).to(DEV))
+    with torch.no_grad():
+        got = gm(rb)
+    sd_new = {k: v.detach().cpu() for k, v in gm.state_dict().items()}
+    want = H.get_outputs(sd_new, o, d, None, ocfg)
+    # 20 Adam steps at lr 1e-2 move the touched table entries by ~0.2 next to untouched ~1e-4 neighbours: a field with
+    # steep spatial gradients, where ulp-level position differences show up at 1e-4.  Stale weights would be off by ~0.1.
+    assert (got["rgb"].cpu() - want["rgb"]).abs().max().item() <= 2e-3
+    assert (got["thermal"].cpu() - want["thermal"]).abs().max().item() <= 2e-3
+    assert (got["rgb"].cpu() - want["rgb"]).abs().mean().item() <= 2e-4
+
+
+def test_camera_pose_gradients_are_refused():
+    cm, _, _ = helpers.build("init", 48)  # default camera_optimizer_mode = SO3xR3, as in the reference
+    gm = copy.deepcopy(cm).to(DEV).train()
+    o, d = helpers.rays(4, 4)
+    rb = gm.collider(RayBundle(origins=o.to(DEV), directions=d.to(DEV),
+                               camera_indices=torch.zeros(o.shape[0], 1, dtype=torch.long, device=DEV)))
+    with pytest.raises(NotImplementedError, match="camera"):
+        gm.get_outputs(rb)

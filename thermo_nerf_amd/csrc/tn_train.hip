@@ -1,0 +1,720 @@
+// Training-step building blocks: taped forward, losses, backward.
+//
+// A training batch is small next to a rendered frame (4096 rays x (256 + 96 + S) samples), so the step is laid out
+// stage by stage on [N, width] fp32 matrices in HBM instead of as one fused kernel: every stage is a short kernel
+// with an exact adjoint, the tape (per-sample activations) is a few hundred MB that stays in L2/MALL, and the heavy
+// part — the hash-table scatter-add — is atomics-bound whatever surrounds it.
+//
+//   tn_hash_encode_fwd / _bwd     NS HashEncoding.pytorch_fwd and its adjoint w.r.t. the table (fp32 atomics)
+//   tn_linear_fwd / _bwd          torch.nn.Linear + ReLU/Sigmoid; bwd gives dx, dW (+=), db (+=)
+//   tn_density_act_fwd / _bwd     average_init_density * trunc_exp(raw) * selector
+//   tn_weights_bwd                adjoint of RaySamples.get_weights (reverse wave scan per ray)
+//   tn_composite_bwd              adjoint of the "last_sample" compositing (RGB, thermal)
+//   tn_color_input_fwd / _bwd     [SH | geo | appearance] assembly of mlp_head's input; embedding gradient
+//   tn_distortion_loss            NS lossfun_distortion in O(n) per ray (sorted mid-points -> prefix sums)
+//   tn_interlevel_loss            NS lossfun_outer: envelope look-ups + gradient by difference arrays
+#include "tn_field_eval.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+using namespace tn;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
+
+inline int grid_for(long long work, int block, int cap) {
+    long long b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// hash encoding
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+hash_encode_fwd_kernel(Grid g, tn_space space, const float *__restrict__ positions, long long n,
+                       float *__restrict__ enc, float *__restrict__ selector) {
+    const Space sp = make_space(space);
+    const int L = g.num_levels;
+    const long long total = n * L;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long long)gridDim.x * kBlock) {
+        const long long i = t / L;
+        const int l = (int)(t - i * L);
+        float px, py, pz;
+        const float sel = normalize_position(sp, positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2], px, py, pz);
+        const float2 f = encode_level<false, false>(g, l, px, py, pz);
+        reinterpret_cast<float2 *>(enc)[t] = f;
+        if (l == 0 && selector) selector[i] = sel;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positions, const float *__restrict__ d_enc,
+                       long long n, float *__restrict__ d_table) {
+    const Space sp = make_space(space);
+    const int L = g.num_levels;
+    const long long total = n * L;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long long)gridDim.x * kBlock) {
+        const float2 ge = reinterpret_cast<const float2 *>(d_enc)[t];
+        if (ge.x == 0.0f && ge.y == 0.0f) continue;
+        const long long i = t / L;
+        const int l = (int)(t - i * L);
+        float px, py, pz;
+        normalize_position(sp, positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2], px, py, pz);
+        // same corner / offset arithmetic as encode_level<false>
+        const float s = g.scal[l];
+        const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+        const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+        const float ox = sub_rn(sx, fxf), oy = sub_rn(sy, fyf), oz = sub_rn(sz, fzf);
+        const float qx = sub_rn(1.0f, ox), qy = sub_rn(1.0f, oy), qz = sub_rn(1.0f, oz);
+        const unsigned cx = (unsigned)(int)ceilf(sx), cy = (unsigned)(int)ceilf(sy), cz = (unsigned)(int)ceilf(sz);
+        const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
+        const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
+        float *tb = d_table + ((size_t)l * g.tsize) * 2;
+        const unsigned m = g.mask;
+        // enc = ((f0 ox + f3 qx) oy + (f1 ox + f2 qx) qy) oz + ((f4 ox + f7 qx) oy + (f5 ox + f6 qx) qy) qz
+        const unsigned idx[8] = {(cx ^ hcy ^ hcz) & m, (cx ^ hfy ^ hcz) & m, (fx ^ hfy ^ hcz) & m, (fx ^ hcy ^ hcz) & m,
+                                 (cx ^ hcy ^ hfz) & m, (cx ^ hfy ^ hfz) & m, (fx ^ hfy ^ hfz) & m, (fx ^ hcy ^ hfz) & m};
+        const float wgt[8] = {ox * oy * oz, ox * qy * oz, qx * qy * oz, qx * oy * oz,
+                              ox * oy * qz, ox * qy * qz, qx * qy * qz, qx * oy * qz};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (wgt[c] != 0.0f) {
+                atomic_add_f32(tb + (size_t)idx[c] * 2, wgt[c] * ge.x);
+                atomic_add_f32(tb + (size_t)idx[c] * 2 + 1, wgt[c] * ge.y);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Linear layers.  A block owns tiles of 64 rows (samples); 256 threads = 64 rows x 4 column groups.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == TN_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == TN_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+__device__ __forceinline__ float act_bwd(float y, int act) {  // derivative expressed through the OUTPUT y
+    if (act == TN_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    if (act == TN_ACT_SIGMOID) return y * (1.0f - y);
+    return 1.0f;
+}
+
+constexpr int TILE = 64;
+constexpr int LDP = 65;  // padded row length of the row tiles in LDS (odd: conflict-free column walks)
+
+// NO = outputs per thread (OUT <= 4 * NO)
+template <int NO>
+__global__ void __launch_bounds__(kBlock)
+linear_fwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ W, const float *__restrict__ b,
+                  int IN, int OUT, int act, long long n, float *__restrict__ y, int ldy) {
+    constexpr int OUTP = 4 * NO;
+    __shared__ __attribute__((aligned(16))) float Wt[64 * OUTP];  // [i][o]
+    __shared__ float bs[OUTP];
+    __shared__ float xs[TILE * LDP];
+    for (int e = threadIdx.x; e < IN * OUTP; e += kBlock) {
+        const int i = e / OUTP, o = e - i * OUTP;
+        Wt[e] = o < OUT ? W[o * IN + i] : 0.0f;
+    }
+    if (threadIdx.x < OUTP) bs[threadIdx.x] = (threadIdx.x < OUT && b) ? b[threadIdx.x] : 0.0f;
+    const int s = threadIdx.x & 63, og = threadIdx.x >> 6;
+    const long long tiles = (n + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        __syncthreads();
+        for (int e = threadIdx.x; e < TILE * IN; e += kBlock) {
+            const int r = e / IN, i = e - r * IN;
+            xs[r * LDP + i] = base + r < n ? x[(base + r) * ldx + i] : 0.0f;
+        }
+        __syncthreads();
+        float acc[NO];
+#pragma unroll
+        for (int k = 0; k < NO; ++k) acc[k] = bs[og * NO + k];
+        for (int i = 0; i < IN; ++i) {
+            const float xv = xs[s * LDP + i];
+            const float *wr = Wt + i * OUTP + og * NO;
+#pragma unroll
+            for (int k = 0; k < NO; ++k) acc[k] = fmaf(wr[k], xv, acc[k]);
+        }
+        if (base + s < n) {
+#pragma unroll
+            for (int k = 0; k < NO; ++k) {
+                const int o = og * NO + k;
+                if (o < OUT) y[(base + s) * ldy + o] = act_fwd(acc[k], act);
+            }
+        }
+    }
+}
+
+// NI = inputs per thread (IN <= 4 * NI)
+template <int NI>
+__global__ void __launch_bounds__(kBlock)
+linear_bwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ y, const float *__restrict__ dy, int ldy,
+                  const float *__restrict__ W, int IN, int OUT, int act, long long n, float *__restrict__ dx, int lddx,
+                  int accumulate_dx, float *__restrict__ dW, float *__restrict__ db) {
+    constexpr int INP = 4 * NI;
+    __shared__ __attribute__((aligned(16))) float Ws[64 * INP];  // [o][i], zero padded
+    __shared__ float gs[TILE * LDP];                               // g = dy * act'(y)   [row][o]
+    __shared__ float xs[TILE * LDP];                               // [row][i]
+    for (int e = threadIdx.x; e < OUT * INP; e += kBlock) {
+        const int o = e / INP, i = e - o * INP;
+        Ws[e] = i < IN ? W[o * IN + i] : 0.0f;
+    }
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float accw[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) accw[k] = 0.0f;
+    float accb = 0.0f;
+    const bool want_w = dW != nullptr || db != nullptr;
+    const long long tiles = (n + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        __syncthreads();
+        for (int e = threadIdx.x; e < TILE * OUT; e += kBlock) {
+            const int r = e / OUT, o = e - r * OUT;
+            float g = 0.0f;
+            if (base + r < n) {
+                const size_t a = (size_t)(base + r) * ldy + o;
+                g = dy[a] * act_bwd(act == TN_ACT_NONE ? 0.0f : y[a], act);
+            }
+            gs[r * LDP + o] = g;
+        }
+        if (want_w) {
+            for (int e = threadIdx.x; e < TILE * INP; e += kBlock) {
+                const int r = e / INP, i = e - r * INP;
+                xs[r * LDP + i] = (base + r < n && i < IN) ? x[(base + r) * ldx + i] : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (dx) {  // dx[row = lane][i = grp*NI + k] = sum_o g[row][o] W[o][i]
+            float acc[NI];
+#pragma unroll
+            for (int k = 0; k < NI; ++k) acc[k] = 0.0f;
+            for (int o = 0; o < OUT; ++o) {
+                const float gv = gs[lane * LDP + o];
+                const float *wr = Ws + o * INP + grp * NI;
+#pragma unroll
+                for (int k = 0; k < NI; ++k) acc[k] = fmaf(wr[k], gv, acc[k]);
+            }
+            if (base + lane < n) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int i = grp * NI + k;
+                    if (i < IN) {
+                        float *p = dx + (size_t)(base + lane) * lddx + i;
+                        *p = accumulate_dx ? *p + acc[k] : acc[k];
+                    }
+                }
+            }
+        }
+        if (want_w && lane < OUT) {  // dW[o = lane][i = grp*NI + k] += sum_rows g[row][o] x[row][i]
+            for (int r = 0; r < TILE; ++r) {
+                const float gv = gs[r * LDP + lane];
+                const float *xr = xs + r * LDP + grp * NI;
+#pragma unroll
+                for (int k = 0; k < NI; ++k) accw[k] = fmaf(xr[k], gv, accw[k]);
+                if (grp == 0) accb += gv;
+            }
+        }
+    }
+    if (want_w && lane < OUT) {
+        if (dW) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int i = grp * NI + k;
+                if (i < IN) atomic_add_f32(dW + lane * IN + i, accw[k]);
+            }
+        }
+        if (db && grp == 0) atomic_add_f32(db + lane, accb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// density activation
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+density_act_fwd_kernel(const float *__restrict__ raw, int ld, const float *__restrict__ sel, float avg, long long n,
+                       float *__restrict__ density) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+        density[i] = mul_rn(mul_rn(avg, expf(raw[i * ld])), sel[i]);
+}
+__global__ void __launch_bounds__(kBlock)
+density_act_bwd_kernel(const float *__restrict__ raw, int ld, const float *__restrict__ sel, float avg,
+                       const float *__restrict__ dd, long long n, float *__restrict__ d_raw, int ldd) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+        d_raw[i * ldd] = dd[i] * sel[i] * avg * expf(fminf(raw[i * ld], 15.0f));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// get_weights backward: one wave per ray, chunks of 64 samples walked back to front.
+//   a_i = delta_i sigma_i,  T_i = exp(-sum_{j<i} a_j),  w_i = (1 - e^{-a_i}) T_i
+//   dL/da_k = g_k e^{-a_k} T_k - sum_{i>k} g_i w_i
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_scan_rev(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += t;
+    }
+    return v;
+}
+
+constexpr int kMaxChunks = 16;  // n <= 1024
+
+__global__ void __launch_bounds__(kBlock)
+weights_bwd_kernel(const float *__restrict__ deltas, const float *__restrict__ dens, const float *__restrict__ gw,
+                   long long R, int n, float *__restrict__ gd) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float *dl = deltas + ray * n, *dn = dens + ray * n, *g = gw + ray * n;
+    float *out = gd + ray * n;
+    const int chunks = (n + 63) / 64;
+    float csum[kMaxChunks];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        csum[c] = 0.0f;
+        if (c < chunks) {
+            const int i = c * 64 + lane;
+            csum[c] = wave_sum(i < n ? mul_rn(dl[i], dn[i]) : 0.0f);
+        }
+    }
+    float suffix = 0.0f;  // sum of g_i w_i over the chunks behind this one
+#pragma unroll
+    for (int c = kMaxChunks - 1; c >= 0; --c) {
+        if (c >= chunks) continue;
+        float before = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q)
+            if (q < c) before += csum[q];
+        const int i = c * 64 + lane;
+        const bool live = i < n;
+        const float a = live ? mul_rn(dl[i], dn[i]) : 0.0f;
+        const float incl = wave_incl_scan(a, lane);
+        const float excl = wave_excl_from_incl(incl, lane) + before;
+        const float T = expf(-excl), ea = expf(-a);
+        const float w = (1.0f - ea) * T;
+        const float gi = live ? g[i] : 0.0f;
+        const float gwv = live ? gi * w : 0.0f;
+        const float rincl = wave_incl_scan_rev(gwv, lane);
+        const float behind = rincl - gwv + suffix;  // sum_{i > k}
+        if (live) out[i] = dl[i] * (gi * ea * T - behind);
+        suffix += __shfl(rincl, 0, 64);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// compositing backward (training mode):  out_c = sum_i w_i v_ic + v_last,c (1 - acc)
+// ------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(kBlock)
+composite_bwd_kernel(const float *__restrict__ v, const float *__restrict__ w, const float *__restrict__ acc,
+                     const float *__restrict__ go, long long R, int n, float *__restrict__ gv, float *__restrict__ gw) {
+    const long long total = R * n;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long long)gridDim.x * kBlock) {
+        const long long r = t / n;
+        const int i = (int)(t - r * n);
+        const float wi = w[t];
+        const float bg = 1.0f - acc[r];
+        float dwi = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float g = go[r * C + c];
+            gv[t * C + c] = g * (i == n - 1 ? wi + bg : wi);
+            dwi += g * (v[t * C + c] - v[(r * n + n - 1) * C + c]);
+        }
+        gw[t] += dwi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// mlp_head input
+// ------------------------------------------------------------------------------------------------------
+struct CinArgs {
+    const float *appearance;
+    int num_images, app_dim, geo_dim, use_avg, sh_shifted, training;
+};
+
+__global__ void __launch_bounds__(kBlock)
+color_input_fwd_kernel(CinArgs a, const float *__restrict__ dirs, const float *__restrict__ geo, int ld_geo,
+                       const int *__restrict__ cams, long long R, int n, float *__restrict__ cin) {
+    const long long total = R * n;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long long)gridDim.x * kBlock) {
+        const long long r = t / n;
+        float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+        if (a.sh_shifted) {
+            dx = add_rn(dx, 1.0f) / 2.0f; dy = add_rn(dy, 1.0f) / 2.0f; dz = add_rn(dz, 1.0f) / 2.0f;
+        }
+        float c[16];
+        sh16(dx, dy, dz, c);
+        float *o = cin + t * 64;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = c[k];
+        for (int k = 0; k < a.geo_dim; ++k) o[16 + k] = geo[t * ld_geo + k];
+        float *oa = o + 16 + a.geo_dim;
+        if (a.training) {
+            const float *e = a.appearance + (size_t)cams[r] * a.app_dim;
+            for (int k = 0; k < a.app_dim; ++k) oa[k] = e[k];
+        } else if (a.use_avg) {
+            for (int k = 0; k < a.app_dim; ++k) {
+                float s = 0.0f;
+                for (int j = 0; j < a.num_images; ++j) s += a.appearance[(size_t)j * a.app_dim + k];
+                oa[k] = s / (float)a.num_images;
+            }
+        } else {
+            for (int k = 0; k < a.app_dim; ++k) oa[k] = 0.0f;
+        }
+        for (int k = 16 + a.geo_dim + a.app_dim; k < 64; ++k) o[k] = 0.0f;
+    }
+}
+
+// geo part: one thread per (sample, geo component)
+__global__ void __launch_bounds__(kBlock)
+color_input_bwd_geo_kernel(int geo_dim, const float *__restrict__ d_cin, long long N, float *__restrict__ d_geo, int ldg) {
+    const long long total = N * geo_dim;
+    for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long long)gridDim.x * kBlock) {
+        const long long i = t / geo_dim;
+        const int k = (int)(t - i * geo_dim);
+        d_geo[i * ldg + k] += d_cin[i * 64 + 16 + k];
+    }
+}
+
+// appearance part: one wave per ray sums its samples first, then app_dim atomics per ray
+__global__ void __launch_bounds__(kBlock)
+color_input_bwd_app_kernel(int geo_dim, int app_dim, const float *__restrict__ d_cin, const int *__restrict__ cams,
+                           long long R, int n, float *__restrict__ d_app) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const int k = lane & 31, half = lane >> 5;
+    float s = 0.0f;
+    if (k < app_dim)
+        for (int i = half; i < n; i += 2) s += d_cin[(ray * n + i) * 64 + 16 + geo_dim + k];
+    s += __shfl_xor(s, 32, 64);
+    if (half == 0 && k < app_dim) atomic_add_f32(d_app + (size_t)cams[ray] * app_dim + k, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// distortion loss: one wave per ray.  With sorted mid-points u:
+//   S_i = sum_j w_j |u_i - u_j| = u_i (W_<i - W_>i) - (WU_<i - WU_>i)
+//   loss = sum_i w_i S_i + sum_i w_i^2 d_i / 3,   dloss/dw_i = 2 S_i + 2 w_i d_i / 3
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weights, long long R, int n,
+                  float *__restrict__ loss_sum, float *__restrict__ gw) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float *t = bins + ray * (n + 1), *w = weights + ray * n;
+    const int chunks = (n + 63) / 64;
+    float W = 0.0f, WU = 0.0f;
+    for (int c = 0; c < chunks; ++c) {
+        const int i = c * 64 + lane;
+        const float wi = i < n ? w[i] : 0.0f;
+        const float ui = i < n ? (t[i + 1] + t[i]) / 2.0f : 0.0f;
+        W += wave_sum(wi);
+        WU += wave_sum(wi * ui);
+    }
+    float cW = 0.0f, cWU = 0.0f, loss = 0.0f;
+    for (int c = 0; c < chunks; ++c) {
+        const int i = c * 64 + lane;
+        const bool live = i < n;
+        const float wi = live ? w[i] : 0.0f;
+        const float t0 = live ? t[i] : 0.0f, t1 = live ? t[i + 1] : 0.0f;
+        const float ui = (t1 + t0) / 2.0f, di = t1 - t0;
+        const float iw = wave_incl_scan(wi, lane), iwu = wave_incl_scan(wi * ui, lane);
+        const float Wlt = cW + iw - wi, WUlt = cWU + iwu - wi * ui;
+        const float Wgt = W - Wlt - wi, WUgt = WU - WUlt - wi * ui;
+        const float Si = ui * (Wlt - Wgt) - (WUlt - WUgt);
+        if (live) {
+            gw[ray * n + i] = 2.0f * Si + 2.0f * wi * di / 3.0f;
+            loss += wi * Si + wi * wi * di / 3.0f;
+        }
+        cW += __shfl(iw, 63, 64);
+        cWU += __shfl(iwu, 63, 64);
+    }
+    loss = wave_sum(loss);
+    if (lane == 0) atomic_add_f32(loss_sum, loss);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// interlevel loss (one proposal level): one wave per ray, LDS per wave: cp[p+1], cum[p+1], d_hi[p], d_lo[p+1]
+// ------------------------------------------------------------------------------------------------------
+constexpr int kMaxP = 1024;
+
+__device__ __forceinline__ int upper_bound(const float *a, int len, float x) {  // first index with a[idx] > x
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] > x) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(kBlock)
+interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, const float *__restrict__ cp,
+                  const float *__restrict__ wp, long long R, int n, int p, float *__restrict__ loss_sum,
+                  float *__restrict__ g_wp) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + wave;
+    if (ray >= R) return;
+    const int stride = 4 * (p + 2);
+    float *edges = lds + wave * stride;  // [p+1]
+    float *cum = edges + (p + 2);        // [p+1] exclusive cumsum of wp (cum[p] = total)
+    float *dhi = cum + (p + 2);          // [p]   + coef at hi
+    float *dlo = dhi + (p + 2);          // [p+1] + coef at lo
+    const float *cpr = cp + ray * (p + 1), *wpr = wp + ray * p;
+    float carry = 0.0f;
+    for (int b = 0; b <= p; b += 64) {
+        const int k = b + lane;
+        if (k <= p) edges[k] = cpr[k];
+        const float v = k < p ? wpr[k] : 0.0f;
+        const float incl = wave_incl_scan(v, lane);
+        if (k <= p) cum[k] = carry + incl - v;
+        if (k <= p) { dlo[k] = 0.0f; if (k < p) dhi[k] = 0.0f; }
+        carry += __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const float *cr = c + ray * (n + 1), *wr = w + ray * n;
+    float loss = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+        int lo = upper_bound(edges, p, cr[i]) - 1;          // searchsorted(starts = cp[:-1], right) - 1
+        lo = min(max(lo, 0), p - 1);
+        int hi = upper_bound(edges + 1, p, cr[i + 1]);       // searchsorted(ends = cp[1:], right)
+        hi = min(max(hi, 0), p - 1);
+        const float w_outer = cum[hi + 1] - cum[lo];
+        const float wi = wr[i];
+        const float d = fmaxf(wi - w_outer, 0.0f);
+        const float den = wi + 1.0e-7f;
+        loss += d * d / den;
+        const float coef = -2.0f * d / den;  // d loss / d w_outer
+        if (coef != 0.0f) {
+            atomicAdd(&dhi[hi], coef);  // + coef on every k <= hi
+            atomicAdd(&dlo[lo], coef);  // - coef on every k <  lo
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // grad_k = sum_{h >= k} dhi[h] - sum_{l > k} dlo[l]; walk the chunks back to front
+    float s_hi = 0.0f, s_lo = 0.0f;
+    for (int b = ((p - 1) / 64) * 64; b >= 0; b -= 64) {
+        const int k = b + lane;
+        const float vh = k < p ? dhi[k] : 0.0f;
+        const float vl = k < p ? dlo[k + 1] : 0.0f;  // shifted by one: sum_{j >= k} dlo[j + 1] = sum_{l > k} dlo[l]
+        const float rh = wave_incl_scan_rev(vh, lane);
+        const float rl = wave_incl_scan_rev(vl, lane);
+        if (k < p) g_wp[ray * p + k] = (s_hi + rh) - (s_lo + rl);
+        s_hi += __shfl(rh, 0, 64);
+        s_lo += __shfl(rl, 0, 64);
+    }
+    loss = wave_sum(loss);
+    if (lane == 0) atomic_add_f32(loss_sum, loss);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, int64_t n, float *enc,
+                       float *selector, void *stream) {
+    if (!grid || !space) return TN_ERR_NULL;
+    TN_TRY(tn_check_grid(*grid));
+    if (n == 0) return TN_OK;
+    if (!positions || !enc) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(hash_encode_fwd_kernel, dim3(grid_for(n * grid->num_levels, kBlock, 1 << 16)), dim3(kBlock), 0,
+                       (hipStream_t)stream, tn_make_grid(*grid), *space, positions, (long long)n, enc, selector);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                       int64_t n, float *d_table, void *stream) {
+    if (!grid || !space) return TN_ERR_NULL;
+    TN_TRY(tn_check_grid(*grid));
+    if (n == 0) return TN_OK;
+    if (!positions || !d_enc || !d_table) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(hash_encode_bwd_kernel, dim3(grid_for(n * grid->num_levels, kBlock, 1 << 16)), dim3(kBlock), 0,
+                       (hipStream_t)stream, tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_table);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act, int64_t n, float *y, int32_t ldy,
+                  void *stream) {
+    if (!lin || !lin->weight) return TN_ERR_NULL;
+    const int IN = lin->in_dim, OUT = lin->out_dim;
+    if (IN < 1 || IN > 64 || OUT < 1 || OUT > 64 || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
+    if (act < TN_ACT_NONE || act > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
+    if (n == 0) return TN_OK;
+    if (!x || !y) return TN_ERR_NULL;
+    const dim3 g(grid_for((n + TILE - 1) / TILE, 1, 4096)), b(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (OUT <= 4)
+        hipLaunchKernelGGL(linear_fwd_kernel<1>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy);
+    else if (OUT <= 16)
+        hipLaunchKernelGGL(linear_fwd_kernel<4>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy);
+    else
+        hipLaunchKernelGGL(linear_fwd_kernel<16>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, int32_t ldy, const tn_linear *lin,
+                  int32_t act, int64_t n, float *dx, int32_t lddx, int32_t accumulate_dx, float *d_weight,
+                  float *d_bias, void *stream) {
+    if (!lin || !lin->weight) return TN_ERR_NULL;
+    const int IN = lin->in_dim, OUT = lin->out_dim;
+    if (IN < 1 || IN > 64 || OUT < 1 || OUT > 64 || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
+    if (dx && lddx < IN) return TN_ERR_SHAPE;
+    if (act < TN_ACT_NONE || act > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
+    if (n == 0) return TN_OK;
+    if (!dy || (act != TN_ACT_NONE && !y) || ((d_weight || d_bias) && !x)) return TN_ERR_NULL;
+    // few persistent blocks: each ends with one atomic per weight entry
+    const dim3 g(grid_for((n + TILE - 1) / TILE, 1, 512)), b(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (IN <= 16)
+        hipLaunchKernelGGL(linear_bwd_kernel<4>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
+                           lddx, accumulate_dx, d_weight, d_bias);
+    else if (IN <= 32)
+        hipLaunchKernelGGL(linear_bwd_kernel<8>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
+                           lddx, accumulate_dx, d_weight, d_bias);
+    else
+        hipLaunchKernelGGL(linear_bwd_kernel<16>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
+                           lddx, accumulate_dx, d_weight, d_bias);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_density_act_fwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density, int64_t n,
+                       float *density, void *stream) {
+    if (n == 0) return TN_OK;
+    if (!raw || !selector || !density) return TN_ERR_NULL;
+    if (n < 0 || ld_raw < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(density_act_fwd_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, raw,
+                       ld_raw, selector, average_init_density, (long long)n, density);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density,
+                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, void *stream) {
+    if (n == 0) return TN_OK;
+    if (!raw || !selector || !d_density || !d_raw) return TN_ERR_NULL;
+    if (n < 0 || ld_raw < 1 || ld_d_raw < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(density_act_bwd_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, raw,
+                       ld_raw, selector, average_init_density, d_density, (long long)n, d_raw, ld_d_raw);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
+                   float *d_densities, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!deltas || !densities || !d_weights || !d_densities) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1 || n > 64 * kMaxChunks) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(weights_bwd_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, deltas,
+                       densities, d_weights, (long long)num_rays, n, d_densities);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_composite_bwd(const float *values, const float *weights, const float *accumulation, const float *d_out,
+                     int64_t num_rays, int32_t n, int32_t channels, float *d_values, float *d_weights, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!values || !weights || !accumulation || !d_out || !d_values || !d_weights) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    const dim3 g(grid_for(num_rays * n, kBlock, 1 << 16)), b(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (channels == 3)
+        hipLaunchKernelGGL(composite_bwd_kernel<3>, g, b, 0, st, values, weights, accumulation, d_out, (long long)num_rays, n,
+                           d_values, d_weights);
+    else if (channels == 1)
+        hipLaunchKernelGGL(composite_bwd_kernel<1>, g, b, 0, st, values, weights, accumulation, d_out, (long long)num_rays, n,
+                           d_values, d_weights);
+    else
+        return TN_ERR_UNSUPPORTED;
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+static int cin_args(const tn_thermal_field *f, int training, CinArgs *a) {
+    if (!f) return TN_ERR_NULL;
+    if (f->geo_feat_dim < 1 || f->app_dim < 0 || 16 + f->geo_feat_dim + f->app_dim > 64) return TN_ERR_SHAPE;
+    if (f->app_dim > 32) return TN_ERR_UNSUPPORTED;
+    if (f->app_dim > 0 && (training || f->use_average_appearance) && !f->appearance) return TN_ERR_NULL;
+    a->appearance = f->appearance; a->num_images = f->num_images; a->app_dim = f->app_dim; a->geo_dim = f->geo_feat_dim;
+    a->use_avg = f->use_average_appearance; a->sh_shifted = f->sh_shifted; a->training = training;
+    return TN_OK;
+}
+
+int tn_color_input_fwd(const tn_thermal_field *field, const float *directions, const float *geo, int32_t ld_geo,
+                       const int32_t *camera_indices, int32_t training, int64_t num_rays, int32_t n, float *cin,
+                       void *stream) {
+    CinArgs a;
+    TN_TRY(cin_args(field, training, &a));
+    if (num_rays == 0) return TN_OK;
+    if (!directions || !geo || !cin || (training && !camera_indices)) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1 || ld_geo < a.geo_dim) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(color_input_fwd_kernel, dim3(grid_for(num_rays * n, kBlock, 1 << 16)), dim3(kBlock), 0,
+                       (hipStream_t)stream, a, directions, geo, ld_geo, camera_indices, (long long)num_rays, n, cin);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const int32_t *camera_indices,
+                       int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
+                       float *d_appearance, void *stream) {
+    CinArgs a;
+    TN_TRY(cin_args(field, training, &a));
+    if (num_rays == 0) return TN_OK;
+    if (!d_cin) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    if (d_geo) {
+        if (ld_d_geo < a.geo_dim) return TN_ERR_SHAPE;
+        hipLaunchKernelGGL(color_input_bwd_geo_kernel, dim3(grid_for(num_rays * n * a.geo_dim, kBlock, 1 << 16)), dim3(kBlock),
+                           0, (hipStream_t)stream, a.geo_dim, d_cin, (long long)(num_rays * n), d_geo, ld_d_geo);
+        TN_LAUNCH_CHECK();
+    }
+    if (d_appearance && training && a.app_dim > 0) {
+        if (!camera_indices) return TN_ERR_NULL;
+        hipLaunchKernelGGL(color_input_bwd_app_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0,
+                           (hipStream_t)stream, a.geo_dim, a.app_dim, d_cin, camera_indices, (long long)num_rays, n,
+                           d_appearance);
+        TN_LAUNCH_CHECK();
+    }
+    return TN_OK;
+}
+
+int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float *loss_sum,
+                       float *d_weights, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!spacing_bins || !weights || !loss_sum || !d_weights) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(distortion_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream,
+                       spacing_bins, weights, (long long)num_rays, n, loss_sum, d_weights);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
+                       int32_t p, float *loss_sum, float *d_wp, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!c || !w || !cp || !wp || !loss_sum || !d_wp) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1 || p < 1 || p > kMaxP) return TN_ERR_SHAPE;
+    const size_t lds = (size_t)(kBlock / 64) * 4 * (p + 2) * sizeof(float);
+    hipLaunchKernelGGL(interlevel_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), lds, (hipStream_t)stream, c, w,
+                       cp, wp, (long long)num_rays, n, p, loss_sum, d_wp);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+}  // extern "C"

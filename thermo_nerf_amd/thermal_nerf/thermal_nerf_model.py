@@ -153,9 +153,49 @@ class ThermalNerfModel(ThermalNerfactoModel):
         fusable = (self.config.fused and self.config.num_proposal_iterations == 2
                    and not self.config.use_same_proposal_network and not self.config.predict_normals
                    and not self.config.use_gradient_scaling)
+        if self.training and torch.is_grad_enabled():
+            from ..training import get_outputs_train  # taped forward: the outputs carry the HIP backward
+            return get_outputs_train(self, ray_bundle)
         if fusable:
             return self._get_outputs_fused(ray_bundle)
         return self._get_outputs_modular(ray_bundle)
+
+    # ------------------------------------------------------------------------------------------------
+    def get_metrics_dict(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """NS NerfactoModel.get_metrics_dict: psnr, and the distortion metric that get_loss_dict scales
+        [REF thermal_nerf_model.py:301-304]."""
+        from ..training import distortion_loss
+
+        gt_rgb = batch["image"].to(self.device)[..., :3]
+        metrics = {"psnr": 10.0 * torch.log10(1.0 / torch.mean((outputs["rgb"].detach() - gt_rgb) ** 2))}
+        if self.training:
+            metrics["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+        return metrics
+
+    def get_loss_dict(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor],
+                      metrics_dict: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+        """[REF thermal_nerf_model.py:277-326]"""
+        from ..training import interlevel_loss
+
+        loss_dict: Dict[str, Tensor] = {}
+        image = batch["image"].to(self.device)
+        pred_rgb, gt_rgb = self.renderer_rgb.blend_background_for_loss_computation(
+            pred_image=outputs["rgb"], pred_accumulation=outputs[RenderedImageModality.ACCUMULATION.value], gt_image=image)
+        if self.field.pass_rgb_gradients:
+            loss_dict["rgb_loss"] = torch.nn.functional.mse_loss(gt_rgb, pred_rgb)  # REF :294-295
+        if self.training:
+            loss_dict["interlevel_loss"] = self.config.interlevel_loss_mult * interlevel_loss(
+                outputs["weights_list"], outputs["ray_samples_list"])  # REF :296-300
+            assert metrics_dict is not None and "distortion" in metrics_dict  # REF :301
+            loss_dict["distortion_loss"] = self.config.distortion_loss_mult * metrics_dict["distortion"]
+            if self.config.predict_normals:
+                raise NotImplementedError("predict_normals is off on the ThermoNeRF path")
+        thermal_batch = batch[RenderedImageModality.THERMAL.value].to(self.device)
+        if self.field.pass_thermal_gradients:
+            # the reference gates the thermal LOSS (not only the geo gradient) on this flag [REF :319-323]
+            loss_dict[RenderedImageModality.THERMAL.value] = torch.nn.functional.mse_loss(
+                outputs[RenderedImageModality.THERMAL.value], thermal_batch)
+        return loss_dict
 
     # --- the reference's call sequence, one HIP entry point per nerfstudio module ----------------------
     def _get_outputs_modular(self, ray_bundle: RayBundle, jitter: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:

@@ -1,0 +1,408 @@
+"""Training step of the hot path on the HIP kernels.
+
+The reference trains through torch autograd over nerfstudio's modules: ``ThermalNerfModel.get_outputs`` in train mode
+[REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:210-275], ``get_loss_dict`` [REF :277-326] and nerfstudio's
+``interlevel_loss`` / ``distortion_loss``.  Here the same graph is ONE ``torch.autograd.Function`` (``RenderTrain``)
+whose forward chains the taped C-ABI stages of ``include/thermonerf_hip.h`` (hash encode -> Linear layers -> density
+-> weights -> compositing, per level) and whose backward chains their adjoints; the two regularisers are Functions
+of their own.  torch is used for what it is here for: the autograd tape between these Functions, the two MSE
+reductions over [R,3]/[R,1] pixels, and the optimizer.
+
+What carries gradient (as in nerfstudio): the final level through rgb / thermal / accumulation and its weights; the
+proposal levels only through their weights (PDFSampler detaches the sample positions), and only on steps where
+ProposalNetworkSampler's update schedule says so.  Not differentiated: median/expected depth.  Camera-pose gradients
+(``camera_optimizer_mode != "off"``) are not implemented and raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _hip
+from .rays import RayBundle
+from .samplers import linspace_bins, pdf_positions, _samples_from_bins
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _f32(shape, dev) -> Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _stream():
+    return _hip.current_stream()
+
+
+# --------------------------------------------------------------------------------------------------
+# thin wrappers: one per C entry point (allocate the output, call, check)
+# --------------------------------------------------------------------------------------------------
+def hash_encode_fwd(grid, space, pos: Tensor) -> Tuple[Tensor, Tensor]:
+    n = pos.shape[0]
+    enc = _f32((n, 2 * grid.num_levels), pos.device)
+    sel = _f32((n,), pos.device)
+    _hip.check(_hip.load().tn_hash_encode_fwd(grid, space, pos.data_ptr(), n, enc.data_ptr(), sel.data_ptr(), _stream()),
+               "tn_hash_encode_fwd")
+    return enc, sel
+
+
+def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor) -> None:
+    _hip.check(_hip.load().tn_hash_encode_bwd(grid, space, pos.data_ptr(), d_enc.data_ptr(), pos.shape[0],
+                                              d_table.data_ptr(), _stream()), "tn_hash_encode_bwd")
+
+
+def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor:
+    y = _f32((n, lin.out_dim), x.device)
+    _hip.check(_hip.load().tn_linear_fwd(x.data_ptr() + 4 * x_off, ldx, lin, act, n, y.data_ptr(), lin.out_dim, _stream()),
+               "tn_linear_fwd")
+    return y
+
+
+def linear_bwd(x: Tensor, x_off: int, ldx: int, y: Optional[Tensor], dy: Tensor, ldy: int, lin, act: int, n: int,
+               dx: Optional[Tensor], dx_off: int, lddx: int, accumulate: bool, d_w: Optional[Tensor],
+               d_b: Optional[Tensor]) -> None:
+    _hip.check(_hip.load().tn_linear_bwd(
+        x.data_ptr() + 4 * x_off, ldx, None if y is None else y.data_ptr(), dy.data_ptr(), ldy, lin, act, n,
+        None if dx is None else dx.data_ptr() + 4 * dx_off, lddx, 1 if accumulate else 0,
+        None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(), _stream()), "tn_linear_bwd")
+
+
+def weights_fwd(deltas: Tensor, density: Tensor) -> Tensor:
+    R, n = deltas.shape
+    w = _f32((R, n), deltas.device)
+    _hip.check(_hip.load().tn_weights_fwd(deltas.data_ptr(), density.data_ptr(), R, n, w.data_ptr(), _stream()),
+               "tn_weights_fwd")
+    return w
+
+
+def weights_bwd(deltas: Tensor, density: Tensor, g_w: Tensor) -> Tensor:
+    R, n = deltas.shape
+    g = _f32((R, n), deltas.device)
+    _hip.check(_hip.load().tn_weights_bwd(deltas.data_ptr(), density.data_ptr(), g_w.data_ptr(), R, n, g.data_ptr(),
+                                          _stream()), "tn_weights_bwd")
+    return g
+
+
+class _LevelTape:
+    """What one sampling level keeps for its backward."""
+
+    __slots__ = ("pos", "enc", "sel", "hid", "raw", "density", "deltas", "weights", "spacing", "eucl")
+
+
+def _frustum_positions(o: Tensor, d: Tensor, eucl: Tensor) -> Tuple[Tensor, Tensor]:
+    R, n1 = eucl.shape
+    n = n1 - 1
+    starts, ends = eucl[:, :-1].contiguous(), eucl[:, 1:].contiguous()
+    pos = _f32((R * n, 3), o.device)
+    _hip.check(_hip.load().tn_frustum_positions(o.data_ptr(), d.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, n,
+                                                pos.data_ptr(), _stream()), "tn_frustum_positions")
+    return pos, ends - starts
+
+
+def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl: Tensor) -> _LevelTape:
+    lib = _hip.load()
+    t = _LevelTape()
+    t.spacing, t.eucl = spacing, eucl
+    t.pos, t.deltas = _frustum_positions(o, d, eucl)
+    n = t.pos.shape[0]
+    t.enc, t.sel = hash_encode_fwd(net_struct.grid, net_struct.space, t.pos)
+    t.hid = linear_fwd(t.enc, 0, t.enc.shape[1], net_struct.l0, ACT_RELU, n)
+    t.raw = linear_fwd(t.hid, 0, t.hid.shape[1], net_struct.l1, ACT_NONE, n)
+    t.density = _f32((n,), o.device)
+    _hip.check(lib.tn_density_act_fwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density, n,
+                                      t.density.data_ptr(), _stream()), "tn_density_act_fwd")
+    t.weights = weights_fwd(t.deltas, t.density.view(t.deltas.shape))
+    return t
+
+
+def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict) -> None:
+    lib = _hip.load()
+    n = t.pos.shape[0]
+    g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
+    g_raw = _f32((n, 1), g_w.device)
+    _hip.check(lib.tn_density_act_bwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density,
+                                      g_density.data_ptr(), n, g_raw.data_ptr(), 1, _stream()), "tn_density_act_bwd")
+    names = [f"{prefix}.mlp_base.encoder.hash_table", f"{prefix}.mlp_base.mlp.layers.0.weight",
+             f"{prefix}.mlp_base.mlp.layers.0.bias", f"{prefix}.mlp_base.mlp.layers.1.weight",
+             f"{prefix}.mlp_base.mlp.layers.1.bias"]
+    for k in names:
+        if k not in grads:
+            grads[k] = torch.zeros_like(like[k])
+    H = t.hid.shape[1]
+    g_hid = _f32((n, H), g_w.device)
+    linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
+    E = t.enc.shape[1]
+    g_enc = _f32((n, E), g_w.device)
+    linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
+    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]])
+
+
+class RenderTrain(torch.autograd.Function):
+    """Train-mode ``get_outputs`` with a tape.  ``apply(model, origins, directions, nears, fars, camera_indices,
+    jitter, updated, *parameters)``; returns (rgb [R,3], thermal [R,1], accumulation [R,1], w0 [R,P0,1], w1 [R,P1,1],
+    w2 [R,S,1], depth, expected_depth, prop_depth_0, prop_depth_1, sp0, sp1, sp2, eu0, eu1, eu2)."""
+
+    @staticmethod
+    def forward(ctx, model, o: Tensor, d: Tensor, nears: Tensor, fars: Tensor, cam: Tensor, jitter: Tensor,
+                updated: bool, *params: Tensor):
+        lib = _hip.load()
+        ctx.set_materialize_grads(False)  # outputs no loss touches arrive as None: their branches are skipped
+        cfg = model.config
+        dev = o.device
+        R = o.shape[0]
+        P = tuple(cfg.num_proposal_samples_per_ray)
+        S = cfg.num_nerf_samples_per_ray
+        prop_structs = [model.proposal_networks[i].c_struct() for i in range(2)]
+        fld = model.field.c_struct(prepare=False)
+        anneal = float(model.proposal_sampler._anneal)
+
+        # ---- proposal levels: sample -> taped density -> weights -------------------------------------------
+        tapes: List[_LevelTape] = []
+        spacing = _f32((R, P[0] + 1), dev)
+        eucl = _f32((R, P[0] + 1), dev)
+        _hip.check(lib.tn_sample_initial(linspace_bins(P[0], dev).data_ptr(), jitter[0].data_ptr(), nears.data_ptr(),
+                                         fars.data_ptr(), R, P[0], spacing.data_ptr(), eucl.data_ptr(), _stream()),
+                   "tn_sample_initial")
+        counts = (P[1], S)
+        for lvl in range(2):
+            t = _proposal_level_fwd(prop_structs[lvl], o, d, spacing, eucl)
+            tapes.append(t)
+            n_out = counts[lvl]
+            w_in = t.weights if anneal == 1.0 else torch.pow(t.weights, anneal)
+            spacing, eucl = _f32((R, n_out + 1), dev), _f32((R, n_out + 1), dev)
+            _hip.check(lib.tn_sample_pdf(w_in.data_ptr(), t.spacing.data_ptr(), pdf_positions(n_out + 1, dev, True).data_ptr(),
+                                         jitter[lvl + 1].data_ptr(), nears.data_ptr(), fars.data_ptr(), R, P[lvl], n_out,
+                                         spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
+
+        # ---- final level: taped field ----------------------------------------------------------------------
+        f = _LevelTape()
+        f.spacing, f.eucl = spacing, eucl
+        f.pos, f.deltas = _frustum_positions(o, d, eucl)
+        N = R * S
+        f.enc, f.sel = hash_encode_fwd(fld.grid, fld.space, f.pos)
+        E = f.enc.shape[1]
+        h1 = linear_fwd(f.enc, 0, E, fld.base0, ACT_RELU, N)
+        bo = linear_fwd(h1, 0, h1.shape[1], fld.base1, ACT_NONE, N)  # [N, 1 + geo]: raw density | geo features
+        G = fld.geo_feat_dim
+        ldb = bo.shape[1]
+        f.density = _f32((N,), dev)
+        _hip.check(lib.tn_density_act_fwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density, N,
+                                          f.density.data_ptr(), _stream()), "tn_density_act_fwd")
+        cin = _f32((N, 64), dev)
+        _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), bo.data_ptr() + 4, ldb, cam.data_ptr(), 1, R, S,
+                                          cin.data_ptr(), _stream()), "tn_color_input_fwd")
+        c1 = linear_fwd(cin, 0, 64, fld.head0, ACT_RELU, N)
+        c2 = linear_fwd(c1, 0, c1.shape[1], fld.head1, ACT_RELU, N)
+        rgb_s = linear_fwd(c2, 0, c2.shape[1], fld.head2, ACT_SIGMOID, N)
+        t1 = linear_fwd(bo, 1, ldb, fld.th0, ACT_RELU, N)
+        t2 = linear_fwd(t1, 0, t1.shape[1], fld.th1, ACT_SIGMOID, N)
+        th_s = linear_fwd(t2, 0, t2.shape[1], fld.thead, ACT_NONE, N)
+        f.weights = weights_fwd(f.deltas, f.density.view(R, S))
+
+        rgb, thermal = _f32((R, 3), dev), _f32((R, 1), dev)
+        _hip.check(lib.tn_composite_fwd(rgb_s.data_ptr(), f.weights.data_ptr(), R, S, 3, 1, rgb.data_ptr(), _stream()),
+                   "tn_composite_fwd")
+        _hip.check(lib.tn_composite_fwd(th_s.data_ptr(), f.weights.data_ptr(), R, S, 1, 1, thermal.data_ptr(), _stream()),
+                   "tn_composite_fwd")
+        acc, depth, expected = _f32((R, 1), dev), _f32((R, 1), dev), _f32((R, 1), dev)
+        scratch = _f32((2,), dev)
+        starts, ends = eucl[:, :-1].contiguous(), eucl[:, 1:].contiguous()
+        _hip.check(lib.tn_depth_fwd(f.weights.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S, acc.data_ptr(),
+                                    depth.data_ptr(), expected.data_ptr(), scratch.data_ptr(), _stream()), "tn_depth_fwd")
+        prop_depths = []
+        for t in tapes:
+            pd = _f32((R, 1), dev)
+            st, en = t.eucl[:, :-1].contiguous(), t.eucl[:, 1:].contiguous()
+            _hip.check(lib.tn_depth_fwd(t.weights.data_ptr(), st.data_ptr(), en.data_ptr(), R, t.weights.shape[1], None,
+                                        pd.data_ptr(), None, None, _stream()), "tn_depth_fwd")
+            prop_depths.append(pd)
+
+        ctx.model, ctx.tapes, ctx.field_tape = model, tapes, f
+        ctx.acts = (h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s)
+        ctx.acc, ctx.o, ctx.d, ctx.cam = acc, o, d, cam
+        ctx.updated = bool(updated)
+        ctx.param_names = [n for n, _ in model.named_parameters()]
+        ctx.params = {n: p for n, p in zip(ctx.param_names, params)}
+        outs = (rgb, thermal, acc, tapes[0].weights[..., None], tapes[1].weights[..., None], f.weights[..., None],
+                depth, expected, prop_depths[0], prop_depths[1], tapes[0].spacing, tapes[1].spacing, f.spacing,
+                tapes[0].eucl, tapes[1].eucl, f.eucl)
+        ctx.mark_non_differentiable(*outs[6:])
+        if not ctx.updated:  # NS evaluates the proposal densities under no_grad on these steps
+            ctx.mark_non_differentiable(outs[3], outs[4])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_th, g_acc, g_w0, g_w1, g_w2, *unused):
+        lib = _hip.load()
+        model, f = ctx.model, ctx.field_tape
+        cfg = model.config
+        dev = ctx.o.device
+        h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s = ctx.acts
+        R, S = f.weights.shape
+        N = R * S
+        fld = model.field.c_struct(prepare=False)
+        like = ctx.params
+        grads: Dict[str, Tensor] = {}
+
+        def zeros(name: str) -> Tensor:
+            grads[name] = torch.zeros_like(like[name])
+            return grads[name]
+
+        # ---- final level ------------------------------------------------------------------------------------
+        g_w = torch.zeros((R, S), dtype=torch.float32, device=dev) if g_w2 is None else g_w2.reshape(R, S).contiguous().clone()
+        if g_acc is not None:
+            g_w += g_acc.reshape(R, 1)
+        g_rgb_s, g_th_s = None, None
+        if g_rgb is not None:
+            g_rgb_s = _f32((N, 3), dev)
+            _hip.check(lib.tn_composite_bwd(rgb_s.data_ptr(), f.weights.data_ptr(), ctx.acc.data_ptr(),
+                                            g_rgb.contiguous().data_ptr(), R, S, 3, g_rgb_s.data_ptr(), g_w.data_ptr(),
+                                            _stream()), "tn_composite_bwd")
+        if g_th is not None:
+            g_th_s = _f32((N, 1), dev)
+            _hip.check(lib.tn_composite_bwd(th_s.data_ptr(), f.weights.data_ptr(), ctx.acc.data_ptr(),
+                                            g_th.contiguous().data_ptr(), R, S, 1, g_th_s.data_ptr(), g_w.data_ptr(),
+                                            _stream()), "tn_composite_bwd")
+        g_density = weights_bwd(f.deltas, f.density.view(R, S), g_w)
+        ldb = bo.shape[1]
+        g_bo = torch.zeros((N, ldb), dtype=torch.float32, device=dev)
+        _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density,
+                                          g_density.data_ptr(), N, g_bo.data_ptr(), ldb, _stream()), "tn_density_act_bwd")
+        W = 64
+        if g_th_s is not None:  # thermal branch [REF thermal_field.py:170-179]
+            g_t2, g_t1 = _f32((N, W), dev), _f32((N, W), dev)
+            linear_bwd(t2, 0, W, None, g_th_s, 1, fld.thead, ACT_NONE, N, g_t2, 0, W, False,
+                       zeros("field.field_head_thermal.net.weight"), zeros("field.field_head_thermal.net.bias"))
+            linear_bwd(t1, 0, W, t2, g_t2, W, fld.th1, ACT_SIGMOID, N, g_t1, 0, W, False,
+                       zeros("field.mlp_thermal.layers.1.weight"), zeros("field.mlp_thermal.layers.1.bias"))
+            into_geo = g_bo if model.field.pass_thermal_gradients else None  # REF :171-172 (.detach())
+            linear_bwd(bo, 1, ldb, t1, g_t1, W, fld.th0, ACT_RELU, N, into_geo, 1, ldb, True,
+                       zeros("field.mlp_thermal.layers.0.weight"), zeros("field.mlp_thermal.layers.0.bias"))
+        if g_rgb_s is not None:  # colour branch [REF :160-168]
+            g_c2, g_c1 = _f32((N, W), dev), _f32((N, W), dev)
+            g_cin = _f32((N, 64), dev)
+            linear_bwd(c2, 0, W, rgb_s, g_rgb_s, 3, fld.head2, ACT_SIGMOID, N, g_c2, 0, W, False,
+                       zeros("field.mlp_head.layers.2.weight"), zeros("field.mlp_head.layers.2.bias"))
+            linear_bwd(c1, 0, W, c2, g_c2, W, fld.head1, ACT_RELU, N, g_c1, 0, W, False,
+                       zeros("field.mlp_head.layers.1.weight"), zeros("field.mlp_head.layers.1.bias"))
+            linear_bwd(cin, 0, 64, c1, g_c1, W, fld.head0, ACT_RELU, N, g_cin, 0, 64, False,
+                       zeros("field.mlp_head.layers.0.weight"), zeros("field.mlp_head.layers.0.bias"))
+            _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, S, g_bo.data_ptr() + 4, ldb,
+                                              zeros("field.embedding_appearance.embedding.weight").data_ptr(), _stream()),
+                       "tn_color_input_bwd")
+        g_h1 = _f32((N, W), dev)
+        linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False,
+                   zeros("field.mlp_base.mlp.layers.1.weight"), zeros("field.mlp_base.mlp.layers.1.bias"))
+        E = f.enc.shape[1]
+        g_enc = _f32((N, E), dev)
+        linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False,
+                   zeros("field.mlp_base.mlp.layers.0.weight"), zeros("field.mlp_base.mlp.layers.0.bias"))
+        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"))
+
+        # ---- proposal levels (only through their weights) --------------------------------------------------
+        if ctx.updated:
+            for lvl, g in enumerate((g_w0, g_w1)):
+                if g is None:
+                    continue
+                t = ctx.tapes[lvl]
+                net = model.proposal_networks[lvl].c_struct()
+                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{lvl}", like)
+
+        return (None,) * 8 + tuple(grads.get(n) for n in ctx.param_names)
+
+
+# --------------------------------------------------------------------------------------------------
+# regularisers
+# --------------------------------------------------------------------------------------------------
+class _Distortion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights: Tensor, spacing_bins: Tensor):
+        R, n = weights.shape[0], weights.shape[1]
+        w = _hip.require_device_tensor(weights.reshape(R, n), "weights")
+        b = _hip.require_device_tensor(spacing_bins, "spacing_bins")
+        loss = torch.zeros((1,), dtype=torch.float32, device=w.device)
+        g = _f32((R, n), w.device)
+        _hip.check(_hip.load().tn_distortion_loss(b.data_ptr(), w.data_ptr(), R, n, loss.data_ptr(), g.data_ptr(), _stream()),
+                   "tn_distortion_loss")
+        ctx.g, ctx.shape = g / R, weights.shape
+        return loss[0] / R
+
+    @staticmethod
+    def backward(ctx, go):
+        return (go * ctx.g).view(ctx.shape), None
+
+
+class _Interlevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wp: Tensor, cp: Tensor, w: Tensor, c: Tensor):
+        R, p = wp.shape[0], wp.shape[1]
+        n = w.shape[1]
+        wp2 = _hip.require_device_tensor(wp.reshape(R, p), "proposal weights")
+        w2 = _hip.require_device_tensor(w.reshape(R, n), "weights")
+        cp2, c2 = _hip.require_device_tensor(cp, "proposal bins"), _hip.require_device_tensor(c, "bins")
+        loss = torch.zeros((1,), dtype=torch.float32, device=wp2.device)
+        g = _f32((R, p), wp2.device)
+        _hip.check(_hip.load().tn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), cp2.data_ptr(), wp2.data_ptr(), R, n, p,
+                                                  loss.data_ptr(), g.data_ptr(), _stream()), "tn_interlevel_loss")
+        ctx.g, ctx.shape = g / (R * n), wp.shape
+        return loss[0] / (R * n)
+
+    @staticmethod
+    def backward(ctx, go):
+        return (go * ctx.g).view(ctx.shape), None, None, None
+
+
+def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) -> Tensor:
+    """NS losses.distortion_loss (final level), O(S) per ray on the device."""
+    return _Distortion.apply(weights_list[-1], ray_samples_list[-1].spacing_bins)
+
+
+def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) -> Tensor:
+    """NS losses.interlevel_loss: final level detached, one term per proposal level."""
+    c = ray_samples_list[-1].spacing_bins.detach()
+    w = weights_list[-1].detach()
+    loss = None
+    for s, wp in zip(ray_samples_list[:-1], weights_list[:-1]):
+        term = _Interlevel.apply(wp, s.spacing_bins, w, c)
+        loss = term if loss is None else loss + term
+    return loss
+
+
+# --------------------------------------------------------------------------------------------------
+# model-facing entry
+# --------------------------------------------------------------------------------------------------
+def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """Train-mode ``get_outputs`` with gradients [REF thermal_nerf_model.py:210-275]."""
+    cfg = model.config
+    if cfg.camera_optimizer.mode != "off":
+        raise NotImplementedError("gradients w.r.t. camera poses are not implemented: train with "
+                                  'camera_optimizer_mode="off" (the forward pass supports SO3xR3)')
+    if (cfg.num_proposal_iterations != 2 or cfg.use_same_proposal_network or cfg.predict_normals
+            or cfg.use_gradient_scaling or not cfg.use_single_jitter):
+        raise NotImplementedError("the training path implements the reference configuration: two proposal networks, "
+                                  "single jitter, no predicted normals, no gradient scaling")
+    o = _hip.require_device_tensor(ray_bundle.origins, "origins")
+    d = _hip.require_device_tensor(ray_bundle.directions, "directions")
+    R, dev = o.shape[0], o.device
+    nears = _hip.require_device_tensor(ray_bundle.nears.reshape(-1), "nears")
+    fars = _hip.require_device_tensor(ray_bundle.fars.reshape(-1), "fars")
+    if ray_bundle.camera_indices is None:
+        raise AttributeError("Camera indices are not provided.")
+    cam = _hip.require_device_tensor(ray_bundle.camera_indices.reshape(-1).to(torch.int32), "camera_indices", torch.int32)
+    if jitter is None:
+        jitter = torch.rand((3, R), dtype=torch.float32, device=dev)
+    jitter = _hip.require_device_tensor(jitter, "jitter")
+    sampler = model.proposal_sampler
+    updated = sampler._steps_since_update > sampler.update_sched(sampler._step) or sampler._step < 10
+    params = [p for _, p in model.named_parameters()]
+    (rgb, thermal, acc, w0, w1, w2, depth, expected, pd0, pd1, sp0, sp1, sp2, eu0, eu1, eu2) = RenderTrain.apply(
+        model, o, d, nears, fars, cam, jitter, updated, *params)
+    if updated:
+        sampler._steps_since_update = 0
+    return {
+        "rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": expected,
+        "weights_list": [w0, w1, w2],
+        "ray_samples_list": [_samples_from_bins(ray_bundle, sp, eu) for sp, eu in ((sp0, eu0), (sp1, eu1), (sp2, eu2))],
+        "prop_depth_0": pd0, "prop_depth_1": pd1, "thermal": thermal,
+    }

@@ -83,7 +83,7 @@ def main():
     for name in sys.argv[1:]:
         tmp = f"/tmp/abl_{name}.hip"
         open(tmp, "w").write(variant(name, src))
-        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_h3.hip", "tn_prepare.hip")]
+        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip")]
         out = os.path.join(ROOT, f"ab_{name}.so")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)
         print("built", out)
