@@ -1,0 +1,63 @@
+"""Time the training step (taped forward + losses + backward + Adam) on the GPU.
+usage: python tools/train_bench.py [--rays 4096] [--samples 48] [--steps 20] [--small]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic  # noqa: E402
+from thermo_nerf_amd.rays import RayBundle  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--weights", default="scene")
+    ap.add_argument("--no-opt", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode="off")
+    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+    synthetic.fill_model_(model, a.weights)
+    model.to(dev).train()
+    groups = model.get_param_groups()
+    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}], lr=1e-2, eps=1e-15)
+    g = torch.Generator().manual_seed(0)
+    side = int(a.rays ** 0.5)
+    o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
+    o, d = o.reshape(-1, 3)[: a.rays].contiguous().to(dev), d.reshape(-1, 3)[: a.rays].contiguous().to(dev)
+    R = o.shape[0]
+    cam = torch.randint(0, 8, (R, 1), generator=g).to(dev)
+    batch = {"image": torch.rand(R, 3, generator=g).to(dev), "thermal": torch.rand(R, 1, generator=g).to(dev)}
+
+    def step(i):
+        model.set_step(i)
+        rb = RayBundle(origins=o, directions=d, camera_indices=cam)
+        out = model(rb)
+        metrics = model.get_metrics_dict(out, batch)
+        loss = sum(model.get_loss_dict(out, batch, metrics).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if not a.no_opt:
+            opt.step()
+        return loss
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / a.steps
+    print(f"rays {R} S {a.samples}: {dt * 1e3:.3f} ms/step, {R / dt / 1e6:.3f} M rays/s, loss {loss.item():.5f}")
+
+
+if __name__ == "__main__":
+    main()
