@@ -97,6 +97,71 @@ def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int):
                       f"CPU oracle, {cores} of {avail} host threads (fastest of the probed pool sizes)"}, idx, out
 
 
+def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, warmup: int = 6, start_step: int = 5000,
+                       cpu: bool = True):
+    """Secondary measurement (BASELINE configs 3/5): one optimisation step = train-mode forward with a
+    tape + get_metrics_dict/get_loss_dict + backward + Adam(lr 1e-2, eps 1e-15) [REF config_thermal_nerf.py:32-45] on
+    `rays` random-target rays, full-size tables, starting at `start_step` (>= proposal_warmup: the proposal networks take
+    gradient every 6th step, as in nerfstudio's schedule)."""
+    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd.rays import RayBundle
+
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=samples, camera_optimizer_mode="off")
+    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+    synthetic.fill_model_(model, "scene")
+    sd_cpu = synthetic.model_state_dict_cpu(model) if cpu else None
+    model.to(dev).train()
+    groups = model.get_param_groups()
+    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}], lr=1e-2, eps=1e-15)
+    g = torch.Generator().manual_seed(0)
+    side = int(rays ** 0.5)
+    o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
+    o_cpu, d_cpu = o.reshape(-1, 3)[:rays].contiguous(), d.reshape(-1, 3)[:rays].contiguous()
+    R = o_cpu.shape[0]
+    cam_cpu = torch.randint(0, 8, (R, 1), generator=g)
+    batch_cpu = {"image": torch.rand(R, 3, generator=g), "thermal": torch.rand(R, 1, generator=g)}
+    o, d, cam = o_cpu.to(dev), d_cpu.to(dev), cam_cpu.to(dev)
+    batch = {k: v.to(dev) for k, v in batch_cpu.items()}
+
+    def step(i):
+        model.set_step(i)
+        out = model(RayBundle(origins=o, directions=d, camera_indices=cam))
+        loss = sum(model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch)).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    for i in range(warmup):
+        step(start_step + i)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(steps):
+        step(start_step + warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    res = {"what": "train step: taped forward + losses + backward + Adam, %d rays/step, P=(256,96)+%d samples/ray, "
+                   "steps %d.. (proposal nets updated every 6th step), camera optimizer off" % (R, samples, start_step),
+           "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps}
+    if cpu:
+        from oracle import training as T
+        from tests import helpers
+
+        n = 256
+        jit = [torch.rand(n, 1, generator=g) for _ in range(3)]
+        b = {k: v[:n] for k, v in batch_cpu.items()}
+        ocfg = helpers.oracle_config(cfg)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        T.loss_and_grads(sd_cpu, o_cpu[:64], d_cpu[:64], cam_cpu[:64], {k: v[:64] for k, v in b.items()}, ocfg,
+                         [j[:64] for j in jit])
+        t = time.perf_counter()
+        T.loss_and_grads(sd_cpu, o_cpu[:n], d_cpu[:n], cam_cpu[:n], b, ocfg, jit)
+        ct = time.perf_counter() - t
+        res["cpu_baseline"] = {"value": n / ct, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "1 x %d rays forward+backward (torch autograd over the CPU oracle), no optimizer "
+                                         "step" % n}
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,6 +285,9 @@ def main():
                     "value": v, "unit": "rays/s", "rgb_mae": float((g_rgb - want["rgb"]).abs().mean()),
                     "thermal_mae": float((g_th - want["thermal"]).abs().mean())}}
                 model.config.mlp_precision = "f32"
+                del engine, out
+                torch.cuda.empty_cache()
+                line["variants"]["train_step"] = measure_train_step(dev, 48)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command (FETCH_SIZE +

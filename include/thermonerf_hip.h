@@ -281,10 +281,12 @@ int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act
                   void *stream);
 /* backward: g = dy * act'(y) (y = the forward OUTPUT, rows ldy apart like dy);  dx[n,:in] (= or += when
  * accumulate_dx) = g W;  d_weight [out,in] (+=) = g^T x;  d_bias [out] (+=) = sum_n g.  dx / d_weight / d_bias
- * may be NULL. */
+ * may be NULL.  `workspace` (tn_linear_bwd_workspace_bytes(), reusable across calls on one stream) holds per-block
+ * partial weight gradients summed by a second kernel; NULL falls back to one atomic per block and weight entry. */
+size_t tn_linear_bwd_workspace_bytes(void);
 int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, int32_t ldy, const tn_linear *lin,
                   int32_t act, int64_t n, float *dx, int32_t lddx, int32_t accumulate_dx, float *d_weight,
-                  float *d_bias, void *stream);
+                  float *d_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* density = average_init_density * trunc_exp(raw) * selector (NS get_density); raw rows ld_raw floats apart.
  * backward: d_raw = d_density * average_init_density * exp(min(raw, 15)) * selector (NS trunc_exp.backward). */

@@ -172,7 +172,9 @@ SIGNATURES = {
     "tn_hash_encode_fwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _i64, _vp, _vp, _vp]),
     "tn_hash_encode_bwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),
     "tn_linear_fwd": (C.c_int, [_vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _vp]),
-    "tn_linear_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "tn_linear_bwd_workspace_bytes": (_sz, []),
+    "tn_linear_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
+                                _sz, _vp]),
     "tn_density_act_fwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _i64, _vp, _vp]),
     "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _vp, _i64, _vp, _i32, _vp]),
     "tn_weights_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),

@@ -152,6 +152,7 @@ __device__ __forceinline__ float act_bwd(float y, int act) {  // derivative expr
 }
 
 constexpr int TILE = 64;
+constexpr int kLinBwdBlocks = 768;  // persistent blocks of tn_linear_bwd (3 per CU fit the 49 KB of LDS each)
 constexpr int LDP = 65;  // padded row length of the row tiles in LDS (odd: conflict-free column walks)
 
 // NO = outputs per thread (OUT <= 4 * NO)
@@ -202,7 +203,7 @@ template <int NI>
 __global__ void __launch_bounds__(kBlock)
 linear_bwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ y, const float *__restrict__ dy, int ldy,
                   const float *__restrict__ W, int IN, int OUT, int act, long long n, float *__restrict__ dx, int lddx,
-                  int accumulate_dx, float *__restrict__ dW, float *__restrict__ db) {
+                  int accumulate_dx, float *__restrict__ dW, float *__restrict__ db, float *__restrict__ partials) {
     constexpr int INP = 4 * NI;
     __shared__ __attribute__((aligned(16))) float Ws[64 * INP];  // [o][i], zero padded
     __shared__ float gs[TILE * LDP];                               // g = dy * act'(y)   [row][o]
@@ -269,14 +270,52 @@ linear_bwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict_
         }
     }
     if (want_w && lane < OUT) {
-        if (dW) {
+        if (partials) {  // [block][i (INP rows) | bias row][64]: plain coalesced stores, summed by linear_bwd_reduce_kernel
+            float *pb = partials + (size_t)blockIdx.x * (INP + 1) * 64;
 #pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int i = grp * NI + k;
-                if (i < IN) atomic_add_f32(dW + lane * IN + i, accw[k]);
+            for (int k = 0; k < NI; ++k) pb[(grp * NI + k) * 64 + lane] = accw[k];
+            if (grp == 0) pb[INP * 64 + lane] = accb;
+        } else {
+            if (dW) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int i = grp * NI + k;
+                    if (i < IN) atomic_add_f32(dW + lane * IN + i, accw[k]);
+                }
             }
+            if (db && grp == 0) atomic_add_f32(db + lane, accb);
         }
-        if (db && grp == 0) atomic_add_f32(db + lane, accb);
+    }
+}
+
+// dW[o][i] += sum_b partials[b][i][o];  db[o] += sum_b partials[b][INP][o].  grid (INP + 1 rows, kRedSplit slices of
+// the block range); 256 threads = 64 outputs x 4 interleaved block streams; one atomic per (entry, slice).
+constexpr int kRedSplit = 8;
+__global__ void __launch_bounds__(kBlock)
+linear_bwd_reduce_kernel(const float *__restrict__ partials, int blocks, int INP, int IN, int OUT, float *__restrict__ dW,
+                         float *__restrict__ db) {
+    __shared__ float red[kBlock];
+    const int i = blockIdx.x, o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int per = (blocks + kRedSplit - 1) / kRedSplit;
+    const int b0 = blockIdx.y * per, b1 = min(blocks, b0 + per);
+    const float *p = partials + (size_t)i * 64 + o;
+    const size_t st = (size_t)(INP + 1) * 64;
+    float s0 = 0.0f, s1 = 0.0f;
+    int b = b0 + q;
+    for (; b + 4 < b1; b += 8) {
+        s0 += p[(size_t)b * st];
+        s1 += p[(size_t)(b + 4) * st];
+    }
+    if (b < b1) s0 += p[(size_t)b * st];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && o < OUT) {
+        const float tot = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
+        if (i == INP) {
+            if (db) atomic_add_f32(db + o, tot);
+        } else if (i < IN && dW) {
+            atomic_add_f32(dW + o * IN + i, tot);
+        }
     }
 }
 
@@ -614,9 +653,11 @@ int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act
     return TN_OK;
 }
 
+size_t tn_linear_bwd_workspace_bytes(void) { return (size_t)kLinBwdBlocks * 65 * 64 * sizeof(float); }
+
 int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, int32_t ldy, const tn_linear *lin,
                   int32_t act, int64_t n, float *dx, int32_t lddx, int32_t accumulate_dx, float *d_weight,
-                  float *d_bias, void *stream) {
+                  float *d_bias, void *workspace, size_t workspace_bytes, void *stream) {
     if (!lin || !lin->weight) return TN_ERR_NULL;
     const int IN = lin->in_dim, OUT = lin->out_dim;
     if (IN < 1 || IN > 64 || OUT < 1 || OUT > 64 || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
@@ -624,19 +665,31 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
     if (act < TN_ACT_NONE || act > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
     if (n == 0) return TN_OK;
     if (!dy || (act != TN_ACT_NONE && !y) || ((d_weight || d_bias) && !x)) return TN_ERR_NULL;
-    // few persistent blocks: each ends with one atomic per weight entry
-    const dim3 g(grid_for((n + TILE - 1) / TILE, 1, 512)), b(kBlock);
+    // persistent blocks; their partial weight gradients go to the workspace and are summed by a second kernel
+    // (without a workspace: one memory-side atomic per block and weight entry)
+    const int blocks = grid_for((n + TILE - 1) / TILE, 1, kLinBwdBlocks);
+    const dim3 g(blocks), b(kBlock);
     hipStream_t st = (hipStream_t)stream;
+    const int INP = IN <= 16 ? 16 : IN <= 32 ? 32 : 64;
+    const bool want_w = d_weight || d_bias;
+    float *partials = nullptr;
+    if (want_w && workspace && workspace_bytes >= (size_t)blocks * (INP + 1) * 64 * sizeof(float))
+        partials = reinterpret_cast<float *>(workspace);
     if (IN <= 16)
         hipLaunchKernelGGL(linear_bwd_kernel<4>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
-                           lddx, accumulate_dx, d_weight, d_bias);
+                           lddx, accumulate_dx, d_weight, d_bias, partials);
     else if (IN <= 32)
         hipLaunchKernelGGL(linear_bwd_kernel<8>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
-                           lddx, accumulate_dx, d_weight, d_bias);
+                           lddx, accumulate_dx, d_weight, d_bias, partials);
     else
         hipLaunchKernelGGL(linear_bwd_kernel<16>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
-                           lddx, accumulate_dx, d_weight, d_bias);
+                           lddx, accumulate_dx, d_weight, d_bias, partials);
     TN_LAUNCH_CHECK();
+    if (partials) {
+        hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(INP + 1, kRedSplit), dim3(kBlock), 0, st, partials, blocks, INP, IN, OUT, d_weight,
+                           d_bias);
+        TN_LAUNCH_CHECK();
+    }
     return TN_OK;
 }
 

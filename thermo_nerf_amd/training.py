@@ -59,13 +59,27 @@ def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor
     return y
 
 
+_LIN_WS: Dict = {}
+
+
+def _linear_workspace(dev) -> Tensor:
+    """per-device scratch for tn_linear_bwd's partial weight gradients (calls on one stream are ordered, so one buffer)"""
+    ws = _LIN_WS.get(dev)
+    if ws is None:
+        ws = torch.empty(_hip.load().tn_linear_bwd_workspace_bytes(), dtype=torch.uint8, device=dev)
+        _LIN_WS[dev] = ws
+    return ws
+
+
 def linear_bwd(x: Tensor, x_off: int, ldx: int, y: Optional[Tensor], dy: Tensor, ldy: int, lin, act: int, n: int,
                dx: Optional[Tensor], dx_off: int, lddx: int, accumulate: bool, d_w: Optional[Tensor],
                d_b: Optional[Tensor]) -> None:
+    ws = _linear_workspace(dy.device)
     _hip.check(_hip.load().tn_linear_bwd(
         x.data_ptr() + 4 * x_off, ldx, None if y is None else y.data_ptr(), dy.data_ptr(), ldy, lin, act, n,
         None if dx is None else dx.data_ptr() + 4 * dx_off, lddx, 1 if accumulate else 0,
-        None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(), _stream()), "tn_linear_bwd")
+        None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(), ws.data_ptr(), ws.numel(),
+        _stream()), "tn_linear_bwd")
 
 
 def weights_fwd(deltas: Tensor, density: Tensor) -> Tensor:

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--weights", default="scene")
     ap.add_argument("--no-opt", action="store_true")
+    ap.add_argument("--start-step", type=int, default=5000,
+                    help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode="off")
@@ -49,11 +51,11 @@ def main():
         return loss
 
     for i in range(a.warmup):
-        step(i)
+        step(a.start_step + i)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(a.steps):
-        loss = step(a.warmup + i)
+        loss = step(a.start_step + a.warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / a.steps
     print(f"rays {R} S {a.samples}: {dt * 1e3:.3f} ms/step, {R / dt / 1e6:.3f} M rays/s, loss {loss.item():.5f}")
