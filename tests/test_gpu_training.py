@@ -297,3 +297,70 @@ def test_camera_pose_gradients_are_refused():
                                camera_indices=torch.zeros(o.shape[0], 1, dtype=torch.long, device=DEV)))
     with pytest.raises(NotImplementedError, match="camera"):
         gm.get_outputs(rb)
+
+
+# --------------------------------------------------------------------------------------------------
+# the loop: fit a closed-form RGB + thermal scene, check HELD-OUT views; checkpoint round trip
+# --------------------------------------------------------------------------------------------------
+def test_trainer_fits_analytic_scene_and_resumes(tmp_path):
+    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd.cameras import psnr
+    from thermo_nerf_amd.trainer import RayDataset, Trainer, TrainerConfig, render_view
+
+    res, n_views = 64, 72
+    views = list(range(n_views))
+    train_cams = synthetic.orbit_cameras(res, res, views, num_views=n_views,
+                                         elevation_deg=[(-10.0, 20.0, 50.0)[v % 3] for v in views])
+    test_cams = synthetic.orbit_cameras(res, res, [0.5, n_views / 2 + 0.5], num_views=n_views, elevation_deg=[5.0, 35.0])
+
+    def truth(cams, i):
+        rb = cams.generate_rays(i, device=DEV)
+        return synthetic.analytic_scene(rb.origins, rb.directions)
+
+    imgs, ths = zip(*[truth(train_cams, i) for i in range(n_views)])
+    held_out = [truth(test_cams, i) for i in range(2)]
+    ds = RayDataset.from_images(train_cams, imgs, ths, DEV)
+    assert len(ds) == n_views * res * res
+
+    def fresh():
+        cfg = ThermalNerfModelConfig(camera_optimizer_mode="off", eval_num_rays_per_chunk=1 << 16, **helpers.SMALL)
+        m = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=n_views)
+        synthetic.fill_model_(m, "init")
+        return m.to(DEV)
+
+    def evaluate(m):
+        ps, ma = [], []
+        for i in range(2):
+            o = render_view(m, test_cams, i, DEV)
+            ps.append(psnr(o["rgb"], held_out[i][0]).item())
+            ma.append((o["thermal"] - held_out[i][1]).abs().mean().item())
+        return sum(ps) / 2, sum(ma) / 2
+
+    model = fresh()
+    tr = Trainer(model, ds, TrainerConfig(train_num_rays_per_batch=4096, steps_per_save=125))
+    p0, m0 = evaluate(model)
+    tr.train(250, checkpoint_dir=tmp_path)
+    p1, m1 = evaluate(model)
+    # measured on MI355X at 64x64: 12.5 dB / 0.26 before, ~20 dB / ~0.03 after 200-300 steps (the early PSNR wobbles by
+    # a few dB from step to step: per-camera appearance codes are swapped for their mean at eval)
+    print(f"held-out psnr {p0:.2f} -> {p1:.2f} dB, thermal mae {m0:.4f} -> {m1:.4f}")
+    assert p1 >= p0 + 2.0, (p0, p1)
+    assert m1 <= 0.12 and m1 <= 0.5 * m0, (m0, m1)
+    assert sorted(p.name for p in tmp_path.glob("*.ckpt")) == ["step-000000125.ckpt", "step-000000250.ckpt"]
+
+    # resume into a fresh model/trainer: same step, same weights, same optimizer moments, same learning rate
+    other = fresh()
+    tr2 = Trainer(other, ds, TrainerConfig(train_num_rays_per_batch=4096))
+    assert tr2.load_checkpoint(tmp_path) == 250
+    for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
+    s1 = tr.optimizers["fields"].state_dict()["state"]
+    s2 = tr2.optimizers["fields"].state_dict()["state"]
+    assert s1.keys() == s2.keys()
+    for k in s1:
+        assert torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"].to(s1[k]["exp_avg"].device))
+    assert abs(tr.optimizers["fields"].param_groups[0]["lr"] - tr2.optimizers["fields"].param_groups[0]["lr"]) < 1e-12
+    # the proposal-weight anneal is callback state (set from the step by set_step), not checkpoint content
+    other.proposal_sampler.set_anneal(model.proposal_sampler._anneal)
+    p2, m2 = evaluate(other)
+    assert abs(p2 - p1) < 1e-3 and abs(m2 - m1) < 1e-5

@@ -73,10 +73,9 @@ def fill_model_(model: torch.nn.Module, kind: str = "init", seed: int = SEED) ->
     return model
 
 
-def orbit_camera_rays(height: int, width: int, view: int = 0, num_views: int = 8, radius: float = 0.8,
-                      fov_deg: float = 50.0, elevation_deg: float = 20.0) -> Tuple[Tensor, Tensor, Tensor]:
-    """Pinhole camera on an orbit looking at the origin (nerfstudio/OpenGL convention: -z forward, +y up,
-    pixel centres at +0.5).  Returns origins [H,W,3], unit directions [H,W,3], pixel_area [H,W,1] on the host."""
+def orbit_pose(view: int, num_views: int = 8, radius: float = 0.8, elevation_deg: float = 20.0) -> Tuple[Tensor, Tensor]:
+    """(rotation [3,3] with columns x, y, z(back); eye [3]) of a camera on an orbit looking at the origin
+    (nerfstudio/OpenGL convention: -z forward, +y up)."""
     az = 2.0 * math.pi * view / num_views
     el = math.radians(elevation_deg)
     eye = torch.tensor([radius * math.cos(el) * math.cos(az), radius * math.cos(el) * math.sin(az), radius * math.sin(el)])
@@ -85,7 +84,31 @@ def orbit_camera_rays(height: int, width: int, view: int = 0, num_views: int = 8
     right = torch.linalg.cross(fwd, up)
     right = right / right.norm()
     true_up = torch.linalg.cross(right, fwd)
-    c2w = torch.stack([right, true_up, -fwd], dim=1)  # columns: x, y, z(back)
+    return torch.stack([right, true_up, -fwd], dim=1), eye
+
+
+def orbit_cameras(height: int, width: int, views, num_views: int = 8, radius: float = 0.8, fov_deg: float = 50.0,
+                  elevation_deg=20.0):
+    """The same orbit as ``orbit_camera_rays`` as a ``Cameras`` object: one camera per entry of ``views`` (azimuth index,
+    may be fractional); ``elevation_deg`` is a number or one value per view."""
+    from .cameras import Cameras
+
+    c2w = []
+    for k, v in enumerate(views):
+        el = elevation_deg[k] if isinstance(elevation_deg, (list, tuple)) else elevation_deg
+        rot, eye = orbit_pose(v, num_views, radius, el)
+        c2w.append(torch.cat([rot, eye[:, None]], dim=1))
+    f = 0.5 * width / math.tan(0.5 * math.radians(fov_deg))
+    n = len(c2w)
+    return Cameras(camera_to_worlds=torch.stack(c2w).float(), fx=torch.full((n,), f), fy=torch.full((n,), f),
+                   cx=width / 2.0, cy=height / 2.0, height=height, width=width)
+
+
+def orbit_camera_rays(height: int, width: int, view: int = 0, num_views: int = 8, radius: float = 0.8,
+                      fov_deg: float = 50.0, elevation_deg: float = 20.0) -> Tuple[Tensor, Tensor, Tensor]:
+    """Pinhole camera on an orbit looking at the origin (nerfstudio/OpenGL convention: -z forward, +y up,
+    pixel centres at +0.5).  Returns origins [H,W,3], unit directions [H,W,3], pixel_area [H,W,1] on the host."""
+    c2w, eye = orbit_pose(view, num_views, radius, elevation_deg)
     fx = fy = 0.5 * width / math.tan(0.5 * math.radians(fov_deg))
     cx, cy = width / 2.0, height / 2.0
     ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float32) + 0.5,
@@ -102,3 +125,26 @@ def orbit_camera_rays(height: int, width: int, view: int = 0, num_views: int = 8
 def model_state_dict_cpu(model: torch.nn.Module) -> Dict[str, Tensor]:
     """CPU fp32 copy of the state dict (nerfstudio key names) — what the oracle consumes in tests/bench."""
     return {k: v.detach().to("cpu").clone() for k, v in model.state_dict().items()}
+
+
+def analytic_scene(origins: Tensor, directions: Tensor) -> Tuple[Tensor, Tensor]:
+    """Ground truth of a closed-form RGB + thermal scene for training tests / demos (no dataset on this box):
+    a textured sphere (radius 0.3, warm top / cold bottom) in front of a direction-dependent backdrop.
+    origins / unit directions [...,3] -> (rgb [...,3], thermal [...,1]) in [0,1]."""
+    o, d = origins, directions
+    b = (o * d).sum(-1)
+    c = (o * o).sum(-1) - 0.3 * 0.3
+    disc = b * b - c
+    hit = (disc > 0) & (-b - torch.sqrt(disc.clamp_min(0)) > 0)
+    t = (-b - torch.sqrt(disc.clamp_min(0)))
+    p = o + d * t[..., None]
+    n = p / 0.3
+    shade = 0.35 + 0.65 * (n * torch.tensor([0.3, 0.5, 0.8]).to(n)).sum(-1).clamp(0, 1)
+    stripes = 0.5 + 0.5 * torch.sin(18.0 * p[..., 2:3] + 6.0 * torch.atan2(p[..., 1:2], p[..., 0:1]))
+    albedo = torch.cat([0.9 - 0.5 * stripes, 0.3 + 0.5 * stripes, 0.25 + 0.2 * n[..., 0:1].abs()], dim=-1)
+    rgb_s = (albedo * shade[..., None]).clamp(0, 1)
+    th_s = (0.55 + 0.4 * n[..., 2:3]).clamp(0, 1)
+    rgb_b = torch.stack([0.25 + 0.2 * d[..., 2], 0.3 + 0.15 * d[..., 0], 0.45 + 0.25 * d[..., 1]], dim=-1).clamp(0, 1)
+    th_b = torch.full_like(th_s, 0.15)
+    h = hit[..., None]
+    return torch.where(h, rgb_s, rgb_b), torch.where(h, th_s, th_b)

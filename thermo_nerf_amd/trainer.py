@@ -1,0 +1,187 @@
+"""Training loop around the HIP training step — the slice of nerfstudio's ``Trainer`` / ``VanillaPipeline`` /
+``VanillaDataManager`` the reference's ``thermal-nerf`` method config drives [REF thermo_nerf/thermal_nerf/
+config_thermal_nerf.py:17-50]: per-group Adam + ExponentialDecay schedules, the two model callbacks per step
+(proposal anneal + sampler step), ``loss = sum(get_loss_dict(...))``, checkpoints in nerfstudio's layout.
+
+MI355X layout: the whole training set lives in HBM as a flat ray table (origins, directions, camera index, RGB,
+thermal — 52 B/ray; 100 images of 640x480 are 1.6 GB of 288 GB), generated on the device by ``tn_generate_rays``.  A
+batch is a random gather of ``train_num_rays_per_batch`` rows (nerfstudio's PixelSampler draws uniform random pixels
+across all images); nothing crosses PCIe during training.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from .cameras import Cameras
+from .rays import RayBundle
+
+
+@dataclass
+class OptimizerConfig:
+    """AdamOptimizerConfig + ExponentialDecaySchedulerConfig of one parameter group."""
+
+    lr: float = 1e-2
+    eps: float = 1e-15
+    weight_decay: float = 0.0
+    lr_final: Optional[float] = 1e-4
+    max_steps: int = 200000
+    warmup_steps: int = 0
+    lr_pre_warmup: float = 1e-8
+
+
+def default_optimizers() -> Dict[str, OptimizerConfig]:
+    """[REF config_thermal_nerf.py:31-44]; the thermal-nerf method config names no ``camera_opt`` optimizer (nerfstudio
+    then falls back to CameraOptimizerConfig's own); the values here are the ones the reference spells out for its
+    nerfacto track [REF nerfacto_config/config_nerfacto.py:28-34]."""
+    return {
+        "proposal_networks": OptimizerConfig(lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000),
+        "fields": OptimizerConfig(lr=1e-2, eps=1e-15, lr_final=1e-4, max_steps=200000),
+        "camera_opt": OptimizerConfig(lr=6e-4, eps=1e-8, weight_decay=1e-2, lr_final=6e-6, max_steps=200000),
+    }
+
+
+def exponential_decay_multiplier(cfg: OptimizerConfig, step: int) -> float:
+    """NS ExponentialDecayScheduler.get_scheduler.func (ramp "cosine"): the factor applied to ``lr``."""
+    lr_final = cfg.lr if cfg.lr_final is None else cfg.lr_final
+    if step < cfg.warmup_steps:
+        lr = cfg.lr_pre_warmup + (cfg.lr - cfg.lr_pre_warmup) * math.sin(0.5 * math.pi * min(max(step / cfg.warmup_steps, 0), 1))
+    else:
+        t = min(max((step - cfg.warmup_steps) / (cfg.max_steps - cfg.warmup_steps), 0.0), 1.0)
+        lr = math.exp(math.log(cfg.lr) * (1 - t) + math.log(lr_final) * t)
+    return lr / cfg.lr
+
+
+@dataclass
+class TrainerConfig:
+    """The TrainerConfig / datamanager fields the reference sets [REF config_thermal_nerf.py:17-30]."""
+
+    max_num_iterations: int = 30000
+    steps_per_save: int = 2000
+    train_num_rays_per_batch: int = 4096
+    optimizers: Dict[str, OptimizerConfig] = field(default_factory=default_optimizers)
+    mixed_precision: bool = False  # the reference asks for fp16 autocast; this path computes in fp32
+    seed: int = 0
+
+
+class RayDataset:
+    """All training rays resident on the device: origins/directions [N,3], camera_indices [N,1], image [N,3], thermal [N,1]."""
+
+    def __init__(self, origins: Tensor, directions: Tensor, camera_indices: Tensor, image: Tensor, thermal: Tensor) -> None:
+        n = origins.shape[0]
+        assert directions.shape == (n, 3) and camera_indices.shape == (n, 1) and image.shape == (n, 3) and thermal.shape == (n, 1)
+        self.origins, self.directions, self.camera_indices = origins, directions, camera_indices
+        self.image, self.thermal = image, thermal
+
+    def __len__(self) -> int:
+        return self.origins.shape[0]
+
+    @classmethod
+    def from_images(cls, cameras: Cameras, images: Sequence[Tensor], thermals: Sequence[Tensor], device="cuda") -> "RayDataset":
+        """images[i] [H,W,3], thermals[i] [H,W,1] in [0,1] (what ThermalDataset yields, REF thermal_dataset.py:50-73)."""
+        o, d, c, im, th = [], [], [], [], []
+        for i in range(len(cameras)):
+            rb = cameras.generate_rays(i, device=device, flat=True)
+            o.append(rb.origins)
+            d.append(rb.directions)
+            c.append(rb.camera_indices)
+            im.append(images[i].reshape(-1, 3).to(device=device, dtype=torch.float32))
+            th.append(thermals[i].reshape(-1, 1).to(device=device, dtype=torch.float32))
+        return cls(torch.cat(o), torch.cat(d), torch.cat(c), torch.cat(im), torch.cat(th))
+
+    def sample(self, num_rays: int, generator: Optional[torch.Generator] = None) -> Tuple[RayBundle, Dict[str, Tensor]]:
+        idx = torch.randint(0, len(self), (num_rays,), device=self.origins.device, generator=generator)
+        rb = RayBundle(origins=self.origins[idx], directions=self.directions[idx], camera_indices=self.camera_indices[idx])
+        return rb, {"image": self.image[idx], "thermal": self.thermal[idx]}
+
+
+class Trainer:
+    def __init__(self, model, dataset: RayDataset, config: Optional[TrainerConfig] = None) -> None:
+        self.model, self.dataset = model, dataset
+        self.config = config or TrainerConfig()
+        self.step = 0
+        self.optimizers: Dict[str, torch.optim.Optimizer] = {}
+        self.schedulers: Dict[str, torch.optim.lr_scheduler.LambdaLR] = {}
+        for name, params in model.get_param_groups().items():
+            oc = self.config.optimizers.get(name)
+            if oc is None:
+                raise KeyError(f"no optimizer configured for parameter group '{name}'")
+            opt = torch.optim.Adam(params, lr=oc.lr, eps=oc.eps, weight_decay=oc.weight_decay)
+            self.optimizers[name] = opt
+            self.schedulers[name] = torch.optim.lr_scheduler.LambdaLR(opt, lambda s, oc=oc: exponential_decay_multiplier(oc, s))
+        self.generator = torch.Generator(device=dataset.origins.device)
+        self.generator.manual_seed(self.config.seed)
+
+    def train_iteration(self, step: int) -> Tuple[Tensor, Dict[str, Tensor], Dict[str, Tensor]]:
+        """NS Trainer.train_iteration: callbacks, forward, losses, backward, optimizer + scheduler steps."""
+        model = self.model
+        model.train()
+        model.set_step(step)
+        ray_bundle, batch = self.dataset.sample(self.config.train_num_rays_per_batch, self.generator)
+        outputs = model(ray_bundle)
+        metrics_dict = model.get_metrics_dict(outputs, batch)
+        loss_dict = model.get_loss_dict(outputs, batch, metrics_dict)
+        loss = sum(loss_dict.values())
+        for opt in self.optimizers.values():
+            opt.zero_grad(set_to_none=True)
+        loss.backward()
+        for name, opt in self.optimizers.items():
+            opt.step()
+            self.schedulers[name].step()
+        return loss.detach(), loss_dict, metrics_dict
+
+    def train(self, num_iterations: Optional[int] = None, checkpoint_dir=None, log_every: int = 0) -> List[float]:
+        end = self.config.max_num_iterations if num_iterations is None else self.step + num_iterations
+        history: List[float] = []
+        while self.step < end:
+            loss, _, metrics = self.train_iteration(self.step)
+            if log_every and self.step % log_every == 0:
+                history.append(float(loss))
+            self.step += 1
+            if checkpoint_dir is not None and self.step % self.config.steps_per_save == 0:
+                self.save_checkpoint(checkpoint_dir)
+        return history
+
+    # nerfstudio's Trainer.save_checkpoint layout: step, pipeline, optimizers, schedulers (scalers: no AMP here)
+    def save_checkpoint(self, directory) -> Path:
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        path = directory / f"step-{self.step:09d}.ckpt"
+        torch.save({
+            "step": self.step,
+            "pipeline": {"_model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+            "optimizers": {k: v.state_dict() for k, v in self.optimizers.items()},
+            "schedulers": {k: v.state_dict() for k, v in self.schedulers.items()},
+        }, path)
+        return path
+
+    def load_checkpoint(self, source) -> int:
+        """Resume: model weights through checkpoint.load_nerfstudio_checkpoint, optimizer/scheduler state as saved."""
+        from .checkpoint import latest_checkpoint, load_nerfstudio_checkpoint
+
+        path = Path(source)
+        if path.is_dir():
+            path = latest_checkpoint(path)
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        load_nerfstudio_checkpoint(self.model, state)
+        for k, v in state.get("optimizers", {}).items():
+            self.optimizers[k].load_state_dict(v)
+        for k, v in state.get("schedulers", {}).items():
+            self.schedulers[k].load_state_dict(v)
+        self.step = int(state["step"])
+        return self.step
+
+
+@torch.no_grad()
+def render_view(model, cameras: Cameras, index: int, device="cuda") -> Dict[str, Tensor]:
+    """Eval render of one camera (NS get_outputs_for_camera_ray_bundle) -> [H,W,C] tensors."""
+    was_training = model.training
+    model.eval()
+    out = model.get_outputs_for_camera_ray_bundle(cameras.generate_rays(index, device=device))
+    model.train(was_training)
+    return out

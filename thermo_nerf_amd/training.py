@@ -238,7 +238,9 @@ class RenderTrain(torch.autograd.Function):
         ctx.updated = bool(updated)
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.params = {n: p for n, p in zip(ctx.param_names, params)}
-        outs = (rgb, thermal, acc, tapes[0].weights[..., None], tapes[1].weights[..., None], f.weights[..., None],
+        # ctx must not hold a tensor OBJECT that is also returned as a differentiable output (output -> grad_fn -> ctx ->
+        # output is a cycle the collector cannot see: the step's whole tape would leak); return fresh views instead
+        outs = (rgb, thermal, acc.view(R, 1), tapes[0].weights[..., None], tapes[1].weights[..., None], f.weights[..., None],
                 depth, expected, prop_depths[0], prop_depths[1], tapes[0].spacing, tapes[1].spacing, f.spacing,
                 tapes[0].eucl, tapes[1].eucl, f.eucl)
         ctx.mark_non_differentiable(*outs[6:])
@@ -323,7 +325,9 @@ class RenderTrain(torch.autograd.Function):
                 net = model.proposal_networks[lvl].c_struct()
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{lvl}", like)
 
-        return (None,) * 8 + tuple(grads.get(n) for n in ctx.param_names)
+        result = (None,) * 8 + tuple(grads.get(n) for n in ctx.param_names)
+        ctx.tapes = ctx.field_tape = ctx.acts = ctx.acc = None  # the tape is dead after one backward
+        return result
 
 
 # --------------------------------------------------------------------------------------------------
