@@ -106,13 +106,14 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.rays import RayBundle
 
-    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=samples, camera_optimizer_mode="off")
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=samples)  # camera_optimizer_mode = SO3xR3, the reference default
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, "scene")
     sd_cpu = synthetic.model_state_dict_cpu(model) if cpu else None
     model.to(dev).train()
     groups = model.get_param_groups()
-    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}], lr=1e-2, eps=1e-15)
+    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]},
+                            {"params": groups["camera_opt"], "lr": 6e-4}], lr=1e-2, eps=1e-15)
     g = torch.Generator().manual_seed(0)
     side = int(rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
@@ -140,7 +141,7 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / steps
     res = {"what": "train step: taped forward + losses + backward + Adam, %d rays/step, P=(256,96)+%d samples/ray, "
-                   "steps %d.. (proposal nets updated every 6th step), camera optimizer off" % (R, samples, start_step),
+                   "steps %d.. (proposal nets updated every 6th step), camera optimizer SO3xR3" % (R, samples, start_step),
            "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps}
     if cpu:
         from oracle import training as T

@@ -275,6 +275,15 @@ int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const flo
 int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
                        int64_t n, float *d_table, void *stream);
 
+/* and w.r.t. the WORLD positions (camera-pose optimisation, NS CameraOptimizer applied at REF thermal_nerf_model.py:
+ * 218-219): through the trilinear offsets, `p * selector`, (x + 2) / 4 and the L-inf contraction (or the AABB
+ * normalisation): d_enc [N, 2*num_levels] -> d_positions [N,3] (=). */
+int tn_hash_encode_bwd_input(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                             int64_t n, float *d_positions, void *stream);
+/* backward of tn_frustum_positions: d_positions [R,n,3] -> d_origins [R,3] (+=), d_directions [R,3] (+=). */
+int tn_frustum_positions_bwd(const float *d_positions, const float *starts, const float *ends, int64_t num_rays, int32_t n,
+                             float *d_origins, float *d_directions, void *stream);
+
 /* torch.nn.Linear (+ activation): y[n, :out] = act(x[n, :in] W^T + b); x rows are ldx floats apart, y rows ldy.
  * in_dim, out_dim <= 64. */
 int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act, int64_t n, float *y, int32_t ldy,
@@ -309,10 +318,11 @@ int tn_composite_bwd(const float *values, const float *weights, const float *acc
 int tn_color_input_fwd(const tn_thermal_field *field, const float *directions, const float *geo, int32_t ld_geo,
                        const int32_t *camera_indices, int32_t training, int64_t num_rays, int32_t n, float *cin,
                        void *stream);
-/* backward: d_cin [R*n,64] -> d_geo (+=, rows ld_d_geo apart), d_appearance [num_images, app_dim] (+=; training). */
+/* backward: d_cin [R*n,64] -> d_geo (+=, rows ld_d_geo apart), d_appearance [num_images, app_dim] (+=; training),
+ * d_directions [R,3] (+=; through the SH basis; NULL to skip, needs `directions`). */
 int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const int32_t *camera_indices,
                        int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
-                       float *d_appearance, void *stream);
+                       float *d_appearance, const float *directions, float *d_directions, void *stream);
 
 /* NS losses.distortion_loss on one level: spacing bins [R,n+1], weights [R,n] -> loss_sum[0] (+=) = sum over rays
  * of lossfun_distortion (divide by R for the mean), d_weights [R,n] (=) = d(sum)/dw.  O(n) per ray. */

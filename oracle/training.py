@@ -125,7 +125,9 @@ def loss_and_grads(sd: Dict[str, Tensor], origins: Tensor, directions: Tensor, c
                 leaves[k] = v.detach().to(dtype).clone().requires_grad_(True)
         sdd = {k: (leaves[k] if k in leaves else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
         jit = [j.to(dtype) for j in jitter]
-        out = H.get_outputs(sdd, origins.to(dtype), directions.to(dtype), camera_indices, cfg, training=True,
+        origins = origins.detach().to(dtype).clone().requires_grad_(True)      # what a camera optimizer differentiates
+        directions = directions.detach().to(dtype).clone().requires_grad_(True)
+        out = H.get_outputs(sdd, origins, directions, camera_indices, cfg, training=True,
                             jitter=jit, anneal=anneal, proposal_requires_grad=proposal_requires_grad)
         b = {k: v.to(dtype) for k, v in batch.items()}
         metrics = get_metrics_dict(out, b, True)
@@ -133,6 +135,7 @@ def loss_and_grads(sd: Dict[str, Tensor], origins: Tensor, directions: Tensor, c
         total = sum(loss_dict.values())
         total.backward()
         grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+        grads["__origins__"], grads["__directions__"] = origins.grad, directions.grad
     finally:
         torch.set_default_dtype(prev)
     return out, loss_dict, grads

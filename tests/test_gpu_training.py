@@ -224,7 +224,7 @@ def test_training_step_matches_autograd_oracle(kind, S):
     named = dict(gm.named_parameters())
     checked = 0
     for name, gw in want_grads.items():
-        if gw.numel() == 0 or name.startswith("camera_optimizer"):
+        if gw.numel() == 0 or name.startswith("camera_optimizer") or name.startswith("__"):
             continue
         gg = named[name].grad
         if gw.norm().item() == 0.0:
@@ -289,14 +289,70 @@ def test_adam_steps_reduce_the_loss_and_eval_follows():
     assert (got["rgb"].cpu() - want["rgb"]).abs().mean().item() <= 2e-4
 
 
-def test_camera_pose_gradients_are_refused():
-    cm, _, _ = helpers.build("init", 48)  # default camera_optimizer_mode = SO3xR3, as in the reference
+@pytest.mark.parametrize("kind,contraction", [("stress", True), ("scene", True), ("stress", False)])
+def test_ray_gradients_match_autograd_oracle(kind, contraction):
+    """d loss / d (origins, directions) — what a camera optimizer backpropagates — through the sample positions of all
+    three levels (trilinear offsets, selector, contraction / AABB) and the SH basis."""
+    over = {} if contraction else {"disable_scene_contraction": True}
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, 48, **over)
+    if not contraction:
+        o = o * 0.6
+    od, dd = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+    rb = gm.collider(RayBundle(origins=od, directions=dd, camera_indices=cam.to(DEV)))
+    out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values()).backward()
+    _, _, want = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit)
+    # the position gradient is a sum over 16 levels of (feature differences x level scale up to 2047): the fine levels
+    # dominate and cancel.  Yardstick: the fp32 oracle itself is 3e-3 .. 1e-2 away from its fp64 run on these cases.
+    assert rel(od.grad, want["__origins__"]) <= 2e-2, rel(od.grad, want["__origins__"])
+    assert rel(dd.grad, want["__directions__"]) <= 2e-2, rel(dd.grad, want["__directions__"])
+    # and the parameter gradients are unchanged by asking for ray gradients
+    assert rel(gm.field.mlp_head.layers[0].weight.grad, want["field.mlp_head.layers.0.weight"]) <= 2e-3
+
+
+def test_camera_optimizer_receives_the_pose_gradient():
+    """Reference default camera_optimizer_mode="SO3xR3" [REF nerfacto_config/thermal_nerfacto.py:24]: pose_adjustment gets
+    its gradient through apply_to_raybundle (torch) from the HIP ray gradients."""
+    from thermo_nerf_amd.camera_optimizer import CameraOptimizer, CameraOptimizerConfig
+
+    cm, sd, ocfg = helpers.build("stress", 48)
+    assert cm.config.camera_optimizer.mode == "SO3xR3"
     gm = copy.deepcopy(cm).to(DEV).train()
-    o, d = helpers.rays(4, 4)
-    rb = gm.collider(RayBundle(origins=o.to(DEV), directions=d.to(DEV),
-                               camera_indices=torch.zeros(o.shape[0], 1, dtype=torch.long, device=DEV)))
-    with pytest.raises(NotImplementedError, match="camera"):
-        gm.get_outputs(rb)
+    o, d = helpers.rays(12, 12, view=3)
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(5)
+    cam = torch.randint(0, 8, (R, 1), generator=g)
+    batch = {"image": torch.rand(R, 3, generator=g), "thermal": torch.rand(R, 1, generator=g)}
+    pose = 0.02 * torch.randn(8, 6, generator=g)
+    with torch.no_grad():
+        gm.camera_optimizer.pose_adjustment.copy_(pose)
+    jit = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    # the model draws its own jitter inside forward: fix it by seeding the device generator the same way twice
+    rb = RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV))
+    rb = gm.collider(rb)
+    gm.camera_optimizer.apply_to_raybundle(rb)
+    out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    gm.zero_grad(set_to_none=True)
+    sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values()).backward()
+    got = gm.camera_optimizer.pose_adjustment.grad
+    assert got is not None and torch.isfinite(got).all() and got.abs().max().item() > 0
+
+    # expected: the same chain on the CPU — camera optimizer (torch) in front of the autograd oracle
+    copt = CameraOptimizer(CameraOptimizerConfig(mode="SO3xR3"), 8)
+    with torch.no_grad():
+        copt.pose_adjustment.copy_(pose)
+    rb_cpu = RayBundle(origins=o.clone(), directions=d.clone(), camera_indices=cam)
+    copt.apply_to_raybundle(rb_cpu)
+    _, _, want = T.loss_and_grads(sd, rb_cpu.origins.detach(), rb_cpu.directions.detach(), cam, batch, ocfg, jit)
+    (rb_cpu.origins * want["__origins__"]).sum().backward(retain_graph=True)
+    (rb_cpu.directions * want["__directions__"]).sum().backward()
+    assert rel(got, copt.pose_adjustment.grad) <= 2e-2, rel(got, copt.pose_adjustment.grad)
+    # used cameras only
+    used = torch.zeros(8, dtype=torch.bool)
+    used[cam.reshape(-1)] = True
+    assert torch.all(got.cpu()[~used] == 0)
 
 
 # --------------------------------------------------------------------------------------------------

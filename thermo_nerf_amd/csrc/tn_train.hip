@@ -137,6 +137,105 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
     }
 }
 
+// Gradient of the encoding w.r.t. the WORLD position (camera-pose optimisation): d enc / d offset per level from the
+// same 8 corners (table reads this time), times the level scale; then back through `p * selector`, the
+// (x + 2) / 4 shift and the L-inf contraction (or the AABB normalisation).  One lane per sample, levels looped.
+__global__ void __launch_bounds__(kBlock)
+hash_encode_bwd_input_kernel(Grid g, tn_space space, const float *__restrict__ positions, const float *__restrict__ d_enc,
+                             long long n, float *__restrict__ d_pos) {
+    const Space sp = make_space(space);
+    const int L = g.num_levels;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float x = positions[i * 3], y = positions[i * 3 + 1], z = positions[i * 3 + 2];
+        float px, py, pz;
+        const float sel = normalize_position(sp, x, y, z, px, py, pz);
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;  // d loss / d p (p = normalised, selector applied)
+        for (int l = 0; l < L; ++l) {
+            const float2 ge = reinterpret_cast<const float2 *>(d_enc)[i * L + l];
+            const float s = g.scal[l];
+            const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+            const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+            const float ox = sub_rn(sx, fxf), oy = sub_rn(sy, fyf), oz = sub_rn(sz, fzf);
+            const float qx = 1.0f - ox, qy = 1.0f - oy, qz = 1.0f - oz;
+            const unsigned cx = (unsigned)(int)ceilf(sx), cy = (unsigned)(int)ceilf(sy), cz = (unsigned)(int)ceilf(sz);
+            const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
+            const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
+            const float2 *t = g.table + (size_t)l * g.tsize;
+            const unsigned m = g.mask;
+            const float2 f0 = t[(cx ^ hcy ^ hcz) & m], f1 = t[(cx ^ hfy ^ hcz) & m], f2 = t[(fx ^ hfy ^ hcz) & m];
+            const float2 f3 = t[(fx ^ hcy ^ hcz) & m], f4 = t[(cx ^ hcy ^ hfz) & m], f5 = t[(cx ^ hfy ^ hfz) & m];
+            const float2 f6 = t[(fx ^ hfy ^ hfz) & m], f7 = t[(fx ^ hcy ^ hfz) & m];
+            // enc = ((f0 ox + f3 qx) oy + (f1 ox + f2 qx) qy) oz + ((f4 ox + f7 qx) oy + (f5 ox + f6 qx) qy) qz
+#define TN_DENC(c)                                                                                                   \
+            {                                                                                                        \
+                const float f03 = f0.c * ox + f3.c * qx, f12 = f1.c * ox + f2.c * qx;                                \
+                const float f47 = f4.c * ox + f7.c * qx, f56 = f5.c * ox + f6.c * qx;                                \
+                const float dox = ((f0.c - f3.c) * oy + (f1.c - f2.c) * qy) * oz + ((f4.c - f7.c) * oy + (f5.c - f6.c) * qy) * qz; \
+                const float doy = (f03 - f12) * oz + (f47 - f56) * qz;                                               \
+                const float doz = (f03 * oy + f12 * qy) - (f47 * oy + f56 * qy);                                     \
+                gx += ge.c * dox * s;                                                                                \
+                gy += ge.c * doy * s;                                                                                \
+                gz += ge.c * doz * s;                                                                                \
+            }
+            TN_DENC(x)
+            TN_DENC(y)
+#undef TN_DENC
+        }
+        gx *= sel; gy *= sel; gz *= sel;  // p = p * selector
+        float rx, ry, rz;
+        if (sp.contraction) {
+            gx *= 0.25f; gy *= 0.25f; gz *= 0.25f;  // (c + 2) / 4
+            const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+            const float mag = fmaxf(fmaxf(ax, ay), az);
+            if (mag < 1.0f) {
+                rx = gx; ry = gy; rz = gz;
+            } else {
+                // c = s(m) x,  s = 2/m - 1/m^2,  m = |x_k| (k = arg max)
+                const float sm = 2.0f / mag - 1.0f / (mag * mag);
+                const float dsm = -2.0f / (mag * mag) + 2.0f / (mag * mag * mag);
+                const float dot = gx * x + gy * y + gz * z;
+                rx = sm * gx; ry = sm * gy; rz = sm * gz;
+                // torch's inf-norm backward splits the subgradient evenly among tied maxima
+                const int ties = (ax == mag) + (ay == mag) + (az == mag);
+                const float share = dsm * dot / (float)ties;
+                if (ax == mag) rx += share * (x > 0.0f ? 1.0f : -1.0f);
+                if (ay == mag) ry += share * (y > 0.0f ? 1.0f : -1.0f);
+                if (az == mag) rz += share * (z > 0.0f ? 1.0f : -1.0f);
+            }
+        } else {
+            rx = gx / (sp.mx[0] - sp.mn[0]); ry = gy / (sp.mx[1] - sp.mn[1]); rz = gz / (sp.mx[2] - sp.mn[2]);
+        }
+        d_pos[i * 3] = rx; d_pos[i * 3 + 1] = ry; d_pos[i * 3 + 2] = rz;
+    }
+}
+
+// Frustums.get_positions backward: pos = o + d (s + e) / 2  ->  d_o += sum_i g_i,  d_d += sum_i g_i (s_i + e_i) / 2.
+__global__ void __launch_bounds__(kBlock)
+frustum_positions_bwd_kernel(const float *__restrict__ d_pos, const float *__restrict__ starts,
+                             const float *__restrict__ ends, long long R, int n, float *__restrict__ d_o,
+                             float *__restrict__ d_d) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    float a[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = lane; i < n; i += 64) {
+        const long long k = ray * n + i;
+        const float t = (starts[k] + ends[k]) / 2.0f;
+        const float gx = d_pos[k * 3], gy = d_pos[k * 3 + 1], gz = d_pos[k * 3 + 2];
+        a[0] += gx; a[1] += gy; a[2] += gz;
+        a[3] += gx * t; a[4] += gy * t; a[5] += gz * t;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a[q] = wave_sum(a[q]);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            d_o[ray * 3 + q] += a[q];
+            d_d[ray * 3 + q] += a[3 + q];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Linear layers.  A block owns tiles of 64 rows (samples); 256 threads = 64 rows x 4 column groups.
 // ------------------------------------------------------------------------------------------------------
@@ -484,6 +583,42 @@ color_input_bwd_app_kernel(int geo_dim, int app_dim, const float *__restrict__ d
     if (half == 0 && k < app_dim) atomic_add_f32(d_app + (size_t)cams[ray] * app_dim + k, s);
 }
 
+// direction part: d_dir[r] += J_SH(dir)^T sum_i d_cin[r, i, 0:16]  (x 1/2 when the SH input is (d + 1) / 2)
+__global__ void __launch_bounds__(kBlock)
+color_input_bwd_dir_kernel(int sh_shifted, const float *__restrict__ d_cin, const float *__restrict__ dirs, long long R,
+                           int n, float *__restrict__ d_dirs) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const int k = lane & 15, q = lane >> 4;  // component, sample stream
+    float s = 0.0f;
+    for (int i = q; i < n; i += 4) s += d_cin[(ray * n + i) * 64 + k];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    float g[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) g[c] = __shfl(s, c, 64);
+    if (lane != 0) return;
+    float x = dirs[ray * 3], y = dirs[ray * 3 + 1], z = dirs[ray * 3 + 2];
+    if (sh_shifted) {
+        x = add_rn(x, 1.0f) / 2.0f; y = add_rn(y, 1.0f) / 2.0f; z = add_rn(z, 1.0f) / 2.0f;
+    }
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float a1 = 0.4886025119029199f, a4 = 1.0925484305920792f, a6 = 0.9461746957575601f, a8 = 0.5462742152960396f;
+    const float a9 = 0.5900435899266435f, a10 = 2.890611442640554f, a11 = 0.4570457994644658f, a12 = 0.3731763325901154f;
+    const float a14 = 1.445305721320277f;
+    float dx = g[3] * a1 + g[4] * a4 * y + g[7] * a4 * z + g[8] * 2.0f * a8 * x + g[9] * 6.0f * a9 * x * y + g[10] * a10 * y * z +
+               g[13] * a11 * (5.0f * zz - 1.0f) + g[14] * 2.0f * a14 * x * z + g[15] * a9 * (3.0f * xx - 3.0f * yy);
+    float dy = g[1] * a1 + g[4] * a4 * x + g[5] * a4 * z - g[8] * 2.0f * a8 * y + g[9] * a9 * (3.0f * xx - 3.0f * yy) +
+               g[10] * a10 * x * z + g[11] * a11 * (5.0f * zz - 1.0f) - g[14] * 2.0f * a14 * y * z - g[15] * 6.0f * a9 * x * y;
+    float dz = g[2] * a1 + g[5] * a4 * y + g[6] * 2.0f * a6 * z + g[7] * a4 * x + g[10] * a10 * x * y + g[11] * 10.0f * a11 * y * z +
+               g[12] * a12 * (15.0f * zz - 3.0f) + g[13] * 10.0f * a11 * x * z + g[14] * a14 * (xx - yy);
+    const float f = sh_shifted ? 0.5f : 1.0f;
+    d_dirs[ray * 3] += f * dx;
+    d_dirs[ray * 3 + 1] += f * dy;
+    d_dirs[ray * 3 + 2] += f * dz;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // distortion loss: one wave per ray.  With sorted mid-points u:
 //   S_i = sum_j w_j |u_i - u_j| = u_i (W_<i - W_>i) - (WU_<i - WU_>i)
@@ -633,6 +768,30 @@ int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const flo
     return TN_OK;
 }
 
+int tn_hash_encode_bwd_input(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                             int64_t n, float *d_positions, void *stream) {
+    if (!grid || !space) return TN_ERR_NULL;
+    TN_TRY(tn_check_grid(*grid));
+    if (n == 0) return TN_OK;
+    if (!positions || !d_enc || !d_positions) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(hash_encode_bwd_input_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
+                       tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_positions);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_frustum_positions_bwd(const float *d_positions, const float *starts, const float *ends, int64_t num_rays, int32_t n,
+                             float *d_origins, float *d_directions, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!d_positions || !starts || !ends || !d_origins || !d_directions) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(frustum_positions_bwd_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream,
+                       d_positions, starts, ends, (long long)num_rays, n, d_origins, d_directions);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act, int64_t n, float *y, int32_t ldy,
                   void *stream) {
     if (!lin || !lin->weight) return TN_ERR_NULL;
@@ -771,7 +930,7 @@ int tn_color_input_fwd(const tn_thermal_field *field, const float *directions, c
 
 int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const int32_t *camera_indices,
                        int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
-                       float *d_appearance, void *stream) {
+                       float *d_appearance, const float *directions, float *d_directions, void *stream) {
     CinArgs a;
     TN_TRY(cin_args(field, training, &a));
     if (num_rays == 0) return TN_OK;
@@ -788,6 +947,12 @@ int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const 
         hipLaunchKernelGGL(color_input_bwd_app_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0,
                            (hipStream_t)stream, a.geo_dim, a.app_dim, d_cin, camera_indices, (long long)num_rays, n,
                            d_appearance);
+        TN_LAUNCH_CHECK();
+    }
+    if (d_directions) {
+        if (!directions) return TN_ERR_NULL;
+        hipLaunchKernelGGL(color_input_bwd_dir_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0,
+                           (hipStream_t)stream, a.sh_shifted, d_cin, directions, (long long)num_rays, n, d_directions);
         TN_LAUNCH_CHECK();
     }
     return TN_OK;

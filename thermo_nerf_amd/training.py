@@ -10,8 +10,8 @@ reductions over [R,3]/[R,1] pixels, and the optimizer.
 
 What carries gradient (as in nerfstudio): the final level through rgb / thermal / accumulation and its weights; the
 proposal levels only through their weights (PDFSampler detaches the sample positions), and only on steps where
-ProposalNetworkSampler's update schedule says so.  Not differentiated: median/expected depth.  Camera-pose gradients
-(``camera_optimizer_mode != "off"``) are not implemented and raise.
+ProposalNetworkSampler's update schedule says so; the ray origins / directions through the sample positions and the
+SH basis when a camera optimizer makes them depend on ``pose_adjustment``.  Not differentiated: median/expected depth.
 """
 from __future__ import annotations
 
@@ -130,7 +130,21 @@ def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl:
     return t
 
 
-def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict) -> None:
+def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, g_d: Tensor) -> None:
+    """d loss / d (origins, directions) through the sample positions of one level (camera-pose optimisation)."""
+    lib = _hip.load()
+    n = t.pos.shape[0]
+    R, per = t.deltas.shape
+    g_pos = _f32((n, 3), g_enc.device)
+    _hip.check(lib.tn_hash_encode_bwd_input(grid, space, t.pos.data_ptr(), g_enc.data_ptr(), n, g_pos.data_ptr(), _stream()),
+               "tn_hash_encode_bwd_input")
+    starts, ends = t.eucl[:, :-1].contiguous(), t.eucl[:, 1:].contiguous()
+    _hip.check(lib.tn_frustum_positions_bwd(g_pos.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, per, g_o.data_ptr(),
+                                            g_d.data_ptr(), _stream()), "tn_frustum_positions_bwd")
+
+
+def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict,
+                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None) -> None:
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
@@ -150,6 +164,8 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
     g_enc = _f32((n, E), g_w.device)
     linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
     hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]])
+    if ray_grads is not None:
+        _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads)
 
 
 class RenderTrain(torch.autograd.Function):
@@ -260,6 +276,10 @@ class RenderTrain(torch.autograd.Function):
         fld = model.field.c_struct(prepare=False)
         like = ctx.params
         grads: Dict[str, Tensor] = {}
+        # camera-pose optimisation: the ray origins / directions carry gradient (NS CameraOptimizer.apply_to_raybundle)
+        ray_grads = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            ray_grads = (torch.zeros_like(ctx.o), torch.zeros_like(ctx.d))
 
         def zeros(name: str) -> Tensor:
             grads[name] = torch.zeros_like(like[name])
@@ -305,7 +325,9 @@ class RenderTrain(torch.autograd.Function):
             linear_bwd(cin, 0, 64, c1, g_c1, W, fld.head0, ACT_RELU, N, g_cin, 0, 64, False,
                        zeros("field.mlp_head.layers.0.weight"), zeros("field.mlp_head.layers.0.bias"))
             _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, S, g_bo.data_ptr() + 4, ldb,
-                                              zeros("field.embedding_appearance.embedding.weight").data_ptr(), _stream()),
+                                              zeros("field.embedding_appearance.embedding.weight").data_ptr(),
+                                              ctx.d.data_ptr() if ray_grads else None,
+                                              ray_grads[1].data_ptr() if ray_grads else None, _stream()),
                        "tn_color_input_bwd")
         g_h1 = _f32((N, W), dev)
         linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False,
@@ -315,6 +337,8 @@ class RenderTrain(torch.autograd.Function):
         linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False,
                    zeros("field.mlp_base.mlp.layers.0.weight"), zeros("field.mlp_base.mlp.layers.0.bias"))
         hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"))
+        if ray_grads:
+            _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
 
         # ---- proposal levels (only through their weights) --------------------------------------------------
         if ctx.updated:
@@ -323,9 +347,11 @@ class RenderTrain(torch.autograd.Function):
                     continue
                 t = ctx.tapes[lvl]
                 net = model.proposal_networks[lvl].c_struct()
-                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{lvl}", like)
+                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{lvl}", like,
+                                    ray_grads)
 
-        result = (None,) * 8 + tuple(grads.get(n) for n in ctx.param_names)
+        g_o, g_d = ray_grads if ray_grads else (None, None)
+        result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)
         ctx.tapes = ctx.field_tape = ctx.acts = ctx.acc = None  # the tape is dead after one backward
         return result
 
@@ -393,9 +419,6 @@ def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) 
 def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """Train-mode ``get_outputs`` with gradients [REF thermal_nerf_model.py:210-275]."""
     cfg = model.config
-    if cfg.camera_optimizer.mode != "off":
-        raise NotImplementedError("gradients w.r.t. camera poses are not implemented: train with "
-                                  'camera_optimizer_mode="off" (the forward pass supports SO3xR3)')
     if (cfg.num_proposal_iterations != 2 or cfg.use_same_proposal_network or cfg.predict_normals
             or cfg.use_gradient_scaling or not cfg.use_single_jitter):
         raise NotImplementedError("the training path implements the reference configuration: two proposal networks, "

@@ -20,16 +20,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--weights", default="scene")
     ap.add_argument("--no-opt", action="store_true")
+    ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode="off")
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
     groups = model.get_param_groups()
-    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}], lr=1e-2, eps=1e-15)
+    pg = [{"params": groups["fields"]}, {"params": groups["proposal_networks"]}]
+    if "camera_opt" in groups:
+        pg.append({"params": groups["camera_opt"], "lr": 6e-4})
+    opt = torch.optim.Adam(pg, lr=1e-2, eps=1e-15)
     g = torch.Generator().manual_seed(0)
     side = int(a.rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
