@@ -420,3 +420,59 @@ def test_trainer_fits_analytic_scene_and_resumes(tmp_path):
     other.proposal_sampler.set_anneal(model.proposal_sampler._anneal)
     p2, m2 = evaluate(other)
     assert abs(p2 - p1) < 1e-3 and abs(m2 - m1) < 1e-5
+
+
+def test_thermoscenes_style_tree_to_training_steps(tmp_path):
+    """Dataset boundary end to end: write a transforms.json tree (images/ + thermal/ PNGs, frame_train_* / frame_eval_*),
+    parse it with the Thermal dataparser, build the HBM ray table and take optimisation steps on it."""
+    import json
+
+    import numpy as np
+    from PIL import Image
+
+    from thermo_nerf_amd import ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd.data import ThermalDataParserConfig, ThermalDataset
+    from thermo_nerf_amd.trainer import Trainer, TrainerConfig
+
+    res, n = 32, 10
+    cams = synthetic.orbit_cameras(res, res, list(range(n)), num_views=n, elevation_deg=[(0.0, 25.0)[v % 2] for v in range(n)])
+    (tmp_path / "images").mkdir()
+    (tmp_path / "thermal").mkdir()
+    frames = []
+    for i in range(n):
+        rb = cams.generate_rays(i, device=DEV)
+        rgb, th = synthetic.analytic_scene(rb.origins, rb.directions)
+        name = f"frame_{'eval' if i % 5 == 4 else 'train'}_{i:04d}.png"
+        Image.fromarray((rgb.cpu().numpy() * 255).round().astype(np.uint8)).save(tmp_path / "images" / name)
+        Image.fromarray((th[..., 0].cpu().numpy() * 255).round().astype(np.uint8), mode="L").save(tmp_path / "thermal" / name)
+        c2w = torch.cat([cams.camera_to_worlds[i], torch.tensor([[0.0, 0.0, 0.0, 1.0]])]).tolist()
+        frames.append({"file_path": f"images/{name}", "thermal_file_path": f"thermal/{name}", "transform_matrix": c2w})
+    f = float(cams.fx[0])
+    (tmp_path / "transforms.json").write_text(json.dumps(
+        {"fl_x": f, "fl_y": f, "cx": res / 2, "cy": res / 2, "w": res, "h": res, "frames": frames}))
+
+    parser = ThermalDataParserConfig(data=tmp_path).setup()
+    train_out, eval_out = parser.get_dataparser_outputs("train"), parser.get_dataparser_outputs("val")
+    assert len(train_out.cameras) == 8 and len(eval_out.cameras) == 2
+    ds = ThermalDataset(train_out)
+    table = ds.to_ray_table(DEV)
+    assert len(table) == 8 * res * res and table.thermal.shape == (8 * res * res, 1)
+    assert table.camera_indices.max().item() == 7
+    # quantised to 8 bits on disk: within half a grey level of the analytic value
+    rb0 = train_out.cameras.generate_rays(0, device=DEV, flat=True)
+    assert torch.equal(rb0.origins, table.origins[: res * res])
+
+    cfg = ThermalNerfModelConfig(**helpers.SMALL)  # camera optimizer SO3xR3, as in the reference
+    model = ThermalNerfModel(cfg, metadata=train_out.metadata, scene_box=train_out.scene_box, num_train_data=len(ds)).to(DEV)
+    synthetic.fill_model_(model, "init")
+    tr = Trainer(model, table, TrainerConfig(train_num_rays_per_batch=2048))
+    first = None
+    for step in range(30):
+        loss, loss_dict, metrics = tr.train_iteration(step)
+        tr.step += 1
+        first = loss.item() if first is None else first
+    assert set(loss_dict) == {"rgb_loss", "interlevel_loss", "distortion_loss", "thermal"}
+    assert torch.isfinite(loss) and loss.item() < 0.6 * first
+    assert model.camera_optimizer.pose_adjustment.grad is not None
+    with pytest.raises(ValueError, match="Thermal images not found"):
+        ThermalNerfModel(cfg, metadata={}, scene_box=train_out.scene_box, num_train_data=8)  # REF thermal_nerf_model.py:75-76
