@@ -114,10 +114,12 @@ typedef struct tn_thermal_field {
 /* NS Cameras.generate_rays for one perspective camera, as called by the reference's harnesses
  * [REF thermo_nerf/render/renderer.py:182-184; thermo_nerf/evaluator/evaluator.py:68-70]: pixels
  * [first_pixel, first_pixel + num_pixels) of the row-major H x W image (pixel centres at +0.5) ->
- * origins [n,3], unit directions [n,3], pixel_area [n] (may be NULL).  c2w_host = 12 HOST floats, row-major [3,4]. */
+ * origins [n,3], unit directions [n,3], pixel_area [n] (may be NULL).  c2w_host = 12 HOST floats, row-major [3,4].
+ * distortion_host = 6 HOST floats (k1, k2, k3, k4, p1, p2: NS get_distortion_params order) or NULL; when any is non-zero
+ * the normalised pixel coordinates go through NS camera_utils.radial_and_tangential_undistort (10 Newton steps). */
 int tn_generate_rays(const float *c2w_host, float fx, float fy, float cx, float cy, int32_t height, int32_t width,
-                     int64_t first_pixel, int64_t num_pixels, float *origins, float *directions, float *pixel_area,
-                     void *stream);
+                     const float *distortion_host, int64_t first_pixel, int64_t num_pixels, float *origins,
+                     float *directions, float *pixel_area, void *stream);
 
 /* NS Frustums.get_positions: pos = origins + directions * (starts + ends) / 2.
  * origins/directions [R,3]; starts/ends [R,n]; positions out [R,n,3]. */

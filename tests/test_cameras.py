@@ -74,3 +74,37 @@ def test_render_camera_path_frame_end_to_end(golden_dir):
     assert (got["thermal"].cpu() - want["thermal"]).abs().mean().item() < 1e-4
     m = C.frame_metrics(got, want["rgb"], want["thermal"], 33.085, 13.896)
     assert m["psnr"] > 60 and m["mae_thermal"] < 2e-3  # degrees C over a 19.2 C span
+
+
+def test_undistortion_oracle_inverts_the_opencv_model():
+    """CPU: NS radial_and_tangential_undistort restated in oracle/cameras.py is the inverse of the forward model."""
+    g = torch.Generator().manual_seed(0)
+    pts = (torch.rand(500, 2, generator=g) - 0.5) * 1.2
+    for k in ([0.12, -0.05, 0.0, 0.0, 0.003, -0.002], [-0.2, 0.04, 0.01, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0, 0.01, 0.01]):
+        kk = torch.tensor(k)
+        und = OC.radial_and_tangential_undistort(OC.distort(pts, kk), kk)
+        assert (und - pts).abs().max().item() < 1e-5, k
+    zero = torch.zeros(6)
+    assert torch.equal(OC.radial_and_tangential_undistort(pts, zero), pts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [[0.12, -0.05, 0.0, 0.0, 0.003, -0.002], [-0.25, 0.08, 0.0, 0.0, 0.0, 0.0],
+                               [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]])
+def test_generate_rays_with_lens_distortion_matches_oracle(k):
+    """OPENCV k1/k2/p1/p2 as nerfstudio-processed ThermoScenes carry them: device rays vs the oracle's Newton undistortion."""
+    from thermo_nerf_amd import synthetic
+
+    cams = synthetic.orbit_cameras(60, 80, [0, 3], num_views=8)
+    cams.distortion_params = torch.tensor([k, k])
+    rb = cams.generate_rays(1, device="cuda:0")
+    o, d, a = OC.generate_rays(cams.camera_to_worlds[1], float(cams.fx[1]), float(cams.fy[1]), cams.cx, cams.cy, 60, 80,
+                               distortion_params=torch.tensor(k))
+    assert torch.equal(rb.origins.cpu(), o)
+    assert (rb.directions.cpu() - d).abs().max().item() <= 2e-6
+    assert ((rb.pixel_area.cpu() - a).abs() / a).max().item() <= 2e-3
+    plain = OC.generate_rays(cams.camera_to_worlds[1], float(cams.fx[1]), float(cams.fy[1]), cams.cx, cams.cy, 60, 80)[1]
+    if any(k):
+        assert (d - plain).abs().max().item() > 1e-3  # the distortion actually bends the corner rays
+    else:
+        assert torch.equal(d, plain)

@@ -111,11 +111,15 @@ def test_split_lists_per_frame_intrinsics_and_refusals(tmp_path):
     make_scene(tmp_path / "b", per_frame_intrinsics=True)
     cams = ThermalDataParserConfig(data=tmp_path / "b").setup().get_dataparser_outputs("train").cameras
     assert cams.fx.shape == (5,) and len(set(cams.fx.tolist())) == 5 and cams.width == 8
-    make_scene(tmp_path / "c", extra={"k1": 0.1})
-    with pytest.raises(NotImplementedError, match="distortion"):
-        ThermalDataParserConfig(data=tmp_path / "c").setup().get_dataparser_outputs("train")
-    make_scene(tmp_path / "d", extra={"k1": 0.0, "p1": 0.0})  # explicit zeros are fine
-    ThermalDataParserConfig(data=tmp_path / "d").setup().get_dataparser_outputs("train")
+    make_scene(tmp_path / "c", extra={"k1": 0.1, "p2": -0.01})
+    cams = ThermalDataParserConfig(data=tmp_path / "c").setup().get_dataparser_outputs("train").cameras
+    assert cams.distortion_params.shape == (5, 6)
+    assert torch.allclose(cams.distortion_params[3], torch.tensor([0.1, 0.0, 0.0, 0.0, 0.0, -0.01]))  # k1 k2 k3 k4 p1 p2
+    assert torch.equal(ThermalDataParserConfig(data=tmp_path / "b").setup().get_dataparser_outputs("train").cameras
+                       .distortion_params, torch.zeros(5, 6))
+    make_scene(tmp_path / "d", extra={"camera_model": "OPENCV_FISHEYE"})
+    with pytest.raises(NotImplementedError, match="perspective"):
+        ThermalDataParserConfig(data=tmp_path / "d").setup().get_dataparser_outputs("train")
 
 
 def test_dataset_items(tmp_path):

@@ -135,8 +135,8 @@ class tn_render_outputs(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/thermonerf_hip.h
 _vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
 SIGNATURES = {
-    "tn_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, _i32, _i32, _i64,
-                                   _i64, _vp, _vp, _vp, _vp]),
+    "tn_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, _i32, _i32,
+                                   C.POINTER(C.c_float), _i64, _i64, _vp, _vp, _vp, _vp]),
     "tn_frustum_positions": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tn_density_fwd": (C.c_int, [C.POINTER(tn_density_field), _vp, _i64, _vp, _vp]),
     "tn_field_density_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _i64, _vp, _vp, _vp]),

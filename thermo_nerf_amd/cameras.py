@@ -32,6 +32,7 @@ class Cameras:
     cy: float
     height: int
     width: int
+    distortion_params: Optional[Tensor] = None  # [N,6] (k1, k2, k3, k4, p1, p2) as NS get_distortion_params, or None
 
     def __len__(self) -> int:
         return self.camera_to_worlds.shape[0]
@@ -61,11 +62,14 @@ class Cameras:
         area = torch.empty((n, 1), dtype=torch.float32, device=dev)
         _hip.require_device_tensor(o, "origins")
         c2w = (ctypes.c_float * 12)(*self.camera_to_worlds[idx].reshape(-1).tolist())
+        dist = None
+        if self.distortion_params is not None:
+            dist = (ctypes.c_float * 6)(*self.distortion_params[idx].reshape(-1).tolist())
         lib = _hip.load()
         with torch.cuda.device(dev):
             _hip.check(
                 lib.tn_generate_rays(c2w, float(self.fx[idx]), float(self.fy[idx]), float(self.cx), float(self.cy),
-                                     self.height, self.width, r0 * self.width, n, o.data_ptr(), d.data_ptr(),
+                                     self.height, self.width, dist, r0 * self.width, n, o.data_ptr(), d.data_ptr(),
                                      area.data_ptr(), _hip.current_stream()),
                 "tn_generate_rays",
             )

@@ -261,19 +261,58 @@ __device__ __forceinline__ void cam_dir(const CamArgs &c, float u, float v, floa
     dy = y / n;
     dz = z / n;
 }
-__global__ void generate_rays_kernel(CamArgs c, long long first, long long count, float *__restrict__ origins,
-                                     float *__restrict__ dirs, float *__restrict__ area) {
+// NS camera_utils.radial_and_tangential_undistort: 10 Newton steps on the OPENCV model (k1..k4, p1, p2), started at the
+// distorted point; a step is skipped where the Jacobian determinant is below eps = 1e-3.
+struct Distortion {
+    float k1, k2, k3, k4, p1, p2;
+    int on;
+};
+__device__ __forceinline__ void undistort(const Distortion &k, float xd, float yd, float &xo, float &yo) {
+    float x = xd, y = yd;
+#pragma unroll 1
+    for (int it = 0; it < 10; ++it) {
+        const float r = x * x + y * y;
+        const float d = 1.0f + r * (k.k1 + r * (k.k2 + r * (k.k3 + r * k.k4)));
+        const float fx = d * x + 2.0f * k.p1 * x * y + k.p2 * (r + 2.0f * x * x) - xd;
+        const float fy = d * y + 2.0f * k.p2 * x * y + k.p1 * (r + 2.0f * y * y) - yd;
+        const float d_r = k.k1 + r * (2.0f * k.k2 + r * (3.0f * k.k3 + r * 4.0f * k.k4));
+        const float d_x = 2.0f * x * d_r, d_y = 2.0f * y * d_r;
+        const float fx_x = d + d_x * x + 2.0f * k.p1 * y + 6.0f * k.p2 * x;
+        const float fx_y = d_y * x + 2.0f * k.p1 * x + 2.0f * k.p2 * y;
+        const float fy_x = d_x * y + 2.0f * k.p2 * y + 2.0f * k.p1 * x;
+        const float fy_y = d + d_y * y + 2.0f * k.p2 * x + 6.0f * k.p1 * y;
+        const float den = fy_x * fx_y - fx_x * fy_y;
+        const bool ok = fabsf(den) > 1e-3f;
+        x += ok ? (fx * fy_y - fy * fx_y) / den : 0.0f;
+        y += ok ? (fy * fx_x - fx * fy_x) / den : 0.0f;
+    }
+    xo = x;
+    yo = y;
+}
+
+__global__ void generate_rays_kernel(CamArgs c, Distortion k, long long first, long long count,
+                                     float *__restrict__ origins, float *__restrict__ dirs, float *__restrict__ area) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const long long p = first + i;
     const float px = (float)(p % c.W) + 0.5f, py = (float)(p / c.W) + 0.5f;
-    const float u = sub_rn(px, c.cx) / c.fx, v = -(sub_rn(py, c.cy) / c.fy);
-    const float ux = add_rn(sub_rn(px, c.cx), 1.0f) / c.fx;  // (x - cx + 1) / fx, torch's left-to-right order
-    const float vy = -(add_rn(sub_rn(py, c.cy), 1.0f) / c.fy);
+    float u = sub_rn(px, c.cx) / c.fx, v = -(sub_rn(py, c.cy) / c.fy);
+    float ux = add_rn(sub_rn(px, c.cx), 1.0f) / c.fx;  // (x - cx + 1) / fx, torch's left-to-right order
+    float vy = -(add_rn(sub_rn(py, c.cy), 1.0f) / c.fy);
     float d0, d1, d2, a0, a1, a2, b0, b1, b2;
-    cam_dir(c, u, v, d0, d1, d2);
-    cam_dir(c, ux, v, a0, a1, a2);
-    cam_dir(c, u, vy, b0, b1, b2);
+    if (k.on) {  // each of the three coordinate pairs is undistorted on its own, in NS's y-flipped frame
+        float ax, ay, bx, by;
+        undistort(k, ux, v, ax, ay);
+        undistort(k, u, vy, bx, by);
+        undistort(k, u, v, u, v);
+        cam_dir(c, u, v, d0, d1, d2);
+        cam_dir(c, ax, ay, a0, a1, a2);
+        cam_dir(c, bx, by, b0, b1, b2);
+    } else {
+        cam_dir(c, u, v, d0, d1, d2);
+        cam_dir(c, ux, v, a0, a1, a2);
+        cam_dir(c, u, vy, b0, b1, b2);
+    }
     origins[i * 3 + 0] = c.c2w[3];
     origins[i * 3 + 1] = c.c2w[7];
     origins[i * 3 + 2] = c.c2w[11];
@@ -294,8 +333,8 @@ inline unsigned blocks_for(long long items, int per_block) { return (unsigned)((
 extern "C" {
 
 int tn_generate_rays(const float *c2w_host, float fx, float fy, float cx, float cy, int32_t height, int32_t width,
-                     int64_t first_pixel, int64_t num_pixels, float *origins, float *directions, float *pixel_area,
-                     void *stream) {
+                     const float *distortion_host, int64_t first_pixel, int64_t num_pixels, float *origins,
+                     float *directions, float *pixel_area, void *stream) {
     if (num_pixels == 0) return TN_OK;
     if (!c2w_host || !origins || !directions) return TN_ERR_NULL;
     if (height < 1 || width < 1 || first_pixel < 0 || num_pixels < 0 ||
@@ -304,7 +343,13 @@ int tn_generate_rays(const float *c2w_host, float fx, float fy, float cx, float 
     CamArgs c;
     for (int i = 0; i < 12; ++i) c.c2w[i] = c2w_host[i];
     c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.H = height; c.W = width;
-    hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for(num_pixels, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, c,
+    Distortion k = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0};
+    if (distortion_host) {
+        k.k1 = distortion_host[0]; k.k2 = distortion_host[1]; k.k3 = distortion_host[2];
+        k.k4 = distortion_host[3]; k.p1 = distortion_host[4]; k.p2 = distortion_host[5];
+        for (int i = 0; i < 6; ++i) k.on |= distortion_host[i] != 0.0f;  // NS skips cameras whose parameters are all zero
+    }
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(blocks_for(num_pixels, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, c, k,
                        (long long)first_pixel, (long long)num_pixels, origins, directions, pixel_area);
     TN_LAUNCH_CHECK();
     return TN_OK;

@@ -3,8 +3,8 @@ per-frame ``thermal_file_path`` -> image / thermal file lists, cameras, scene bo
 
 Restates the ``Nerfstudio`` dataparser pieces the reference inherits (``_get_fname`` with its ``images_<k>`` /
 ``thermal_<k>`` downscale folders, the filename split ``frame_train_* / frame_eval_*`` [REF thermo_scenes/docs/
-Collect_new_dataset.md:105-130], auto orient / centre / scale).  Limits, raised explicitly: perspective cameras with one
-shared principal point and image size, zero lens distortion (``tn_generate_rays`` has no undistortion)."""
+Collect_new_dataset.md:105-130], auto orient / centre / scale).  Limits, raised explicitly: perspective (OPENCV / pinhole)
+cameras with one shared principal point and image size."""
 from __future__ import annotations
 
 import json
@@ -106,14 +106,13 @@ class Thermal:
         else:
             meta, data_dir = json.loads((data / "transforms.json").read_text()), data
 
-        for k in ("k1", "k2", "k3", "k4", "p1", "p2"):
-            vals = [float(meta[k])] if k in meta else [float(f[k]) for f in meta["frames"] if k in f]
-            if any(v != 0.0 for v in vals):
-                raise NotImplementedError(f"lens distortion ({k} != 0) is not supported: undistort the images first")
         if meta.get("camera_model", "OPENCV") not in ("OPENCV", "PINHOLE", "SIMPLE_PINHOLE"):
             raise NotImplementedError(f"camera_model {meta['camera_model']}: only perspective cameras")
 
         frames = sorted(meta["frames"], key=lambda f: str(self._get_fname(Path(f["file_path"]), data_dir)))  # REF :100-107
+        dist_keys = ("k1", "k2", "k3", "k4", "p1", "p2")  # NS camera_utils.get_distortion_params order
+        distort_fixed = any(k in meta for k in ("k1", "k2", "k3", "p1", "p2"))  # REF :89-93
+        distort: List[List[float]] = []
         image_filenames, thermal_filenames, poses = [], [], []
         intr = {k: [] for k in ("fl_x", "fl_y", "cx", "cy", "h", "w")}
         for frame in frames:
@@ -123,6 +122,8 @@ class Thermal:
                 if k not in meta:
                     assert k in frame, f"{k} not specified in frame"  # REF :113-130
                     intr[k].append(float(frame[k]))
+            if not distort_fixed:  # REF :131-141
+                distort.append([float(frame[k]) if k in frame else 0.0 for k in dist_keys])
             if "thermal_file_path" in frame:  # REF :146-153
                 thermal_filenames.append(self._get_fname(Path(frame["thermal_file_path"]), data_dir,
                                                          downsample_folder_prefix="thermal_"))
@@ -179,8 +180,12 @@ class Thermal:
         n = len(indices)
         fx = torch.full((n,), float(meta["fl_x"])) if "fl_x" in meta else torch.tensor(intr["fl_x"], dtype=torch.float32)[idx]
         fy = torch.full((n,), float(meta["fl_y"])) if "fl_y" in meta else torch.tensor(intr["fl_y"], dtype=torch.float32)[idx]
+        if distort_fixed:  # REF :287-296
+            distortion = torch.tensor([float(meta[k]) if k in meta else 0.0 for k in dist_keys]).expand(n, 6).contiguous()
+        else:
+            distortion = torch.tensor(distort, dtype=torch.float32).reshape(-1, 6)[idx]
         cameras = Cameras(camera_to_worlds=poses_t[:, :3, :4].contiguous(), fx=fx, fy=fy, cx=shared("cx"), cy=shared("cy"),
-                          height=int(shared("h")), width=int(shared("w")))
+                          height=int(shared("h")), width=int(shared("w")), distortion_params=distortion)
         cameras.rescale_output_resolution(1.0 / self.downscale_factor)  # REF :305-306
 
         if "applied_transform" in meta:  # REF :308-319
