@@ -121,7 +121,6 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
                 if (take[k]) v[e] += u;
             }
         }
-        if (!tail) continue;
         const unsigned cx = (unsigned)cxi, cy = (unsigned)cyi, cz = (unsigned)czi;
         const unsigned fx = (unsigned)fxi, fy = (unsigned)fyi, fz = (unsigned)fzi;
         const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
@@ -129,10 +128,20 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
         const unsigned m = g.mask;
         const unsigned idx[8] = {(cx ^ hcy ^ hcz) & m, (cx ^ hfy ^ hcz) & m, (fx ^ hfy ^ hcz) & m, (fx ^ hcy ^ hcz) & m,
                                  (cx ^ hcy ^ hfz) & m, (cx ^ hfy ^ hfz) & m, (fx ^ hfy ^ hfz) & m, (fx ^ hcy ^ hfz) & m};
+        // issue with the two features of an entry on NEIGHBOURING lanes (one 8-byte segment per lane pair): lane L adds
+        // feature (L & 1) of sample (L >> 1) of each half-wave, so an instruction touches 32 segments instead of 64 lines
+        const int feat = lane & 1, tl = tail ? 1 : 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (v[2 * c] != 0.0f) atomic_add_f32(tb + (size_t)idx[c] * 2, v[2 * c]);
-            if (v[2 * c + 1] != 0.0f) atomic_add_f32(tb + (size_t)idx[c] * 2 + 1, v[2 * c + 1]);
+        for (int half = 0; half < 2; ++half) {
+            const int src = half * 32 + (lane >> 1);
+            const int st = __shfl(tl, src, 64);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float v0 = __shfl(v[2 * c], src, 64), v1 = __shfl(v[2 * c + 1], src, 64);
+                const unsigned id = (unsigned)__shfl((int)idx[c], src, 64);
+                const float val = feat ? v1 : v0;
+                if (st && val != 0.0f) atomic_add_f32(tb + (size_t)id * 2 + feat, val);
+            }
         }
     }
 }
