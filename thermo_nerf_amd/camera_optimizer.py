@@ -49,7 +49,9 @@ class CameraOptimizer(nn.Module):
         if self.config.mode == "off":
             eye = torch.eye(4, device=indices.device)[None, :3, :4]
             return eye.repeat(indices.shape[0], 1, 1)
-        return _so3xr3_exp(self.pose_adjustment[indices, :])
+        # exponentiate once per CAMERA, then gather per ray (index_select: its backward is an index_add, not the
+        # serial indexing_backward kernel of advanced indexing)
+        return _so3xr3_exp(self.pose_adjustment).index_select(0, indices)
 
     def apply_to_raybundle(self, raybundle: RayBundle) -> None:
         if self.config.mode == "off":

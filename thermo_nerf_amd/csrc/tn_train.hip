@@ -246,7 +246,7 @@ frustum_positions_bwd_kernel(const float *__restrict__ d_pos, const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Linear layers.  A block owns tiles of 64 rows (samples); 256 threads = 64 rows x 4 column groups.
+// Linear layers.  Backward: a block owns tiles of 64 rows (samples); 256 threads = 64 rows x 4 column groups.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == TN_ACT_RELU) return fmaxf(v, 0.0f);
@@ -262,49 +262,6 @@ __device__ __forceinline__ float act_bwd(float y, int act) {  // derivative expr
 constexpr int TILE = 64;
 constexpr int kLinBwdBlocks = 768;  // persistent blocks of tn_linear_bwd (3 per CU fit the 49 KB of LDS each)
 constexpr int LDP = 65;  // padded row length of the row tiles in LDS (odd: conflict-free column walks)
-
-// NO = outputs per thread (OUT <= 4 * NO)
-template <int NO>
-__global__ void __launch_bounds__(kBlock)
-linear_fwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ W, const float *__restrict__ b,
-                  int IN, int OUT, int act, long long n, float *__restrict__ y, int ldy) {
-    constexpr int OUTP = 4 * NO;
-    __shared__ __attribute__((aligned(16))) float Wt[64 * OUTP];  // [i][o]
-    __shared__ float bs[OUTP];
-    __shared__ float xs[TILE * LDP];
-    for (int e = threadIdx.x; e < IN * OUTP; e += kBlock) {
-        const int i = e / OUTP, o = e - i * OUTP;
-        Wt[e] = o < OUT ? W[o * IN + i] : 0.0f;
-    }
-    if (threadIdx.x < OUTP) bs[threadIdx.x] = (threadIdx.x < OUT && b) ? b[threadIdx.x] : 0.0f;
-    const int s = threadIdx.x & 63, og = threadIdx.x >> 6;
-    const long long tiles = (n + TILE - 1) / TILE;
-    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const long long base = tile * TILE;
-        __syncthreads();
-        for (int e = threadIdx.x; e < TILE * IN; e += kBlock) {
-            const int r = e / IN, i = e - r * IN;
-            xs[r * LDP + i] = base + r < n ? x[(base + r) * ldx + i] : 0.0f;
-        }
-        __syncthreads();
-        float acc[NO];
-#pragma unroll
-        for (int k = 0; k < NO; ++k) acc[k] = bs[og * NO + k];
-        for (int i = 0; i < IN; ++i) {
-            const float xv = xs[s * LDP + i];
-            const float *wr = Wt + i * OUTP + og * NO;
-#pragma unroll
-            for (int k = 0; k < NO; ++k) acc[k] = fmaf(wr[k], xv, acc[k]);
-        }
-        if (base + s < n) {
-#pragma unroll
-            for (int k = 0; k < NO; ++k) {
-                const int o = og * NO + k;
-                if (o < OUT) y[(base + s) * ldy + o] = act_fwd(acc[k], act);
-            }
-        }
-    }
-}
 
 // NI = inputs per thread (IN <= 4 * NI)
 template <int NI>
@@ -423,6 +380,78 @@ linear_bwd_reduce_kernel(const float *__restrict__ partials, int blocks, int INP
             if (db) atomic_add_f32(db + o, tot);
         } else if (i < IN && dW) {
             atomic_add_f32(dW + o * IN + i, tot);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Linear forward, lane = row.  A wave-uniform operand costs nothing when it comes through the SCALAR cache (s_load +
+// v_pk_fma with SGPR sources), while the same value broadcast from LDS costs LDS->VGPR bandwidth for all 64 lanes (what
+// bounds the tiled kernel above): the row's inputs sit in VGPRs, W[o][:] is read as scalars, no LDS, no barriers:
+// 96 -> 50 us per 64x64 layer over 196 k rows.  (The same idea for dx — 64x64 fully unrolled, instruction-cache bound —
+// and for dW — x rows streamed through the scalar cache — measured 2-3x SLOWER than the tiled backward kernel: kept out.)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int INP>
+__global__ void __launch_bounds__(kBlock)
+linear_fwd_rows_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ W, const float *__restrict__ b, int IN,
+                       int OUT, int act, long long n, float *__restrict__ y, int ldy, int vec_in, int vec_out) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long base = (long long)blockIdx.x * kBlock; base < n; base += stride) {
+        const long long row = base + threadIdx.x;
+        const bool live = row < n;
+        const float *xp = x + (live ? row : n - 1) * ldx;
+        float xr[INP];
+        if (vec_in) {
+#pragma unroll
+            for (int i = 0; i < INP; i += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(xp + i);
+                xr[i] = v.x; xr[i + 1] = v.y; xr[i + 2] = v.z; xr[i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < INP; ++i) xr[i] = i < IN ? xp[i] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < INP; ++i)
+            if (i >= IN) xr[i] = 0.0f;
+        float *yp = y + row * ldy;
+        for (int o0 = 0; o0 < OUT; o0 += 4) {
+            const int oa = o0, ob = min(o0 + 1, OUT - 1), oc = min(o0 + 2, OUT - 1), od = min(o0 + 3, OUT - 1);
+            const float *wa = W + oa * IN, *wb = W + ob * IN, *wc = W + oc * IN, *wd = W + od * IN;
+            float a0 = b ? b[oa] : 0.0f, a1 = b ? b[ob] : 0.0f, a2 = b ? b[oc] : 0.0f, a3 = b ? b[od] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < INP; c += 4) {
+                if (c + 3 < IN) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a0 = fmaf(xr[c + k], wa[c + k], a0);
+                        a1 = fmaf(xr[c + k], wb[c + k], a1);
+                        a2 = fmaf(xr[c + k], wc[c + k], a2);
+                        a3 = fmaf(xr[c + k], wd[c + k], a3);
+                    }
+                } else if (c < IN) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = min(c + k, IN - 1);  // xr is zero beyond IN: the clamped weight is multiplied by 0
+                        a0 = fmaf(xr[c + k], wa[i], a0);
+                        a1 = fmaf(xr[c + k], wb[i], a1);
+                        a2 = fmaf(xr[c + k], wc[i], a2);
+                        a3 = fmaf(xr[c + k], wd[i], a3);
+                    }
+                }
+            }
+            if (live) {
+                if (vec_out) {
+                    *reinterpret_cast<float4 *>(yp + o0) = make_float4(act_fwd(a0, act), act_fwd(a1, act), act_fwd(a2, act), act_fwd(a3, act));
+                } else {
+                    yp[o0] = act_fwd(a0, act);
+                    if (o0 + 1 < OUT) yp[o0 + 1] = act_fwd(a1, act);
+                    if (o0 + 2 < OUT) yp[o0 + 2] = act_fwd(a2, act);
+                    if (o0 + 3 < OUT) yp[o0 + 3] = act_fwd(a3, act);
+                }
+            }
         }
     }
 }
@@ -809,14 +838,20 @@ int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act
     if (act < TN_ACT_NONE || act > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
     if (n == 0) return TN_OK;
     if (!x || !y) return TN_ERR_NULL;
-    const dim3 g(grid_for((n + TILE - 1) / TILE, 1, 4096)), b(kBlock);
     hipStream_t st = (hipStream_t)stream;
-    if (OUT <= 4)
-        hipLaunchKernelGGL(linear_fwd_kernel<1>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy);
-    else if (OUT <= 16)
-        hipLaunchKernelGGL(linear_fwd_kernel<4>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy);
+    const int INP = IN <= 16 ? 16 : IN <= 32 ? 32 : 64;
+    const int vec_in = (ldx % 4 == 0) && (ldx >= INP) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    const int vec_out = (ldy % 4 == 0) && (OUT % 4 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+    const dim3 g(grid_for(n, kBlock, 1 << 16)), b(kBlock);
+    if (INP == 16)
+        hipLaunchKernelGGL(linear_fwd_rows_kernel<16>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y,
+                           ldy, vec_in, vec_out);
+    else if (INP == 32)
+        hipLaunchKernelGGL(linear_fwd_rows_kernel<32>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y,
+                           ldy, vec_in, vec_out);
     else
-        hipLaunchKernelGGL(linear_fwd_kernel<16>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy);
+        hipLaunchKernelGGL(linear_fwd_rows_kernel<64>, g, b, 0, st, x, ldx, lin->weight, lin->bias, IN, OUT, act, (long long)n, y,
+                           ldy, vec_in, vec_out);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -854,8 +889,8 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
                            lddx, accumulate_dx, d_weight, d_bias, partials);
     TN_LAUNCH_CHECK();
     if (partials) {
-        hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(INP + 1, kRedSplit), dim3(kBlock), 0, st, partials, blocks, INP, IN, OUT, d_weight,
-                           d_bias);
+        hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(INP + 1, kRedSplit), dim3(kBlock), 0, st, partials, blocks, INP, IN, OUT,
+                           d_weight, d_bias);
         TN_LAUNCH_CHECK();
     }
     return TN_OK;
