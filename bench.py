@@ -198,18 +198,22 @@ def main():
     n_rays = o.shape[0]
     engine = RayRenderEngine(model, chunk=args.chunk)
     out = engine.allocate_outputs(n_rays, dev)
-    packed = torch.empty((n_rays, 9), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * n_rays, 9), dtype=torch.float32, device=dev) if world > 1 else None
+    pipe = None
+    if world > 1:
+        from thermo_nerf_amd.distributed import PipelinedFrameGather
+
+        pipe = PipelinedFrameGather(n_rays, world, dev)
 
     def step(record: bool):
         engine.render(o, d, out=out, record_events=record)
-        if world > 1:
-            # the exchange step of the path: rendered pixels (9 floats = 36 B per ray) gathered over RCCL/xGMI
-            torch.cat([out[k] for k in OUTPUT_KEYS], dim=1, out=packed)
-            dist.all_gather_into_tensor(gathered, packed)
+        if pipe is not None:
+            # the exchange step of the path: rendered pixels (9 floats = 36 B per ray) all-gathered over RCCL/xGMI,
+            # asynchronously: the next frame renders while this one is on the links (double-buffered)
+            pipe.submit(out)
 
     def barrier():
-        if world > 1:
+        if pipe is not None:
+            pipe.finish()  # every gather of the timed region completes inside it
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -71,3 +71,43 @@ def test_pack_unpack_roundtrip():
     assert D.pack_outputs(out).shape == (16, 9)
     for k in D.OUTPUT_KEYS:
         assert torch.equal(back[k], out[k])
+
+
+def _pipeline_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 50
+        pipe = D.PipelinedFrameGather(n, world, "cpu")
+        ok, slots = True, []
+        for frame in range(5):  # more frames than buffers: slots are recycled only after their collective finished
+            o = torch.full((n, 3), float(frame)) + rank
+            d = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3) / 100.0
+            slots.append((pipe.submit(fake_render(o, d)), frame))
+        pipe.finish()
+        for k, frame in slots[-2:]:  # the two frames still resident
+            got = pipe.frames(k, world)
+            for r in range(world):
+                o = torch.full((n, 3), float(frame)) + r
+                d = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3) / 100.0
+                ok = ok and torch.equal(got[r], D.pack_outputs(fake_render(o, d)))
+        q.put((rank, ok, [k for k, _ in slots]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_frame_gather_double_buffering():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, slots in res:
+        assert ok, f"rank {rank}: gathered frames differ"
+        assert slots == [0, 1, 0, 1, 0]
