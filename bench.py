@@ -113,7 +113,7 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
     model.to(dev).train()
     groups = model.get_param_groups()
     opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]},
-                            {"params": groups["camera_opt"], "lr": 6e-4}], lr=1e-2, eps=1e-15)
+                            {"params": groups["camera_opt"], "lr": 6e-4}], lr=1e-2, eps=1e-15, fused=True)
     g = torch.Generator().manual_seed(0)
     side = int(rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)

@@ -476,3 +476,29 @@ def test_thermoscenes_style_tree_to_training_steps(tmp_path):
     assert model.camera_optimizer.pose_adjustment.grad is not None
     with pytest.raises(ValueError, match="Thermal images not found"):
         ThermalNerfModel(cfg, metadata={}, scene_box=train_out.scene_box, num_train_data=8)  # REF thermal_nerf_model.py:75-76
+
+
+def test_eval_follows_fused_optimizer_updates():
+    """torch.optim.Adam(fused=True) changes parameters without bumping their version counters; the prepared MFMA blobs
+    must still be rebuilt before the next eval render."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48)
+    rb = RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=torch.zeros_like(cam).to(DEV))
+    gm.eval()
+    with torch.no_grad():
+        before = gm(rb)["rgb"].clone()
+    gm.train()
+    opt = torch.optim.Adam(gm.get_param_groups()["fields"], lr=5e-2, eps=1e-15, fused=True)
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    for step in range(3):
+        out = gm(RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV)))
+        loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    gm.eval()
+    with torch.no_grad():
+        after = gm(rb)
+    want = H.get_outputs({k: v.detach().cpu() for k, v in gm.state_dict().items()}, o, d, None, ocfg)
+    assert (after["rgb"] - before).abs().max().item() > 1e-2, "the render did not move: stale prepared weights"
+    assert (after["rgb"].cpu() - want["rgb"]).abs().max().item() <= 2e-3
+    assert (after["thermal"].cpu() - want["thermal"]).abs().max().item() <= 2e-3

@@ -155,6 +155,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
                    and not self.config.use_gradient_scaling)
         if self.training and torch.is_grad_enabled():
             from ..training import get_outputs_train  # taped forward: the outputs carry the HIP backward
+            self.invalidate_prepared()
             return get_outputs_train(self, ray_bundle)
         if fusable:
             return self._get_outputs_fused(ray_bundle)
@@ -224,6 +225,16 @@ class ThermalNerfModel(ThermalNerfactoModel):
             outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
         outputs[RenderedImageModality.THERMAL.value] = self.thermal_renderer(field_outputs[FieldHeadNamesT.THERMAL], weights)
         return outputs
+
+    def invalidate_prepared(self) -> None:
+        """Drop every derived copy of the weights (MFMA blobs, dense re-layouts, cached C structs).  The caches key on
+        parameter versions, but fused multi-tensor optimizers (torch.optim.Adam(fused=True)) update parameters without
+        bumping them — so every training forward, after which weights are about to change, calls this."""
+        self._struct_key = None
+        self.field._prepared_key = None
+        for mod in self.modules():
+            if hasattr(mod, "_dense_key"):
+                mod._dense_key = None
 
     # --- fused: one C-ABI call ------------------------------------------------------------------------
     def _c_structs(self):

@@ -111,7 +111,8 @@ class Trainer:
             oc = self.config.optimizers.get(name)
             if oc is None:
                 raise KeyError(f"no optimizer configured for parameter group '{name}'")
-            opt = torch.optim.Adam(params, lr=oc.lr, eps=oc.eps, weight_decay=oc.weight_decay)
+            fused = all(p.is_cuda for p in params)  # one multi-tensor kernel per group instead of ~10 elementwise passes
+            opt = torch.optim.Adam(params, lr=oc.lr, eps=oc.eps, weight_decay=oc.weight_decay, fused=fused)
             self.optimizers[name] = opt
             self.schedulers[name] = torch.optim.lr_scheduler.LambdaLR(opt, lambda s, oc=oc: exponential_decay_multiplier(oc, s))
         self.generator = torch.Generator(device=dataset.origins.device)

@@ -33,7 +33,7 @@ def main():
     pg = [{"params": groups["fields"]}, {"params": groups["proposal_networks"]}]
     if "camera_opt" in groups:
         pg.append({"params": groups["camera_opt"], "lr": 6e-4})
-    opt = torch.optim.Adam(pg, lr=1e-2, eps=1e-15)
+    opt = torch.optim.Adam(pg, lr=1e-2, eps=1e-15, fused=True)
     g = torch.Generator().manual_seed(0)
     side = int(a.rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
