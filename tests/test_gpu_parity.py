@@ -455,3 +455,21 @@ def test_checkpoint_load_invalidates_prepared_weights(tmp_path, precision):
         got = gm(bundle(o, d))
     assert not torch.equal(before, got["rgb"])
     check_outputs(got, H.get_outputs(sd_new, o, d, None, ocfg), f"after checkpoint load ({precision})")
+
+
+def test_engine_chunks_on_two_streams_match_one_stream():
+    """RayRenderEngine alternates chunks between two HIP streams (own workspace each); results must not depend on it."""
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    gm, sd, ocfg = gpu_model("scene", 64)
+    o, d = helpers.rays(60, 50, view=1)
+    o, d = o.to(DEV), d.to(DEV)
+    one = RayRenderEngine(gm, chunk=700, streams=1).render(o, d)
+    two = RayRenderEngine(gm, chunk=700, streams=2)
+    a = two.render(o, d)
+    b = two.render(o, d)  # second call reuses streams / workspaces
+    torch.cuda.synchronize()
+    for k in one:
+        assert torch.equal(one[k], a[k]) and torch.equal(one[k], b[k]), k
+    want = H.get_outputs(sd, o[:700].cpu(), d[:700].cpu(), None, ocfg)  # first chunk = one oracle call
+    assert (a["rgb"][:700].cpu() - want["rgb"]).abs().max().item() <= 2e-5

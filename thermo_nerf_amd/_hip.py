@@ -254,12 +254,28 @@ def make_linear(layer: torch.nn.Linear) -> tn_linear:
     return tn_linear(w.data_ptr(), b.data_ptr(), layer.in_features, layer.out_features)
 
 
+_HOST_COPIES: dict = {}
+
+
+def host_values(t: torch.Tensor) -> tuple:
+    """Flat host copy of a small constant device buffer (scalings, aabb), cached per (storage, version): reading it back
+    on every call would be a synchronising device-to-host copy in the middle of the launch stream."""
+    key = (t.data_ptr(), t._version, t.numel(), str(t.device))
+    v = _HOST_COPIES.get(key)
+    if v is None:
+        if len(_HOST_COPIES) > 256:
+            _HOST_COPIES.clear()
+        v = tuple(t.detach().float().reshape(-1).cpu().tolist())
+        _HOST_COPIES[key] = v
+    return v
+
+
 def make_space(contraction: bool, aabb: Optional[torch.Tensor]) -> tn_space:
     s = tn_space()
     s.contraction = 1 if contraction else 0
     if aabb is not None:
-        a = aabb.detach().float().cpu()
+        a = host_values(aabb)
         for i in range(3):
-            s.aabb_min[i] = float(a[0, i])
-            s.aabb_max[i] = float(a[1, i])
+            s.aabb_min[i] = a[i]
+            s.aabb_max[i] = a[3 + i]
     return s

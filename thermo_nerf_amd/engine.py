@@ -21,7 +21,7 @@ OUTPUT_KEYS = ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0",
 
 
 class RayRenderEngine:
-    def __init__(self, model: ThermalNerfModel, chunk: Optional[int] = None) -> None:
+    def __init__(self, model: ThermalNerfModel, chunk: Optional[int] = None, streams: int = 2) -> None:
         if model.training:
             raise RuntimeError("RayRenderEngine renders in eval mode; call model.eval() first")
         self.model = model
@@ -36,14 +36,20 @@ class RayRenderEngine:
         self.rc.training = 0
         self.rc.pdf_anneal = float(model.proposal_sampler._anneal)
         self.rc.early_stop_transmittance = float(cfg.early_termination_eps)
+        # a chunk of 65 536 rays is 1024 waves — one per SIMD, half of what the field kernel needs to hide its gathers —
+        # so consecutive chunks go to alternating HIP streams (own workspace each) and overlap on the device
+        self.num_streams = max(1, int(streams))
+        self._streams: List[torch.cuda.Stream] = []
         self._ws: Optional[Tensor] = None
         self._nf: Optional[Tuple[Tensor, Tensor]] = None
         self.timings: List[Tuple[torch.cuda.Event, torch.cuda.Event, torch.cuda.Event]] = []
 
     def _buffers(self, dev) -> None:
         need = self.lib.tn_render_workspace_bytes(self.rc, self.chunk)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        need = (need + 255) // 256 * 256
+        if self._ws is None or self._ws.shape[1] < need or self._ws.device != dev:
+            self._ws = torch.empty((self.num_streams, need), dtype=torch.uint8, device=dev)
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.num_streams)]
         if self._nf is None or self._nf[0].device != dev:
             # NS NearFarCollider in eval: near plane reset to 0
             col = self.model.collider
@@ -76,25 +82,36 @@ class RayRenderEngine:
         ins.u1 = pdf_positions(self.P1 + 1, dev, False).data_ptr()
         ins.u2 = pdf_positions(self.S + 1, dev, False).data_ptr()
         outs = _hip.tn_render_outputs()
-        stream = _hip.current_stream()
-        ws, wsn = self._ws.data_ptr(), self._ws.numel()
-        for i in range(0, n, self.chunk):
+        wsn = self._ws.shape[1]
+        multi = self.num_streams > 1 and n > self.chunk
+        current = torch.cuda.current_stream(dev)
+        if multi:
+            for st in self._streams:
+                st.wait_stream(current)  # inputs (and the prepared weights) were produced on the caller's stream
+        for ci, i in enumerate(range(0, n, self.chunk)):
             r = min(self.chunk, n - i)
+            slot = ci % self.num_streams if multi else 0
+            st = self._streams[slot] if multi else current
+            stream = st.cuda_stream
+            ws = self._ws[slot].data_ptr()
             ins.origins, ins.directions = o.data_ptr() + 12 * i, d.data_ptr() + 12 * i
             outs.rgb = out["rgb"].data_ptr() + 12 * i
             for k in OUTPUT_KEYS[1:]:
                 setattr(outs, k, out[k].data_ptr() + 4 * i)
             if record_events:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record()
+                e0.record(st)
             _hip.check(self.lib.tn_proposal_sample_fwd(prop0, prop1, self.rc, ins, outs, r, ws, wsn, stream),
                        "tn_proposal_sample_fwd")
             if record_events:
-                e1.record()
+                e1.record(st)
             _hip.check(self.lib.tn_field_render_fwd(fld, self.rc, ins, outs, r, ws, wsn, stream), "tn_field_render_fwd")
             if record_events:
-                e2.record()
+                e2.record(st)
                 self.timings.append((e0, e1, e2))
+        if multi:
+            for st in self._streams:
+                current.wait_stream(st)
         return out
 
     def drain_timings(self) -> Tuple[List[float], List[float]]:

@@ -64,9 +64,9 @@ class HashEncoding(nn.Module):
         table = _hip.require_device_tensor(self.hash_table.detach(), "hash_table")
         g = _hip.tn_hashgrid()
         g.table = table.data_ptr()
-        sc = self.scalings.detach().float().cpu()
+        sc = _hip.host_values(self.scalings)  # cached: no device read-back per call
         for i in range(self.num_levels):
-            g.scalings[i] = float(sc[i])
+            g.scalings[i] = sc[i]
         g.num_levels = self.num_levels
         g.log2_hashmap_size = self.log2_hashmap_size
         g.dense = None

@@ -12,6 +12,7 @@ Two execution forms of ``get_outputs`` (both HIP only, no PyTorch arithmetic on 
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Type
 
@@ -30,6 +31,9 @@ from ..scene import NearFarCollider, SceneBox, SceneContraction
 from .thermal_field import ThermalNerfactoTField
 from .thermal_field_head import FieldHeadNamesT
 from .thermal_renderer import ThermalRenderer
+
+
+_ENGINES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
 @dataclass
@@ -150,9 +154,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
             self.camera_optimizer.apply_to_raybundle(ray_bundle)  # REF :218-219
         if ray_bundle.nears is None or ray_bundle.fars is None:
             raise ValueError("ray_bundle.nears/fars are unset: call the model (forward applies the collider)")
-        fusable = (self.config.fused and self.config.num_proposal_iterations == 2
-                   and not self.config.use_same_proposal_network and not self.config.predict_normals
-                   and not self.config.use_gradient_scaling)
+        fusable = self._fusable()
         if self.training and torch.is_grad_enabled():
             from ..training import get_outputs_train  # taped forward: the outputs carry the HIP backward
             self.invalidate_prepared()
@@ -160,6 +162,32 @@ class ThermalNerfModel(ThermalNerfactoModel):
         if fusable:
             return self._get_outputs_fused(ray_bundle)
         return self._get_outputs_modular(ray_bundle)
+
+    def _fusable(self) -> bool:
+        cfg = self.config
+        return (cfg.fused and cfg.num_proposal_iterations == 2 and not cfg.use_same_proposal_network
+                and not cfg.predict_normals and not cfg.use_gradient_scaling)
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """NS Model.get_outputs_for_camera_ray_bundle [REF render/renderer.py:182-187 calls it per camera].  In eval mode
+        with the fused kernels the chunks (``eval_num_rays_per_chunk`` rays each, expected depth clipped per chunk exactly
+        like the reference's per-chunk forward) are written straight into the [H*W,C] outputs by ``RayRenderEngine`` on two
+        alternating HIP streams; otherwise the generic per-chunk loop runs."""
+        if self.training or not self._fusable():
+            return super().get_outputs_for_camera_ray_bundle(camera_ray_bundle)
+        from ..engine import RayRenderEngine
+
+        chunk = int(self.config.eval_num_rays_per_chunk)
+        eng = _ENGINES.get(self)  # side table: streams / ctypes structs must not ride along in deepcopy / state_dict
+        if eng is None or eng.chunk != chunk or eng.rc.early_stop_transmittance != float(self.config.early_termination_eps):
+            eng = _ENGINES[self] = RayRenderEngine(self, chunk=chunk)
+        h, w = camera_ray_bundle.origins.shape[:2]
+        o = camera_ray_bundle.origins.reshape(-1, 3).to(self.device)
+        d = camera_ray_bundle.directions.reshape(-1, 3).to(self.device)
+        eng.rc.pdf_anneal = float(self.proposal_sampler._anneal)
+        out = eng.render(o, d)
+        return {k: v.view(h, w, -1) for k, v in out.items()}
 
     # ------------------------------------------------------------------------------------------------
     def get_metrics_dict(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
