@@ -353,6 +353,148 @@ linear_bwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict_
     }
 }
 
+// The same backward on the matrix pipe (v_mfma_f32_32x32x2_f32; fp32 MFMA runs at the packed-VALU rate, but its operands
+// come from two conflict-free ds_read_b32 per 2048 MACs instead of one broadcast LDS read per 4 FMAs, which is what binds the
+// VALU form above).  Per 64-row tile, 4 waves = 4 output tiles of 32x32:
+//   dx^T[i][n] = sum_o W[o][i] g[n][o]     A = W^T (rows i, k = o)      B = g^T (k = o, cols n)     K = OUT
+//   dW  [o][i] = sum_n g[n][o] x[n][i]     A = g^T (rows o, k = n)      B = x   (k = n, cols i)     K = 64 rows
+// dx^T is transposed back through LDS for coalesced stores; dW accumulates in registers across the block's tiles.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ void __launch_bounds__(kBlock)
+linear_bwd_mfma_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ y, const float *__restrict__ dy, int ldy,
+                       const float *__restrict__ W, int IN, int OUT, int act, long long n, float *__restrict__ dx, int lddx,
+                       int accumulate_dx, int want_w, float *__restrict__ partials, int vec, int vec_dx) {
+    __shared__ float Ws[64 * LDP];  // [o][i], zero padded to 64 x 64
+    __shared__ float gs[TILE * LDP];  // [row][o]
+    __shared__ float xs[TILE * LDP];  // [row][i]; reused as dx staging [row][i]
+    for (int e = threadIdx.x; e < 64 * 64; e += kBlock) {
+        const int o = e >> 6, i = e & 63;
+        Ws[o * LDP + i] = (o < OUT && i < IN) ? W[o * IN + i] : 0.0f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    const int n_it = (IN + 31) >> 5, n_ot = (OUT + 31) >> 5;
+    const int ksteps_o = (OUT + 1) >> 1;
+    // dx tile of this wave: (it, nt); dW tile: (ot, it2)
+    const bool has_dx = dx != nullptr && wave < n_it * 2;
+    const int it = wave % n_it, nt = wave / n_it;
+    const bool has_dw = want_w && wave < n_ot * n_it;
+    const int ot = wave % n_ot, it2 = wave / n_ot;
+    f32x16 accw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[r] = 0.0f;
+    float accb = 0.0f;
+    const long long tiles = (n + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        __syncthreads();
+        if (vec) {  // 16-byte loads: rows are float4-aligned and the widths are multiples of 4
+            float4 gq[4], xq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = threadIdx.x + q * kBlock, r = e >> 4, c = (e & 15) * 4;
+                gq[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                xq[q] = gq[q];
+                if (base + r < n) {
+                    if (c < OUT) {
+                        const size_t a = (size_t)(base + r) * ldy + c;
+                        const float4 d4 = *reinterpret_cast<const float4 *>(dy + a);
+                        float4 y4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (act != TN_ACT_NONE) y4 = *reinterpret_cast<const float4 *>(y + a);
+                        gq[q] = make_float4(d4.x * act_bwd(y4.x, act), d4.y * act_bwd(y4.y, act), d4.z * act_bwd(y4.z, act),
+                                            d4.w * act_bwd(y4.w, act));
+                    }
+                    if (want_w && c < IN) xq[q] = *reinterpret_cast<const float4 *>(x + (size_t)(base + r) * ldx + c);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = threadIdx.x + q * kBlock, r = e >> 4, c = (e & 15) * 4;
+                float *gp = gs + r * LDP + c, *xp = xs + r * LDP + c;
+                gp[0] = gq[q].x; gp[1] = gq[q].y; gp[2] = gq[q].z; gp[3] = gq[q].w;
+                xp[0] = xq[q].x; xp[1] = xq[q].y; xp[2] = xq[q].z; xp[3] = xq[q].w;
+            }
+        } else {
+            for (int e = threadIdx.x; e < TILE * 64; e += kBlock) {
+                const int r = e >> 6, c = e & 63;
+                float g = 0.0f, xv = 0.0f;
+                if (base + r < n) {
+                    if (c < OUT) {
+                        const size_t a = (size_t)(base + r) * ldy + c;
+                        g = dy[a] * act_bwd(act == TN_ACT_NONE ? 0.0f : y[a], act);
+                    }
+                    if (want_w && c < IN) xv = x[(base + r) * ldx + c];
+                }
+                gs[r * LDP + c] = g;
+                xs[r * LDP + c] = xv;
+            }
+        }
+        __syncthreads();
+        if (has_dw) {
+#pragma unroll 8
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const float a = gs[(2 * s2 + h) * LDP + ot * 32 + l31];
+                const float b = xs[(2 * s2 + h) * LDP + it2 * 32 + l31];
+                accw = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accw, 0, 0, 0);
+            }
+        }
+        if (want_w && threadIdx.x < 64) {  // bias: column sums of g
+            float sb = 0.0f;
+            for (int r = 0; r < TILE; ++r) sb += gs[r * LDP + threadIdx.x];
+            accb += sb;
+        }
+        f32x16 accd;
+        if (has_dx) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+            for (int s2 = 0; s2 < ksteps_o; ++s2) {
+                const float a = Ws[(2 * s2 + h) * LDP + it * 32 + l31];
+                const float b = gs[(nt * 32 + l31) * LDP + 2 * s2 + h];
+                accd = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accd, 0, 0, 0);
+            }
+        }
+        if (dx) {
+            __syncthreads();  // everyone is done reading xs
+            if (has_dx) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xs[(nt * 32 + l31) * LDP + it * 32 + crow(r, h)] = accd[r];
+            }
+            __syncthreads();
+            if (vec_dx) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = threadIdx.x + q * kBlock, r = e >> 4, c = (e & 15) * 4;
+                    if (base + r < n && c < IN) {
+                        const float *sp = xs + r * LDP + c;
+                        *reinterpret_cast<float4 *>(dx + (size_t)(base + r) * lddx + c) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                    }
+                }
+            } else {
+                for (int e = threadIdx.x; e < TILE * 64; e += kBlock) {
+                    const int r = e >> 6, i = e & 63;
+                    if (base + r < n && i < IN) {
+                        float *p = dx + (size_t)(base + r) * lddx + i;
+                        const float v = xs[r * LDP + i];
+                        *p = accumulate_dx ? *p + v : v;
+                    }
+                }
+            }
+        }
+    }
+    if (want_w) {  // slab [i (64 rows) | bias row][o (64)]
+        float *pb = partials + (size_t)blockIdx.x * 65 * 64;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 65 * 64; e += kBlock) pb[e] = 0.0f;
+        __syncthreads();
+        if (has_dw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pb[(it2 * 32 + l31) * 64 + ot * 32 + crow(r, h)] = accw[r];
+        }
+        if (threadIdx.x < 64) pb[64 * 64 + threadIdx.x] = accb;
+    }
+}
+
 // dW[o][i] += sum_b partials[b][i][o];  db[o] += sum_b partials[b][INP][o].  grid (INP + 1 rows, kRedSplit slices of
 // the block range); 256 threads = 64 outputs x 4 interleaved block streams; one atomic per (entry, slice).
 constexpr int kRedSplit = 8;
@@ -876,8 +1018,23 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
     const int INP = IN <= 16 ? 16 : IN <= 32 ? 32 : 64;
     const bool want_w = d_weight || d_bias;
     float *partials = nullptr;
-    if (want_w && workspace && workspace_bytes >= (size_t)blocks * (INP + 1) * 64 * sizeof(float))
+    if (want_w && workspace && workspace_bytes >= (size_t)blocks * 65 * 64 * sizeof(float))
         partials = reinterpret_cast<float *>(workspace);
+    if (!want_w || partials) {  // matrix-pipe form (needs the workspace for its partial weight gradients)
+        auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+        const int vec = (ldy % 4 == 0) && (OUT % 4 == 0) && al16(dy) && (act == TN_ACT_NONE || al16(y)) &&
+                        (!want_w || ((ldx % 4 == 0) && (IN % 4 == 0) && al16(x)));
+        const int vec_dx = dx && !accumulate_dx && (lddx % 4 == 0) && (IN % 4 == 0) && al16(dx);
+        hipLaunchKernelGGL(linear_bwd_mfma_kernel, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
+                           lddx, accumulate_dx, want_w ? 1 : 0, partials, vec, vec_dx);
+        TN_LAUNCH_CHECK();
+        if (want_w) {
+            hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(65, kRedSplit), dim3(kBlock), 0, st, partials, blocks, 64, IN, OUT,
+                               d_weight, d_bias);
+            TN_LAUNCH_CHECK();
+        }
+        return TN_OK;
+    }
     if (IN <= 16)
         hipLaunchKernelGGL(linear_bwd_kernel<4>, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
                            lddx, accumulate_dx, d_weight, d_bias, partials);
