@@ -195,6 +195,10 @@ typedef struct tn_render_config {
      * (wave-wide vote).  Skipped samples carry weights < eps each; rgb/thermal/accumulation move by <= eps, the
      * expected depth by <= eps * far.  The reference has no such switch: 0 reproduces it. */
     float early_stop_transmittance;
+    /* 0 = choose by call size (lane = ray from ~60-80 k rays up: a 64-ray tile marches serially and needs >= ~1250 tiles
+     * to fill the chip; one ray per wave below), 1 = lane = ray (a caller that overlaps several calls on different
+     * streams, like RayRenderEngine, fills the chip with fewer rays per call), 2 = one ray per wave. */
+    int32_t kernel_family;
 } tn_render_config;
 
 typedef struct tn_render_inputs {

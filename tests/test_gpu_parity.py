@@ -24,6 +24,14 @@ THERMAL_MAE = 1e-4
 DEPTH_REL = 1e-4
 
 
+@pytest.fixture(autouse=True)
+def lane_ray_kernels(monkeypatch):
+    """The library picks the kernel family by call size (lane = ray from ~60-80 k rays up, one ray per wave below).  The
+    tests in this module use a few hundred rays but target the throughput (lane = ray) kernels, so they force them;
+    test_small_calls_take_the_ray_per_wave_kernels covers the automatic choice."""
+    monkeypatch.setenv("TN_FORCE_LANE_RAY", "1")
+
+
 def gpu_model(kind="stress", S=48, small=True, **over):
     model, sd, ocfg = helpers.build(kind, S, small, **over)
     return copy.deepcopy(model).to(DEV).eval(), sd, ocfg
@@ -473,3 +481,34 @@ def test_engine_chunks_on_two_streams_match_one_stream():
         assert torch.equal(one[k], a[k]) and torch.equal(one[k], b[k]), k
     want = H.get_outputs(sd, o[:700].cpu(), d[:700].cpu(), None, ocfg)  # first chunk = one oracle call
     assert (a["rgb"][:700].cpu() - want["rgb"]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
+    """Automatic dispatch: below ~60-80 k rays the one-ray-per-wave kernels run (a 64-ray tile marches serially, so the
+    lane = ray kernels have a ~2.6 ms floor).  Same oracle tolerances; with f16x3 a small call is served in exact fp32."""
+    import time
+
+    gm, sd, ocfg = gpu_model("scene", 64)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, precision
+    o, d = helpers.rays(32, 32, view=4)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        forced = {k: v.clone() for k, v in gm(bundle(o, d)).items()}
+        monkeypatch.delenv("TN_FORCE_LANE_RAY")
+        auto = gm(bundle(o, d))
+        check_outputs(auto, want, f"auto dispatch {precision}")
+        for k in ("rgb", "thermal"):
+            assert (auto[k] - forced[k]).abs().max().item() <= 2e-5, k
+        # and it is the faster choice at this size
+        def timed():
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                gm(bundle(o, d))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / 5
+        t_auto = timed()
+        monkeypatch.setenv("TN_FORCE_LANE_RAY", "1")
+        t_forced = timed()
+    assert t_auto < t_forced, (t_auto, t_forced)

@@ -100,6 +100,7 @@ class tn_render_config(C.Structure):
         ("training", C.c_int32),
         ("pdf_anneal", C.c_float),
         ("early_stop_transmittance", C.c_float),
+        ("kernel_family", C.c_int32),
     ]
 
 

@@ -623,8 +623,12 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)prop_smem) != hipSuccess)
         return TN_ERR_LAUNCH;
-    if (!getenv("TN_PROPOSAL_PER_RAY")) {
-        // default: lane = ray
+    // lane = ray needs >= ~1250 tiles to fill the chip (a tile marches its 64 rays serially: 1.1 ms whatever the count);
+    // below ~80 k rays one wave per ray finishes sooner (4096 rays: 0.08 vs 1.1 ms).  Env switches force either form.
+    const bool small_call = cfg->kernel_family == 2 ||
+                            (cfg->kernel_family == 0 && num_rays < 81920 && !getenv("TN_FORCE_LANE_RAY"));
+    if (!getenv("TN_PROPOSAL_PER_RAY") && !small_call) {
+        // lane = ray
         PropRaysArgs ra;
         ra.p = pa;
         ra.nmax = nmax;
@@ -662,7 +666,9 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
     const float *ws_spacing = reinterpret_cast<const float *>(workspace);
     unsigned *minmax = ws_minmax(workspace, num_rays, S);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, minmax);
-    if (field->prepared_f16x3 && !cfg->training && !out->weights[2]) {
+    // the split-precision kernel only exists in the lane = ray form: small calls take the exact-fp32 ray-per-wave kernel
+    if (field->prepared_f16x3 && !cfg->training && !out->weights[2] && cfg->kernel_family != 2 &&
+        (num_rays >= 40960 || cfg->kernel_family == 1 || getenv("TN_FORCE_LANE_RAY"))) {
         TN_TRY(launch_main_h3(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
     } else if (field->prepared) {
         TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));

@@ -668,7 +668,10 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
                             (int)smem) != hipSuccess)
         return TN_ERR_LAUNCH;
     const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 77 KB each)
-    if (!cfg->training && !out->weights[2] && !getenv("TN_FORCE_RAY_PER_WAVE")) {
+    // 1.5 ms floor of the tile march vs 0.16 ms at 4096 rays
+    const bool small_call = cfg->kernel_family == 2 ||
+                            (cfg->kernel_family == 0 && num_rays < 57344 && !getenv("TN_FORCE_LANE_RAY"));
+    if (!cfg->training && !out->weights[2] && !getenv("TN_FORCE_RAY_PER_WAVE") && !small_call) {
         // eval: lane = ray (64 consecutive rays per wave), coherent gathers
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_rays_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)

@@ -36,6 +36,7 @@ class RayRenderEngine:
         self.rc.training = 0
         self.rc.pdf_anneal = float(model.proposal_sampler._anneal)
         self.rc.early_stop_transmittance = float(cfg.early_termination_eps)
+        self.rc.kernel_family = 0
         # a chunk of 65 536 rays is 1024 waves — one per SIMD, half of what the field kernel needs to hide its gathers —
         # so consecutive chunks go to alternating HIP streams (own workspace each) and overlap on the device
         self.num_streams = max(1, int(streams))
@@ -84,6 +85,8 @@ class RayRenderEngine:
         outs = _hip.tn_render_outputs()
         wsn = self._ws.shape[1]
         multi = self.num_streams > 1 and n > self.chunk
+        # chunks overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
+        self.rc.kernel_family = 1 if (multi and self.chunk * self.num_streams >= 100000) else 0
         current = torch.cuda.current_stream(dev)
         if multi:
             for st in self._streams:
