@@ -255,27 +255,26 @@ def make_linear(layer: torch.nn.Linear) -> tn_linear:
     return tn_linear(w.data_ptr(), b.data_ptr(), layer.in_features, layer.out_features)
 
 
-_HOST_COPIES: dict = {}
+def host_values(owner, name: str) -> tuple:
+    """Flat host copy of a small constant device buffer of module ``owner`` (scalings, aabb), cached ON the module per
+    (storage, version): reading it back on every call would be a synchronising device-to-host copy in the middle of the
+    launch stream.  (Not a global cache: device addresses are recycled between tensors.)"""
+    t = getattr(owner, name)
+    key = (t.data_ptr(), t._version, str(t.device))
+    cache = owner.__dict__.setdefault("_host_copies", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, tuple(t.detach().float().reshape(-1).cpu().tolist()))
+        cache[name] = hit
+    return hit[1]
 
 
-def host_values(t: torch.Tensor) -> tuple:
-    """Flat host copy of a small constant device buffer (scalings, aabb), cached per (storage, version): reading it back
-    on every call would be a synchronising device-to-host copy in the middle of the launch stream."""
-    key = (t.data_ptr(), t._version, t.numel(), str(t.device))
-    v = _HOST_COPIES.get(key)
-    if v is None:
-        if len(_HOST_COPIES) > 256:
-            _HOST_COPIES.clear()
-        v = tuple(t.detach().float().reshape(-1).cpu().tolist())
-        _HOST_COPIES[key] = v
-    return v
-
-
-def make_space(contraction: bool, aabb: Optional[torch.Tensor]) -> tn_space:
+def make_space(contraction: bool, aabb: Optional[torch.Tensor], owner=None) -> tn_space:
+    """``owner``: the module holding ``aabb`` as its attribute of that name (enables the cached host copy)."""
     s = tn_space()
     s.contraction = 1 if contraction else 0
     if aabb is not None:
-        a = host_values(aabb)
+        a = host_values(owner, "aabb") if owner is not None else tuple(aabb.detach().float().reshape(-1).cpu().tolist())
         for i in range(3):
             s.aabb_min[i] = a[i]
             s.aabb_max[i] = a[3 + i]

@@ -64,7 +64,7 @@ class HashEncoding(nn.Module):
         table = _hip.require_device_tensor(self.hash_table.detach(), "hash_table")
         g = _hip.tn_hashgrid()
         g.table = table.data_ptr()
-        sc = _hip.host_values(self.scalings)  # cached: no device read-back per call
+        sc = _hip.host_values(self, "scalings")  # cached on the module: no device read-back per call
         for i in range(self.num_levels):
             g.scalings[i] = sc[i]
         g.num_levels = self.num_levels
@@ -151,7 +151,7 @@ class HashMLPDensityField(nn.Module):
         f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes)
         f.l0 = _hip.make_linear(self.mlp_base.mlp.layers[0])
         f.l1 = _hip.make_linear(self.mlp_base.mlp.layers[1])
-        f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb)
+        f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb, owner=self)
         f.average_init_density = float(self.average_init_density)
         return f
 

@@ -110,7 +110,7 @@ class ThermalNerfactoTField(nn.Module):
         f.geo_feat_dim = self.geo_feat_dim
         f.use_average_appearance = 1 if self.use_average_appearance_embedding else 0
         f.sh_shifted = 1 if self.sh_input == "shifted" else 0
-        f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb)
+        f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb, owner=self)
         f.average_init_density = float(self.average_init_density)
         f.prepared = None
         f.prepared_f16x3 = None

@@ -187,23 +187,57 @@ class RenderTrain(torch.autograd.Function):
         fld = model.field.c_struct(prepare=False)
         anneal = float(model.proposal_sampler._anneal)
 
-        # ---- proposal levels: sample -> taped density -> weights -------------------------------------------
+        # ---- proposal levels ---------------------------------------------------------------------------------
         tapes: List[_LevelTape] = []
-        spacing = _f32((R, P[0] + 1), dev)
-        eucl = _f32((R, P[0] + 1), dev)
-        _hip.check(lib.tn_sample_initial(linspace_bins(P[0], dev).data_ptr(), jitter[0].data_ptr(), nears.data_ptr(),
-                                         fars.data_ptr(), R, P[0], spacing.data_ptr(), eucl.data_ptr(), _stream()),
-                   "tn_sample_initial")
-        counts = (P[1], S)
-        for lvl in range(2):
-            t = _proposal_level_fwd(prop_structs[lvl], o, d, spacing, eucl)
-            tapes.append(t)
-            n_out = counts[lvl]
-            w_in = t.weights if anneal == 1.0 else torch.pow(t.weights, anneal)
-            spacing, eucl = _f32((R, n_out + 1), dev), _f32((R, n_out + 1), dev)
-            _hip.check(lib.tn_sample_pdf(w_in.data_ptr(), t.spacing.data_ptr(), pdf_positions(n_out + 1, dev, True).data_ptr(),
-                                         jitter[lvl + 1].data_ptr(), nears.data_ptr(), fars.data_ptr(), R, P[lvl], n_out,
-                                         spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
+        prop_depths: List[Tensor] = []
+        if updated:
+            # the proposal networks take gradient this step: sample -> taped density -> weights, level by level
+            spacing = _f32((R, P[0] + 1), dev)
+            eucl = _f32((R, P[0] + 1), dev)
+            _hip.check(lib.tn_sample_initial(linspace_bins(P[0], dev).data_ptr(), jitter[0].data_ptr(), nears.data_ptr(),
+                                             fars.data_ptr(), R, P[0], spacing.data_ptr(), eucl.data_ptr(), _stream()),
+                       "tn_sample_initial")
+            counts = (P[1], S)
+            for lvl in range(2):
+                t = _proposal_level_fwd(prop_structs[lvl], o, d, spacing, eucl)
+                tapes.append(t)
+                n_out = counts[lvl]
+                w_in = t.weights if anneal == 1.0 else torch.pow(t.weights, anneal)
+                spacing, eucl = _f32((R, n_out + 1), dev), _f32((R, n_out + 1), dev)
+                _hip.check(lib.tn_sample_pdf(w_in.data_ptr(), t.spacing.data_ptr(), pdf_positions(n_out + 1, dev, True).data_ptr(),
+                                             jitter[lvl + 1].data_ptr(), nears.data_ptr(), fars.data_ptr(), R, P[lvl], n_out,
+                                             spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
+        else:
+            # nerfstudio evaluates the proposal densities under no_grad on these steps (5 of 6 after warm-up): no tape is
+            # needed, so both levels run as ONE fused kernel (tn_proposal_sample_fwd, train-mode semantics)
+            rc = _hip.tn_render_config()
+            rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = P[0], P[1], S
+            rc.training, rc.pdf_anneal, rc.early_stop_transmittance, rc.kernel_family = 1, anneal, 0.0, 0
+            ins = _hip.tn_render_inputs()
+            ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
+            ins.camera_indices, ins.jitter = cam.data_ptr(), jitter.data_ptr()
+            ins.lin_bins0 = linspace_bins(P[0], dev).data_ptr()
+            ins.u1 = pdf_positions(P[1] + 1, dev, True).data_ptr()
+            ins.u2 = pdf_positions(S + 1, dev, True).data_ptr()
+            outs = _hip.tn_render_outputs()
+            ns = (P[0], P[1], S)
+            sp = [_f32((R, k + 1), dev) for k in ns]
+            eu = [_f32((R, k + 1), dev) for k in ns]
+            ws_ = [_f32((R, k), dev) for k in ns[:2]]
+            prop_depths = [_f32((R, 1), dev), _f32((R, 1), dev)]
+            for i in range(3):
+                outs.spacing_bins[i], outs.eucl_bins[i] = sp[i].data_ptr(), eu[i].data_ptr()
+            outs.weights[0], outs.weights[1] = ws_[0].data_ptr(), ws_[1].data_ptr()
+            outs.prop_depth_0, outs.prop_depth_1 = prop_depths[0].data_ptr(), prop_depths[1].data_ptr()
+            need = lib.tn_render_workspace_bytes(rc, R)
+            wsb = torch.empty(need, dtype=torch.uint8, device=dev)
+            _hip.check(lib.tn_proposal_sample_fwd(prop_structs[0], prop_structs[1], rc, ins, outs, R, wsb.data_ptr(), need,
+                                                  _stream()), "tn_proposal_sample_fwd")
+            for i in range(2):
+                t = _LevelTape()
+                t.spacing, t.eucl, t.weights = sp[i], eu[i], ws_[i]
+                tapes.append(t)
+            spacing, eucl = sp[2], eu[2]
 
         # ---- final level: taped field ----------------------------------------------------------------------
         f = _LevelTape()
@@ -240,8 +274,7 @@ class RenderTrain(torch.autograd.Function):
         starts, ends = eucl[:, :-1].contiguous(), eucl[:, 1:].contiguous()
         _hip.check(lib.tn_depth_fwd(f.weights.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S, acc.data_ptr(),
                                     depth.data_ptr(), expected.data_ptr(), scratch.data_ptr(), _stream()), "tn_depth_fwd")
-        prop_depths = []
-        for t in tapes:
+        for t in (tapes if not prop_depths else []):
             pd = _f32((R, 1), dev)
             st, en = t.eucl[:, :-1].contiguous(), t.eucl[:, 1:].contiguous()
             _hip.check(lib.tn_depth_fwd(t.weights.data_ptr(), st.data_ptr(), en.data_ptr(), R, t.weights.shape[1], None,
