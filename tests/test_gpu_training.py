@@ -477,6 +477,26 @@ def test_thermoscenes_style_tree_to_training_steps(tmp_path):
     with pytest.raises(ValueError, match="Thermal images not found"):
         ThermalNerfModel(cfg, metadata={}, scene_box=train_out.scene_box, num_train_data=8)  # REF thermal_nerf_model.py:75-76
 
+    # evaluation harness on the eval split [REF evaluator/evaluator.py:47-133]
+    from thermo_nerf_amd.evaluator import Evaluator
+    from thermo_nerf_amd.rendered_image_modalities import RenderedImageModality as M
+
+    model.max_temperature, model.min_temperature = 33.0, 14.0
+    ev = Evaluator(model, ThermalDataset(eval_out), experiment_name="unit", job_param_identifier="t",
+                   modalities_to_save=[M.RGB, M.THERMAL, M.THERMAL_COMBINED], threshold=0.5, device=DEV)
+    res = ev.metrics
+    for key in ("psnr", "psnr_thermal", "mae_thermal", "mae_thermal_foreground"):
+        assert len(res[key]) == 2 and res[f"{key}_mean"] == pytest.approx(sum(res[key]) / 2, rel=1e-6)
+        assert res[f"{key}_std"] >= 0
+    assert 0 < res["mae_thermal_mean"] < 19.0  # degrees: normalised error x (33 - 14)
+    ev.save_metrics(tmp_path / "eval")
+    saved = json.loads((tmp_path / "eval" / "metrics.json").read_text())
+    assert saved["method_name"] == "thermal-nerf" and saved["job_param_identifier"] == "t" and "psnr_mean" in saved["results"]
+    ev.save_images([M.RGB, M.THERMAL_COMBINED], tmp_path / "eval" / "images")
+    names = sorted(p.name for p in (tmp_path / "eval" / "images").glob("*.jpg"))
+    assert names == ["img_00000.jpg", "img_00001.jpg", "thermal_combined_00000.jpg", "thermal_combined_00001.jpg"]
+    assert Image.open(tmp_path / "eval" / "images" / "img_00000.jpg").size == (64, 32)  # ground truth | prediction
+
 
 def test_eval_follows_fused_optimizer_updates():
     """torch.optim.Adam(fused=True) changes parameters without bumping their version counters; the prepared MFMA blobs

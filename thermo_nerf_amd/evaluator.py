@@ -1,0 +1,95 @@
+"""Evaluation harness — counterpart of the reference's ``Evaluator`` [REF thermo_nerf/evaluator/evaluator.py:15-160]:
+render every image of the eval split ONCE (all modalities come out of one pass), compute the per-image metrics of
+``get_image_metrics_and_images`` that this path owns (RGB PSNR, thermal PSNR, thermal MAE in degrees for the whole image and
+for the foreground beyond ``threshold``), aggregate ``<key>``, ``<key>_mean``, ``<key>_std`` exactly as the reference does,
+write ``metrics.json`` and the rendered images.  SSIM / LPIPS (torchmetrics networks) are outside the hot path and absent.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .cameras import frame_metrics
+from .rays import RayBundle
+from .rendered_image_modalities import RenderedImageModality
+
+
+class Evaluator:
+    def __init__(self, model, eval_dataset, experiment_name: str = "", method_name: str = "thermal-nerf",
+                 job_param_identifier: Optional[str] = None,
+                 modalities_to_save: Sequence[RenderedImageModality] = (RenderedImageModality.RGB,),
+                 threshold: Optional[float] = None, device="cuda") -> None:
+        self.model, self.dataset, self.device = model, eval_dataset, device
+        self.identifier = job_param_identifier
+        self.modalities_to_save = list(modalities_to_save)
+        self._evaluation_images: Dict[RenderedImageModality, List[np.ndarray]] = {m: [] for m in self.modalities_to_save}
+        self._metrics = self._compute_metrics(threshold)
+        self._benchmark_info = {"experiment_name": experiment_name, "method_name": method_name,
+                                "job_param_identifier": self.identifier, "results": self._metrics}
+
+    @property
+    def metrics(self) -> Dict:
+        return self._metrics
+
+    @torch.no_grad()
+    def _compute_metrics(self, threshold: Optional[float]) -> Dict:
+        """[REF evaluator.py:47-106]"""
+        model = self.model
+        was_training = model.training
+        model.eval()
+        per_image: List[Dict[str, float]] = []
+        cams = self.dataset.cameras
+        for idx in range(len(self.dataset)):
+            item = self.dataset[idx]
+            rb = cams.generate_rays(idx, device=self.device)
+            h, w = rb.origins.shape[:2]
+            flat = rb.flatten()
+            model.camera_optimizer.apply_to_raybundle(flat)  # REF :68-76 (indices address the optimizer's table)
+            rb = RayBundle(origins=flat.origins.view(h, w, 3), directions=flat.directions.view(h, w, 3),
+                           pixel_area=rb.pixel_area, camera_indices=rb.camera_indices)
+            outputs = model.get_outputs_for_camera_ray_bundle(rb)
+            gt_rgb = item["image"].to(self.device)
+            gt_th = item[RenderedImageModality.THERMAL.value].to(self.device)
+            per_image.append(frame_metrics(outputs, gt_rgb, gt_th, model.max_temperature, model.min_temperature,
+                                           cold=model.config.cold, threshold=threshold))
+            images = {  # the images_dict entries of get_image_metrics_and_images [REF thermal_nerf_model.py:341-352]
+                RenderedImageModality.RGB: lambda: torch.cat([gt_rgb, outputs["rgb"]], dim=1),
+                RenderedImageModality.THERMAL: lambda: outputs["thermal"],
+                RenderedImageModality.THERMAL_COMBINED: lambda: torch.cat([gt_th, outputs["thermal"]], dim=1),
+                RenderedImageModality.ACCUMULATION: lambda: outputs["accumulation"],
+            }
+            for m in self.modalities_to_save:
+                if m not in images:
+                    raise NotImplementedError(f"saving modality {m.value} (colour-mapped depth) is not implemented")
+                self._evaluation_images[m].append((images[m]().clamp(0, 1) * 255).byte().cpu().numpy())
+        model.train(was_training)
+        if not per_image:
+            raise RuntimeError("Cannot evaluate without eval images")
+        out: Dict = {}
+        for key in per_image[0]:
+            vals = torch.tensor([m[key] for m in per_image], dtype=torch.float64)
+            std, mean = torch.std_mean(vals) if len(per_image) > 1 else (torch.tensor(float("nan")), vals.mean())
+            out[f"{key}_mean"], out[f"{key}_std"] = float(mean), float(std)
+            out[key] = [m[key] for m in per_image]
+        return out
+
+    def save_images(self, modalities: Sequence[RenderedImageModality], output_path) -> None:
+        """[REF evaluator.py:108-124]"""
+        output_path = Path(output_path)
+        output_path.mkdir(parents=True, exist_ok=True)
+        for m in modalities:
+            for idx, image in enumerate(self._evaluation_images[m]):
+                arr = image[:, :, 0] if image.shape[-1] == 1 else image
+                Image.fromarray(arr).save(output_path / f"{m.value}_{idx:05d}.jpg")
+
+    def save_metrics(self, output_folder) -> Path:
+        """[REF evaluator.py:126-133]"""
+        output_file = Path(output_folder, "metrics.json")
+        output_file.parent.mkdir(parents=True, exist_ok=True)
+        output_file.write_text(json.dumps(self._benchmark_info, indent=2), "utf8")
+        return output_file
