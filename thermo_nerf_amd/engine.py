@@ -21,7 +21,7 @@ OUTPUT_KEYS = ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0",
 
 
 class RayRenderEngine:
-    def __init__(self, model: ThermalNerfModel, chunk: Optional[int] = None, streams: int = 2) -> None:
+    def __init__(self, model: ThermalNerfModel, chunk: Optional[int] = None, streams: Optional[int] = None) -> None:
         if model.training:
             raise RuntimeError("RayRenderEngine renders in eval mode; call model.eval() first")
         self.model = model
@@ -39,6 +39,9 @@ class RayRenderEngine:
         self.rc.kernel_family = 0
         # a chunk of 65 536 rays is 1024 waves — one per SIMD, half of what the field kernel needs to hide its gathers —
         # so consecutive chunks go to alternating HIP streams (own workspace each) and overlap on the device
+        # (default: 2 streams; 4 — the number of hardware queues HIP streams map onto — for small chunks)
+        if streams is None:
+            streams = 2 if self.chunk >= 32768 else 4
         self.num_streams = max(1, int(streams))
         self._streams: List[torch.cuda.Stream] = []
         self._ws: Optional[Tensor] = None
@@ -86,7 +89,7 @@ class RayRenderEngine:
         wsn = self._ws.shape[1]
         multi = self.num_streams > 1 and n > self.chunk
         # chunks overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
-        self.rc.kernel_family = 1 if (multi and self.chunk * self.num_streams >= 100000) else 0
+        self.rc.kernel_family = 1 if (multi and self.chunk >= 49152) else 0
         current = torch.cuda.current_stream(dev)
         if multi:
             for st in self._streams:
