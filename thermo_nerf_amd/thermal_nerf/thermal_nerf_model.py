@@ -181,7 +181,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         chunk = int(self.config.eval_num_rays_per_chunk)
         eng = _ENGINES.get(self)  # side table: streams / ctypes structs must not ride along in deepcopy / state_dict
         if eng is None or eng.chunk != chunk or eng.rc.early_stop_transmittance != float(self.config.early_termination_eps):
-            eng = _ENGINES[self] = RayRenderEngine(self, chunk=chunk)
+            eng = _ENGINES[self] = RayRenderEngine(weakref.proxy(self), chunk=chunk)  # proxy: the table must not keep the model alive
         h, w = camera_ray_bundle.origins.shape[:2]
         o = camera_ray_bundle.origins.reshape(-1, 3).to(self.device)
         d = camera_ray_bundle.directions.reshape(-1, 3).to(self.device)
