@@ -208,7 +208,7 @@ def _gpu_step(gm, o, d, jit, cam, batch):
 
 
 @pytest.mark.parametrize("kind", ["stress", "scene"])
-@pytest.mark.parametrize("S", [48, 64])
+@pytest.mark.parametrize("S", [48, 64, 192])  # 192 = BASELINE config 3 (multi-chunk scans in every per-ray kernel)
 def test_training_step_matches_autograd_oracle(kind, S):
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S)
     out, loss_dict = _gpu_step(gm, o, d, jit, cam, batch)
@@ -231,9 +231,14 @@ def test_training_step_matches_autograd_oracle(kind, S):
             assert gg is None or gg.abs().max().item() == 0.0, name
             continue
         assert gg is not None, f"{name}: no gradient"
+        if gw.norm().item() < 1e-10:
+            # an interlevel loss that is zero up to rounding (the proposal envelope already covers the final weights)
+            # leaves gradients made of a few max(w - w_outer, 0) terms at the 1e-14 level: only their size is comparable
+            assert gg.norm().item() < 1e-9, name
+            continue
         assert rel(gg, gw) <= 2e-3, f"{name}: rel {rel(gg, gw):.2e} (|g| {gw.norm().item():.2e})"
         checked += 1
-    assert checked >= 25
+    assert checked >= 18
 
 
 def test_proposal_networks_frozen_between_updates():
