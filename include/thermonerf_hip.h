@@ -187,8 +187,8 @@ int tn_depth_fwd(const float *weights, const float *starts, const float *ends, i
  * ---------------------------------------------------------------------------------------------------- */
 
 typedef struct tn_render_config {
-    int32_t num_proposal_samples[2]; /* (256, 96)                     */
-    int32_t num_nerf_samples;        /* 48 | 64 | 192 ... (<= 256)    */
+    int32_t num_proposal_samples[2]; /* (256, 96); 1..1024 each       */
+    int32_t num_nerf_samples;        /* 48 | 64 | 192 ...; 1..1024    */
     int32_t training;                /* eval == 0                     */
     float pdf_anneal;                /* ProposalNetworkSampler._anneal (1.0 at inference) */
     /* eval only, 0 = off (exact): a wave of 64 rays stops marching once EVERY ray's transmittance is below this value

@@ -512,3 +512,30 @@ def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
         monkeypatch.setenv("TN_FORCE_LANE_RAY", "1")
         t_forced = timed()
     assert t_auto < t_forced, (t_auto, t_forced)
+
+
+@pytest.mark.parametrize("P,S", [((256, 96), 1), ((256, 96), 2), ((256, 96), 256), ((1, 1), 3), ((2, 256), 64), ((256, 256), 33),
+                                 ((7, 5), 65)])
+@pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
+def test_extreme_sample_counts(monkeypatch, P, S, family):
+    """Smallest and largest per-level sample counts the kernels accept, for both kernel families."""
+    if family == "ray_per_wave":
+        monkeypatch.delenv("TN_FORCE_LANE_RAY")
+    gm, sd, ocfg = gpu_model("stress", S, num_proposal_samples_per_ray=P)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f32"
+    o, d = helpers.rays(11, 13, view=2)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    check_outputs(got, want, f"P={P} S={S} {family}")
+
+
+def test_sample_counts_beyond_the_kernel_limits_are_refused():
+    gm, sd, ocfg = gpu_model("stress", 300)  # above 256: still inside the limit of 1024 per level
+    o, d = helpers.rays(6, 6)
+    with torch.no_grad():
+        check_outputs(gm(bundle(o, d)), H.get_outputs(sd, o, d, None, ocfg), "S=300")
+    big, _, _ = gpu_model("stress", 1025)
+    with pytest.raises(RuntimeError, match="TN_ERR_SHAPE"):
+        with torch.no_grad():
+            big(bundle(o, d))
