@@ -539,3 +539,26 @@ def test_sample_counts_beyond_the_kernel_limits_are_refused():
     with pytest.raises(RuntimeError, match="TN_ERR_SHAPE"):
         with torch.no_grad():
             big(bundle(o, d))
+
+
+@pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
+def test_degenerate_rays(monkeypatch, family):
+    """Axis-aligned directions, origins on exact grid points (ceil == floor corners), origins far outside the scene,
+    rays that never enter the unit box."""
+    if family == "ray_per_wave":
+        monkeypatch.delenv("TN_FORCE_LANE_RAY")
+    gm, sd, ocfg = gpu_model("stress", 64)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f32"
+    axes = torch.tensor([[1.0, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+    o = torch.cat([torch.zeros(6, 3), torch.full((6, 3), 0.5), torch.tensor([[40.0, -25.0, 3.0]]).repeat(6, 1),
+                   torch.tensor([[0.25, 0.125, -0.0625]]).repeat(6, 1), torch.tensor([[5.0, 5.0, 5.0]]).repeat(6, 1)])
+    d = axes.repeat(5, 1)
+    diag = torch.nn.functional.normalize(torch.tensor([[1.0, 1.0, 1.0], [-1.0, 1.0, -1.0]]), dim=1)
+    o = torch.cat([o, torch.tensor([[-3.0, -3.0, -3.0], [2.0, -2.0, 2.0]])])
+    d = torch.cat([d, diag])
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    for k in ("rgb", "thermal", "accumulation"):
+        assert torch.isfinite(got[k]).all(), k
+    check_outputs(got, want, f"degenerate rays {family}")
