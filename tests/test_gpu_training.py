@@ -409,6 +409,20 @@ def test_trainer_fits_analytic_scene_and_resumes(tmp_path):
     assert m1 <= 0.12 and m1 <= 0.5 * m0, (m0, m1)
     assert sorted(p.name for p in tmp_path.glob("*.ckpt")) == ["step-000000125.ckpt", "step-000000250.ckpt"]
 
+    # matched quality: the CPU oracle renders the TRAINED weights to the same PSNR / thermal MAE as the HIP path
+    # (BASELINE: "at matched RGB PSNR and thermal MAE")
+    rb = test_cams.generate_rays(0, device=DEV, flat=True)
+    sd_trained = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ocfg = helpers.oracle_config(model.config)
+    want = H.get_outputs(sd_trained, rb.origins.cpu(), rb.directions.cpu(), None, ocfg, anneal=model.proposal_sampler._anneal)
+    got = render_view(model, test_cams, 0, DEV)
+    gt_rgb, gt_th = held_out[0][0].reshape(-1, 3).cpu(), held_out[0][1].reshape(-1, 1).cpu()
+    psnr_cpu, psnr_gpu = psnr(want["rgb"], gt_rgb).item(), psnr(got["rgb"].reshape(-1, 3).cpu(), gt_rgb).item()
+    mae_cpu = (want["thermal"] - gt_th).abs().mean().item()
+    mae_gpu = (got["thermal"].reshape(-1, 1).cpu() - gt_th).abs().mean().item()
+    print(f"held-out view 0: psnr cpu {psnr_cpu:.3f} / gpu {psnr_gpu:.3f} dB, thermal mae cpu {mae_cpu:.5f} / gpu {mae_gpu:.5f}")
+    assert abs(psnr_cpu - psnr_gpu) <= 0.05 and abs(mae_cpu - mae_gpu) <= 5e-4
+
     # resume into a fresh model/trainer: same step, same weights, same optimizer moments, same learning rate
     other = fresh()
     tr2 = Trainer(other, ds, TrainerConfig(train_num_rays_per_batch=4096))
