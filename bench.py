@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render (default): the BASELINE metric on config 2.  train: one optimisation step per 'step' "
+                         "(BASELINE configs 3/5; with N ranks every rank trains its own scene replica, no collective)")
     ap.add_argument("--samples", type=int, default=64, help="num_nerf_samples_per_ray (config 2: 64)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=800)
@@ -178,6 +181,29 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback exists in thermo_nerf_amd)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+
+    if args.mode == "train":
+        # per-GPU scene assignment (BASELINE config 5): independent replicas, no data-path collective; the timed region is
+        # bracketed by barriers like the render mode and `value` is all ranks' rays over the slowest rank's time
+        if world > 1:
+            dist.barrier()
+        res = measure_train_step(dev, args.samples if args.samples != 64 else 48, steps=max(args.steps, 1),
+                                 warmup=max(args.warmup, 1), cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        t = torch.tensor([res["ms_per_step"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ms = float(t.item())
+            line = {"metric": "rays/sec (train step: forward + losses + backward + Adam) @ 4096 rays/step", "value": world * 4096 / (ms * 1e-3),
+                    "unit": "rays/s", "n_gpus": world, "steps": res["steps"], "warmup": max(args.warmup, 1), "ms_per_step": ms,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": res["what"], "parallelism": "scene replica per rank x%d, no collective" % world}}
+            if "cpu_baseline" in res:
+                line["cpu_baseline"] = res["cpu_baseline"]
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.engine import OUTPUT_KEYS, RayRenderEngine
