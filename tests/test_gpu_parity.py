@@ -502,12 +502,15 @@ def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
             assert (auto[k] - forced[k]).abs().max().item() <= 2e-5, k
         # and it is the faster choice at this size
         def timed():
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(5):
-                gm(bundle(o, d))
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / 5
+            best = float("inf")
+            for _ in range(4):  # best of four: the first repetition may carry one-time costs
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(5):
+                    gm(bundle(o, d))
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t) / 5)
+            return best
         t_auto = timed()
         monkeypatch.setenv("TN_FORCE_LANE_RAY", "1")
         t_forced = timed()

@@ -85,6 +85,39 @@ __device__ __forceinline__ float proposal_density_eval(const Grid &g, const TwoL
     return mul_rn(mul_rn(avg, t_exp<FAST>(o)), sel);
 }
 
+// The same density with the MLP weights read as SCALAR operands (constant address space -> s_load, SGPR sources): a
+// wave-uniform weight broadcast from LDS still costs LDS->VGPR bandwidth for 64 lanes (8 clk per ds_read_b128), and the
+// ~50 broadcast reads per sample of the LDS form keep the LDS pipe ~75 % busy at 12 waves per CU.  Same accumulation
+// order as hidden_from_grid (per hidden unit: bias, then the features in level order): bit-identical results.
+typedef __attribute__((address_space(4))) const float tn_cfloat;
+__device__ __forceinline__ const tn_cfloat *as_scalar(const float *p) { return (const tn_cfloat *)p; }
+
+template <int H, int NL, bool FAST>
+__device__ __forceinline__ float proposal_density_scalar(const Grid &g, const tn_cfloat *w0, const tn_cfloat *b0,
+                                                         const tn_cfloat *w1, const tn_cfloat *b1, float avg, float px, float py,
+                                                         float pz, float sel) {
+    float2 f[NL];
+    if (g.num_dense == 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) f[l] = encode_level<false, FAST>(g, l, px, py, pz);
+    } else {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) f[l] = encode_level_any<FAST>(g, l, px, py, pz);
+    }
+    float o = b1[0];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float a = b0[h];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            a = fmaf(w0[h * 2 * NL + 2 * l], f[l].x, a);
+            a = fmaf(w0[h * 2 * NL + 2 * l + 1], f[l].y, a);
+        }
+        o = fmaf(w1[h], fmaxf(a, 0.0f), o);
+    }
+    return mul_rn(mul_rn(avg, t_exp<FAST>(o)), sel);
+}
+
 // ---- SH degree-3 basis (16 comps), NS components_from_spherical_harmonics -----------------------------
 __device__ __forceinline__ void sh16(float x, float y, float z, float (&c)[16]) {
     const float xx = x * x, yy = y * y, zz = z * z;

@@ -68,7 +68,8 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // proposal_net_args_list uses num_levels 5: unrolled form keeps all 40 gathers of a sample in flight
             const float dens = (net.g.num_levels == 5)
-                                   ? proposal_density_eval<PH, 5, true>(net.g, w, net.avg, px, py, pz, sel)
+                                   ? proposal_density_scalar<PH, 5, true>(net.g, as_scalar(net.w0), as_scalar(net.b0),
+                                                                          as_scalar(net.w1), as_scalar(net.b1), net.avg, px, py, pz, sel)
                                    : proposal_density_eval<PH, 0, true>(net.g, w, net.avg, px, py, pz, sel);
             wts[i] = mul_rn(sub_rn(en, st), dens);
         }
@@ -265,7 +266,7 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     for (; j < nb; ++j) emit(j, b0);
 }
 
-__global__ void __launch_bounds__(kBlock, 3) proposal_rays_kernel(PropRaysArgs ra) {
+__global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PropArgs &a = ra.p;
     const int in0 = 2 * a.net[0].g.num_levels, in1 = 2 * a.net[1].g.num_levels;
@@ -325,7 +326,9 @@ __global__ void __launch_bounds__(kBlock, 3) proposal_rays_kernel(PropRaysArgs r
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp0, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                            frustum_pos(oz, dz, st, en), px, py, pz);
-                const float dens = fast0 ? proposal_density_eval<PH, 5, true>(a.net[0].g, w0, a.net[0].avg, px, py, pz, sel)
+                const float dens = fast0 ? proposal_density_scalar<PH, 5, true>(a.net[0].g, as_scalar(a.net[0].w0), as_scalar(a.net[0].b0),
+                                                                                as_scalar(a.net[0].w1), as_scalar(a.net[0].b1),
+                                                                                a.net[0].avg, px, py, pz, sel)
                                          : proposal_density_eval<PH, 0, true>(a.net[0].g, w0, a.net[0].avg, px, py, pz, sel);
                 const float dd = mul_rn(sub_rn(en, st), dens);
                 const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
@@ -364,7 +367,9 @@ __global__ void __launch_bounds__(kBlock, 3) proposal_rays_kernel(PropRaysArgs r
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp1, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                            frustum_pos(oz, dz, st, en), px, py, pz);
-                const float dens = fast1 ? proposal_density_eval<PH, 5, true>(a.net[1].g, w1, a.net[1].avg, px, py, pz, sel)
+                const float dens = fast1 ? proposal_density_scalar<PH, 5, true>(a.net[1].g, as_scalar(a.net[1].w0), as_scalar(a.net[1].b0),
+                                                                                as_scalar(a.net[1].w1), as_scalar(a.net[1].b1),
+                                                                                a.net[1].avg, px, py, pz, sel)
                                          : proposal_density_eval<PH, 0, true>(a.net[1].g, w1, a.net[1].avg, px, py, pz, sel);
                 const float dd = mul_rn(sub_rn(en, st), dens);
                 const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
@@ -640,7 +645,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
                                       two_layer_floats(2 * prop1->grid.num_levels, PH, 1) + (P0 + 1) + (P1 + 1) + (S + 1)) *
                              sizeof(float);
         const long long need = ((long long)tiles + kWaves - 1) / kWaves;
-        const unsigned grid = (unsigned)(need < 768 ? (need < 1 ? 1 : need) : 768);  // 3 workgroups (12 waves) per CU
+        const unsigned grid = (unsigned)(need < 1024 ? (need < 1 ? 1 : need) : 1024);  // 4 workgroups (16 waves) per CU
         hipLaunchKernelGGL(proposal_rays_kernel, dim3(grid), dim3(kBlock), rsmem, s, ra);
         TN_LAUNCH_CHECK();
         return TN_OK;
