@@ -31,6 +31,8 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / TN_WAVE;
 constexpr int PH = 16;  // proposal-net hidden width (proposal_net_args_list: hidden_dim 16)
+constexpr size_t kWsMid = 2048;      // workspace bytes between the final edges and the proposal scratch
+constexpr int kPropWFloats = 208;    // per net: W0 k-major [10][16] | b0 [16] | w1 [16] | b1 [1] (+ pad)
 
 struct PropNet {
     Grid g;
@@ -43,6 +45,7 @@ struct PropArgs {
     PropNet net[2];
     const float *origins, *dirs, *nears, *fars;
     const float *lin0, *u1, *u2, *jitter;
+    const float *wk;  // [2][kPropWFloats] k-major copies of the two proposal MLPs (workspace), scalar-operand evaluation
     long long R;
     int P0, P1, S, training;
     float anneal;
@@ -214,6 +217,61 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
 
 
 // ------------------------------------------------------------------------------------------------------
+// k-major copy of a 10 -> 16 -> 1 proposal MLP for the scalar-operand evaluation below: W0t[k][h] = W0[h][k], so that the
+// two weights of a packed FMA (hidden units 2j, 2j+1 of one input feature) are adjacent dwords of one s_load.
+__global__ void prop_weights_kmajor_kernel(PropNet n0, PropNet n1, float *__restrict__ dst) {
+    const PropNet &n = blockIdx.x == 0 ? n0 : n1;
+    float *d = dst + blockIdx.x * kPropWFloats;
+    const int in = 2 * n.g.num_levels;
+    for (int e = threadIdx.x; e < kPropWFloats; e += blockDim.x) {
+        float v = 0.0f;
+        if (in == 10) {
+            if (e < 160) v = n.w0[(e & 15) * 10 + (e >> 4)];
+            else if (e < 176) v = n.b0[e - 160];
+            else if (e < 192) v = n.w1[e - 176];
+            else if (e == 192) v = n.b1[0];
+        }
+        d[e] = v;
+    }
+}
+
+// density of the 5-level / 16-hidden proposal net with the weights as SCALAR operands in k-major order: per input feature
+// eight packed FMAs (v_pk_fma_f32, SGPR-pair source) update the 16 hidden units.  Per hidden unit the accumulation order is
+// bias, then the features in level order — the order of hidden_from_grid: bit-identical results.
+template <bool FAST>
+__device__ __forceinline__ float proposal_density_kmajor(const Grid &g, const tn_cfloat *wk, float avg, float px, float py,
+                                                         float pz, float sel) {
+    float2 f[5];
+    if (g.num_dense == 0) {
+#pragma unroll
+        for (int l = 0; l < 5; ++l) f[l] = encode_level<false, FAST>(g, l, px, py, pz);
+    } else {
+#pragma unroll
+        for (int l = 0; l < 5; ++l) f[l] = encode_level_any<FAST>(g, l, px, py, pz);
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(4))) const f32x2 cf32x2;
+    const cf32x2 *wk2 = (const cf32x2 *)wk;  // 8-byte aligned: the copy starts 256 B into the workspace's mid region
+    f32x2 hid[PH / 2];
+#pragma unroll
+    for (int j = 0; j < PH / 2; ++j) hid[j] = wk2[80 + j];
+#pragma unroll
+    for (int l = 0; l < 5; ++l) {
+        const f32x2 fx = {f[l].x, f[l].x}, fy = {f[l].y, f[l].y};
+#pragma unroll
+        for (int j = 0; j < PH / 2; ++j) hid[j] = __builtin_elementwise_fma(wk2[(2 * l) * (PH / 2) + j], fx, hid[j]);
+#pragma unroll
+        for (int j = 0; j < PH / 2; ++j) hid[j] = __builtin_elementwise_fma(wk2[(2 * l + 1) * (PH / 2) + j], fy, hid[j]);
+    }
+    float o = wk[192];
+#pragma unroll
+    for (int j = 0; j < PH / 2; ++j) {
+        o = fmaf(wk[176 + 2 * j], fmaxf(hid[j].x, 0.0f), o);
+        o = fmaf(wk[176 + 2 * j + 1], fmaxf(hid[j].y, 0.0f), o);
+    }
+    return mul_rn(mul_rn(avg, t_exp<FAST>(o)), sel);
+}
+
 // proposal_rays_kernel: the same two fused proposal levels with lane = RAY (one wave64 owns 64 consecutive rays and
 // walks their samples in lock-step), like the field kernel:
 //   * adjacent rays at one sample index share hash-grid cells -> coherent gathers;
@@ -326,9 +384,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp0, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                            frustum_pos(oz, dz, st, en), px, py, pz);
-                const float dens = fast0 ? proposal_density_scalar<PH, 5, true>(a.net[0].g, as_scalar(a.net[0].w0), as_scalar(a.net[0].b0),
-                                                                                as_scalar(a.net[0].w1), as_scalar(a.net[0].b1),
-                                                                                a.net[0].avg, px, py, pz, sel)
+                const float dens = fast0 ? proposal_density_kmajor<true>(a.net[0].g, as_scalar(a.wk), a.net[0].avg, px, py, pz, sel)
                                          : proposal_density_eval<PH, 0, true>(a.net[0].g, w0, a.net[0].avg, px, py, pz, sel);
                 const float dd = mul_rn(sub_rn(en, st), dens);
                 const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
@@ -367,9 +423,8 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp1, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                            frustum_pos(oz, dz, st, en), px, py, pz);
-                const float dens = fast1 ? proposal_density_scalar<PH, 5, true>(a.net[1].g, as_scalar(a.net[1].w0), as_scalar(a.net[1].b0),
-                                                                                as_scalar(a.net[1].w1), as_scalar(a.net[1].b1),
-                                                                                a.net[1].avg, px, py, pz, sel)
+                const float dens = fast1 ? proposal_density_kmajor<true>(a.net[1].g, as_scalar(a.wk + kPropWFloats), a.net[1].avg, px, py,
+                                                                         pz, sel)
                                          : proposal_density_eval<PH, 0, true>(a.net[1].g, w1, a.net[1].avg, px, py, pz, sel);
                 const float dd = mul_rn(sub_rn(en, st), dens);
                 const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
@@ -573,11 +628,12 @@ extern "C" {
 
 size_t tn_render_workspace_bytes(const tn_render_config *cfg, int64_t num_rays) {
     if (!cfg || num_rays < 0) return 0;
-    // [final edges, ray-tiled] [256 B: depth min/max + spare] [proposal scratch: level weights + level-1 edges, ray-tiled]
+    // [final edges, ray-tiled] [kWsMid B: depth min/max (8 B) | at +256: the proposal MLPs' k-major weight copies]
+    // [proposal scratch: level weights + level-1 edges, ray-tiled]
     const size_t tiles = (size_t)((num_rays + 63) >> 6);
     const int P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1];
     const size_t nmax = (size_t)(P0 > P1 ? P0 : P1);
-    return align_up(tn_ws_bin_floats(num_rays, cfg->num_nerf_samples) * sizeof(float), 256) + 256 +
+    return align_up(tn_ws_bin_floats(num_rays, cfg->num_nerf_samples) * sizeof(float), 256) + kWsMid +
            tiles * 64 * (nmax + (size_t)P1 + 1) * sizeof(float);
 }
 
@@ -630,6 +686,12 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         return TN_ERR_LAUNCH;
     // lane = ray needs >= ~1250 tiles to fill the chip (a tile marches its 64 rays serially: 1.1 ms whatever the count);
     // below ~80 k rays one wave per ray finishes sooner (4096 rays: 0.08 vs 1.1 ms).  Env switches force either form.
+    {   // k-major weight copies for the scalar-operand MLP of both kernel forms (two tiny blocks, same stream)
+        float *wk = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                              align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256) + 256);
+        hipLaunchKernelGGL(prop_weights_kmajor_kernel, dim3(2), dim3(256), 0, s, pa.net[0], pa.net[1], wk);
+        pa.wk = wk;
+    }
     const bool small_call = cfg->kernel_family == 2 ||
                             (cfg->kernel_family == 0 && num_rays < 81920 && !getenv("TN_FORCE_LANE_RAY"));
     if (!getenv("TN_PROPOSAL_PER_RAY") && !small_call) {
@@ -637,7 +699,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         PropRaysArgs ra;
         ra.p = pa;
         ra.nmax = nmax;
-        char *scratch = reinterpret_cast<char *>(workspace) + align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256) + 256;
+        char *scratch = reinterpret_cast<char *>(workspace) + align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256) + kWsMid;
         const size_t tiles = (size_t)((num_rays + 63) >> 6);
         ra.w_scratch = reinterpret_cast<float *>(scratch);
         ra.b1_scratch = ra.w_scratch + tiles * 64 * (size_t)nmax;
