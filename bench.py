@@ -327,6 +327,22 @@ def main():
                     "value": v, "unit": "rays/s", "rgb_mae": float((g_rgb - want["rgb"]).abs().mean()),
                     "thermal_mae": float((g_th - want["thermal"]).abs().mean())}}
                 model.config.mlp_precision = "f32"
+                if args.early_eps <= 0:
+                    # opt-in early ray termination (wave-wide transmittance vote), exact-fp32 kernels; outputs move by <= eps
+                    engine.rc.early_stop_transmittance = 1e-3
+                    engine.render(o, d, out=out)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        engine.render(o, d, out=out)
+                    torch.cuda.synchronize()
+                    v = 3 * n_rays / (time.perf_counter() - t1)
+                    g_rgb, g_th = out["rgb"][idx.to(dev)].cpu(), out["thermal"][idx.to(dev)].cpu()
+                    line["variants"]["early_termination_1e-3"] = {
+                        "what": "early_termination_eps=1e-3 (a 64-ray tile stops once every ray's transmittance is below it)",
+                        "value": v, "unit": "rays/s", "rgb_mae": float((g_rgb - want["rgb"]).abs().mean()),
+                        "thermal_mae": float((g_th - want["thermal"]).abs().mean())}
+                    engine.rc.early_stop_transmittance = 0.0
                 del engine, out
                 torch.cuda.empty_cache()
                 line["variants"]["train_step"] = measure_train_step(dev, 48)
