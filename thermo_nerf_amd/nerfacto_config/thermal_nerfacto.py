@@ -76,7 +76,8 @@ class NerfactoModelConfig:
     """Use the MFMA form of the main-field kernel when the library provides it."""
     early_termination_eps: float = 0.0
     """eval only; > 0: a wave of 64 rays stops marching once every ray's transmittance is below this value
-    (outputs move by <= eps; 0 = off = the reference's behaviour)."""
+    (outputs move by <= eps; 0 = off = the reference's behaviour).  Only the lane = ray kernels (calls of ~60 k rays and
+    more) implement it; smaller calls run one ray per wave and render exactly."""
     mlp_precision: Literal["f32", "f16x3"] = "f32"
     """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "f16x3": eval-only, every fp32 product evaluated as three f16
     MFMA products accumulated in fp32 (~2^-22 relative product error; activations must stay below 65504)."""
