@@ -158,7 +158,7 @@ def test_distortion_loss_and_gradient(n):
     assert rel(wd.grad, w.grad) <= 2e-5
 
 
-@pytest.mark.parametrize("ns", [(256, 96, 48), (64, 300, 192), (5, 7, 3)])
+@pytest.mark.parametrize("ns", [(256, 96, 48), (64, 300, 192), (5, 7, 3), (1024, 1000, 1024)])
 def test_interlevel_loss_and_gradient(ns):
     lv = _levels(23, ns, sum(ns))
     ws = [w.clone().requires_grad_(True) for _, w in lv]
@@ -174,8 +174,9 @@ def test_interlevel_loss_and_gradient(ns):
     got = TR.interlevel_loss(wd, [rs(s) for s, _ in lv])
     got.backward()
     assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-9
+    tol = 2e-5 if max(ns) <= 512 else 1e-4  # reverse prefix sums over up to 1024 fp32 terms
     for a, b in zip(wd[:-1], ws[:-1]):
-        assert rel(a.grad, b.grad) <= 2e-5
+        assert rel(a.grad, b.grad) <= tol
     assert wd[-1].grad is None and ws[-1].grad is None  # the final level is detached in this loss
 
 
