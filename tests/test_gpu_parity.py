@@ -518,7 +518,7 @@ def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
 
 
 @pytest.mark.parametrize("P,S", [((256, 96), 1), ((256, 96), 2), ((256, 96), 256), ((1, 1), 3), ((2, 256), 64), ((256, 256), 33),
-                                 ((7, 5), 65)])
+                                 ((7, 5), 65), ((1024, 1024), 1024)])
 @pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
 def test_extreme_sample_counts(monkeypatch, P, S, family):
     """Smallest and largest per-level sample counts the kernels accept, for both kernel families."""
