@@ -176,8 +176,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        # TN_BENCH_BACKEND=gloo: exercise the N > 1 code path with several ranks sharing one GPU (RCCL refuses that);
+        # the default is "nccl" = RCCL, one GPU per rank
+        backend = os.environ.get("TN_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback exists in thermo_nerf_amd)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
