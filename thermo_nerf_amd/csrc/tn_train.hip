@@ -704,36 +704,52 @@ struct CinArgs {
     int num_images, app_dim, geo_dim, use_avg, sh_shifted, training;
 };
 
+// one thread per (sample, 4-float column group): coalesced 16-byte stores of the [N,64] rows
 __global__ void __launch_bounds__(kBlock)
 color_input_fwd_kernel(CinArgs a, const float *__restrict__ dirs, const float *__restrict__ geo, int ld_geo,
                        const int *__restrict__ cams, long long R, int n, float *__restrict__ cin) {
-    const long long total = R * n;
+    const long long total = R * n * 16;
+    const int g0 = 16, a0 = 16 + a.geo_dim, end = a0 + a.app_dim;
     for (long long t = (long long)blockIdx.x * kBlock + threadIdx.x; t < total; t += (long long)gridDim.x * kBlock) {
-        const long long r = t / n;
-        float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
-        if (a.sh_shifted) {
-            dx = add_rn(dx, 1.0f) / 2.0f; dy = add_rn(dy, 1.0f) / 2.0f; dz = add_rn(dz, 1.0f) / 2.0f;
-        }
-        float c[16];
-        sh16(dx, dy, dz, c);
-        float *o = cin + t * 64;
+        const long long smp = t >> 4;
+        const int c0 = (int)(t & 15) * 4;
+        const long long r = smp / n;
+        float v[4];
+        if (c0 < 16) {
+            float dx = dirs[r * 3], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+            if (a.sh_shifted) {
+                dx = add_rn(dx, 1.0f) / 2.0f; dy = add_rn(dy, 1.0f) / 2.0f; dz = add_rn(dz, 1.0f) / 2.0f;
+            }
+            float c[16];
+            sh16(dx, dy, dz, c);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) o[k] = c[k];
-        for (int k = 0; k < a.geo_dim; ++k) o[16 + k] = geo[t * ld_geo + k];
-        float *oa = o + 16 + a.geo_dim;
-        if (a.training) {
-            const float *e = a.appearance + (size_t)cams[r] * a.app_dim;
-            for (int k = 0; k < a.app_dim; ++k) oa[k] = e[k];
-        } else if (a.use_avg) {
-            for (int k = 0; k < a.app_dim; ++k) {
-                float s = 0.0f;
-                for (int j = 0; j < a.num_images; ++j) s += a.appearance[(size_t)j * a.app_dim + k];
-                oa[k] = s / (float)a.num_images;
+            for (int q = 0; q < 4; ++q) {
+                float x = c[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) x = (c0 + q == k) ? c[k] : x;
+                v[q] = x;
             }
         } else {
-            for (int k = 0; k < a.app_dim; ++k) oa[k] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = c0 + q;
+                float x = 0.0f;
+                if (k >= g0 && k < a0) {
+                    x = geo[smp * ld_geo + (k - g0)];
+                } else if (k >= a0 && k < end) {
+                    const int j = k - a0;
+                    if (a.training) {
+                        x = a.appearance[(size_t)cams[r] * a.app_dim + j];
+                    } else if (a.use_avg) {
+                        float sum = 0.0f;
+                        for (int im = 0; im < a.num_images; ++im) sum += a.appearance[(size_t)im * a.app_dim + j];
+                        x = sum / (float)a.num_images;
+                    }
+                }
+                v[q] = x;
+            }
         }
-        for (int k = 16 + a.geo_dim + a.app_dim; k < 64; ++k) o[k] = 0.0f;
+        *reinterpret_cast<float4 *>(cin + smp * 64 + c0) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -1123,7 +1139,7 @@ int tn_color_input_fwd(const tn_thermal_field *field, const float *directions, c
     if (num_rays == 0) return TN_OK;
     if (!directions || !geo || !cin || (training && !camera_indices)) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1 || ld_geo < a.geo_dim) return TN_ERR_SHAPE;
-    hipLaunchKernelGGL(color_input_fwd_kernel, dim3(grid_for(num_rays * n, kBlock, 1 << 16)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(color_input_fwd_kernel, dim3(grid_for(num_rays * n * 16, kBlock, 1 << 16)), dim3(kBlock), 0,
                        (hipStream_t)stream, a, directions, geo, ld_geo, camera_indices, (long long)num_rays, n, cin);
     TN_LAUNCH_CHECK();
     return TN_OK;
