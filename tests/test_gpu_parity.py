@@ -565,3 +565,44 @@ def test_degenerate_rays(monkeypatch, family):
     for k in ("rgb", "thermal", "accumulation"):
         assert torch.isfinite(got[k]).all(), k
     check_outputs(got, want, f"degenerate rays {family}")
+
+
+def test_full_frame_properties(monkeypatch):
+    """BASELINE config 2 at full size (800x800 = 640 000 rays, S=64, full-size tables): size-independent properties of the
+    path — idempotence, independence from chunking / stream scheduling, equivariance under a permutation of the rays —
+    plus the oracle on a strided sample of the same frame."""
+    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    monkeypatch.delenv("TN_FORCE_LANE_RAY")  # let every call pick its kernel family by size, as in production
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=64)
+    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+    synthetic.fill_model_(model, "scene")
+    sd = synthetic.model_state_dict_cpu(model)
+    model.to(DEV).eval()
+    o, d, _ = synthetic.orbit_camera_rays(800, 800, view=1)
+    o, d = o.reshape(-1, 3).contiguous().to(DEV), d.reshape(-1, 3).contiguous().to(DEV)
+    n = o.shape[0]
+    whole = RayRenderEngine(model, chunk=n)
+    a = {k: v.clone() for k, v in whole.render(o, d).items()}
+    b = whole.render(o, d)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: not idempotent"
+    # chunked on two streams: per-ray results do not depend on how the frame is cut (expected depth clips per chunk)
+    c = RayRenderEngine(model, chunk=65536).render(o, d)
+    torch.cuda.synchronize()
+    for k in ("rgb", "thermal", "accumulation", "depth", "prop_depth_0", "prop_depth_1"):
+        assert torch.equal(a[k], c[k]), f"{k}: depends on chunking"
+    # permutation equivariance: rays are independent, whatever their neighbours in the 64-ray tile
+    perm = torch.randperm(n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    p = whole.render(o[perm].contiguous(), d[perm].contiguous())
+    torch.cuda.synchronize()
+    for k in ("rgb", "thermal", "accumulation", "depth"):
+        assert torch.equal(p[k], a[k][perm]), f"{k}: depends on the ray order"
+    # the oracle on a strided sample
+    idx = torch.linspace(0, n - 1, 1500).long()
+    want = H.get_outputs(sd, o[idx.to(DEV)].cpu(), d[idx.to(DEV)].cpu(), None, helpers.oracle_config(cfg))
+    assert (a["rgb"][idx.to(DEV)].cpu() - want["rgb"]).abs().mean().item() <= 1e-4
+    assert (a["thermal"][idx.to(DEV)].cpu() - want["thermal"]).abs().mean().item() <= 1e-4
+    assert (a["accumulation"][idx.to(DEV)].cpu() - want["accumulation"]).abs().max().item() <= 2e-5
