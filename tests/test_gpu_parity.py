@@ -24,17 +24,15 @@ THERMAL_MAE = 1e-4
 DEPTH_REL = 1e-4
 
 
-@pytest.fixture(autouse=True)
-def lane_ray_kernels(monkeypatch):
+def gpu_model(kind="stress", S=48, small=True, family="lane_ray", **over):
     """The library picks the kernel family by call size (lane = ray from ~60-80 k rays up, one ray per wave below).  The
-    tests in this module use a few hundred rays but target the throughput (lane = ray) kernels, so they force them;
-    test_small_calls_take_the_ray_per_wave_kernels covers the automatic choice."""
-    monkeypatch.setenv("TN_FORCE_LANE_RAY", "1")
-
-
-def gpu_model(kind="stress", S=48, small=True, **over):
+    tests in this module use a few hundred rays but target the throughput (lane = ray) kernels, so the models they build
+    ask for them through ``config.kernel_family`` (-> ``tn_render_config.kernel_family``; the library reads no environment
+    variable); ``family="auto"`` / ``"ray_per_wave"`` cover the automatic choice and the other form."""
     model, sd, ocfg = helpers.build(kind, S, small, **over)
-    return copy.deepcopy(model).to(DEV).eval(), sd, ocfg
+    gm = copy.deepcopy(model).to(DEV).eval()
+    gm.config.kernel_family = family
+    return gm, sd, ocfg
 
 
 def bundle(o, d, cam=None):
@@ -484,7 +482,7 @@ def test_engine_chunks_on_two_streams_match_one_stream():
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
+def test_small_calls_take_the_ray_per_wave_kernels(precision):
     """Automatic dispatch: below ~60-80 k rays the one-ray-per-wave kernels run (a 64-ray tile marches serially, so the
     lane = ray kernels have a ~2.6 ms floor).  Same oracle tolerances; with f16x3 a small call is served in exact fp32."""
     import time
@@ -495,7 +493,7 @@ def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
     want = H.get_outputs(sd, o, d, None, ocfg)
     with torch.no_grad():
         forced = {k: v.clone() for k, v in gm(bundle(o, d)).items()}
-        monkeypatch.delenv("TN_FORCE_LANE_RAY")
+        gm.config.kernel_family = "auto"
         auto = gm(bundle(o, d))
         check_outputs(auto, want, f"auto dispatch {precision}")
         for k in ("rgb", "thermal"):
@@ -512,7 +510,7 @@ def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
                 best = min(best, (time.perf_counter() - t) / 5)
             return best
         t_auto = timed()
-        monkeypatch.setenv("TN_FORCE_LANE_RAY", "1")
+        gm.config.kernel_family = "lane_ray"
         t_forced = timed()
     assert t_auto < t_forced, (t_auto, t_forced)
 
@@ -520,11 +518,9 @@ def test_small_calls_take_the_ray_per_wave_kernels(monkeypatch, precision):
 @pytest.mark.parametrize("P,S", [((256, 96), 1), ((256, 96), 2), ((256, 96), 256), ((1, 1), 3), ((2, 256), 64), ((256, 256), 33),
                                  ((7, 5), 65), ((1024, 1024), 1024)])
 @pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
-def test_extreme_sample_counts(monkeypatch, P, S, family):
+def test_extreme_sample_counts(P, S, family):
     """Smallest and largest per-level sample counts the kernels accept, for both kernel families."""
-    if family == "ray_per_wave":
-        monkeypatch.delenv("TN_FORCE_LANE_RAY")
-    gm, sd, ocfg = gpu_model("stress", S, num_proposal_samples_per_ray=P)
+    gm, sd, ocfg = gpu_model("stress", S, family=family, num_proposal_samples_per_ray=P)
     gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f32"
     o, d = helpers.rays(11, 13, view=2)
     want = H.get_outputs(sd, o, d, None, ocfg)
@@ -545,12 +541,10 @@ def test_sample_counts_beyond_the_kernel_limits_are_refused():
 
 
 @pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
-def test_degenerate_rays(monkeypatch, family):
+def test_degenerate_rays(family):
     """Axis-aligned directions, origins on exact grid points (ceil == floor corners), origins far outside the scene,
     rays that never enter the unit box."""
-    if family == "ray_per_wave":
-        monkeypatch.delenv("TN_FORCE_LANE_RAY")
-    gm, sd, ocfg = gpu_model("stress", 64)
+    gm, sd, ocfg = gpu_model("stress", 64, family=family)
     gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f32"
     axes = torch.tensor([[1.0, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
     o = torch.cat([torch.zeros(6, 3), torch.full((6, 3), 0.5), torch.tensor([[40.0, -25.0, 3.0]]).repeat(6, 1),
@@ -567,14 +561,14 @@ def test_degenerate_rays(monkeypatch, family):
     check_outputs(got, want, f"degenerate rays {family}")
 
 
-def test_full_frame_properties(monkeypatch):
+def test_full_frame_properties():
     """BASELINE config 2 at full size (800x800 = 640 000 rays, S=64, full-size tables): size-independent properties of the
     path — idempotence, independence from chunking / stream scheduling, equivariance under a permutation of the rays —
     plus the oracle on a strided sample of the same frame."""
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.engine import RayRenderEngine
 
-    monkeypatch.delenv("TN_FORCE_LANE_RAY")  # let every call pick its kernel family by size, as in production
+    # config.kernel_family stays "auto": every call picks its kernel family by size, as in production
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=64)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, "scene")

@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _hip.load().tn_version()
 
 
+def test_library_reads_no_environment_variables():
+    """The header promises no mutable global state: the kernel family is chosen through tn_render_config.kernel_family,
+    never through the process environment (no getenv import, no TN_* switch names in the binary)."""
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _hip.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    blob = open(_hip.lib_path(), "rb").read()
+    for name in (b"TN_FORCE_LANE_RAY", b"TN_FORCE_RAY_PER_WAVE", b"TN_PROPOSAL_PER_RAY"):
+        assert name not in blob, name
+
+
 def test_struct_sizes_match_header_layout():
     # sizes computed from the header's field order (LP64): catches drift between header and ctypes mirror
     assert ctypes.sizeof(_hip.tn_hashgrid) == 8 + 64 + 4 + 4 + 8 + 128 + 64 + 4 + 4

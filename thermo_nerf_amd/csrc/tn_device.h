@@ -267,6 +267,30 @@ static inline int tn_check_grid(const tn_hashgrid &h) {
     return TN_OK;
 }
 
+// Opt a kernel in to `bytes` of dynamic LDS (> 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute is a
+// property of the loaded code object per device, so it is set ONCE per process, device and kernel (the largest size granted
+// so far is remembered) instead of on every launch: an immutable, idempotent initialisation, not mutable library state.
+#ifdef __HIPCC__
+#include <atomic>
+template <auto Kernel>
+static inline bool tn_ensure_dynamic_lds(size_t bytes) {
+    constexpr int kMaxDev = 64;
+    static std::atomic<size_t> granted[kMaxDev];
+    int dev = 0;
+    const bool cached = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev;
+    if (cached && granted[dev].load(std::memory_order_acquire) >= bytes) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+        hipSuccess)
+        return false;
+    if (cached) {
+        size_t cur = granted[dev].load(std::memory_order_relaxed);
+        while (cur < bytes && !granted[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {
+        }
+    }
+    return true;
+}
+#endif
+
 #define TN_LAUNCH_CHECK()                                  \
     do {                                                   \
         if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH; \

@@ -133,9 +133,7 @@ int tn_field_heads_fwd(const tn_thermal_field *f, const float *directions, const
     if (n == 0) return TN_OK;
     const HeadsArgs a = make_heads_args(f);
     const size_t smem = (size_t)heads_floats(f->geo_feat_dim, f->app_dim) * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(field_heads_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return TN_ERR_LAUNCH;
+    if (!tn_ensure_dynamic_lds<field_heads_kernel>(smem)) return TN_ERR_LAUNCH;
     hipLaunchKernelGGL(field_heads_kernel, dim3(grid_for(n)), dim3(kBlock), smem, (hipStream_t)stream, a, directions, geo,
                        camera_indices, (long long)n, training, rgb, thermal);
     TN_LAUNCH_CHECK();

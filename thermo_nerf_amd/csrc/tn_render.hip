@@ -219,7 +219,12 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
 // ------------------------------------------------------------------------------------------------------
 // k-major copy of a 10 -> 16 -> 1 proposal MLP for the scalar-operand evaluation below: W0t[k][h] = W0[h][k], so that the
 // two weights of a packed FMA (hidden units 2j, 2j+1 of one input feature) are adjacent dwords of one s_load.
-__global__ void prop_weights_kmajor_kernel(PropNet n0, PropNet n1, float *__restrict__ dst) {
+// Block 0 also resets the call's depth min/max words (ordered keys): the field kernel of the same call accumulates into them.
+__global__ void prop_weights_kmajor_kernel(PropNet n0, PropNet n1, float *__restrict__ dst, unsigned *__restrict__ mm) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        mm[0] = 0xffffffffu;
+        mm[1] = 0u;
+    }
     const PropNet &n = blockIdx.x == 0 ? n0 : n1;
     float *d = dst + blockIdx.x * kPropWFloats;
     const int in = 2 * n.g.num_levels;
@@ -593,11 +598,6 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
     }
 }
 
-__global__ void minmax_init_kernel(unsigned *mm) {
-    mm[0] = 0xffffffffu;
-    mm[1] = 0u;
-}
-
 __global__ void depth_clip_kernel(float *__restrict__ expected, long long num_rays, const unsigned *mm) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= num_rays) return;
@@ -680,21 +680,18 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
     const size_t prop_smem = (size_t)(two_layer_floats(2 * prop0->grid.num_levels, PH, 1) +
                                       two_layer_floats(2 * prop1->grid.num_levels, PH, 1) +
                                       kWaves * (3 * nbmax + nmax)) * sizeof(float);
-    if (prop_smem > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)prop_smem) != hipSuccess)
-        return TN_ERR_LAUNCH;
+
     // lane = ray needs >= ~1250 tiles to fill the chip (a tile marches its 64 rays serially: 1.1 ms whatever the count);
-    // below ~80 k rays one wave per ray finishes sooner (4096 rays: 0.08 vs 1.1 ms).  Env switches force either form.
+    // below ~80 k rays one wave per ray finishes sooner (4096 rays: 0.08 vs 1.1 ms).  cfg->kernel_family forces either form.
     {   // k-major weight copies for the scalar-operand MLP of both kernel forms (two tiny blocks, same stream)
         float *wk = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
                                               align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256) + 256);
-        hipLaunchKernelGGL(prop_weights_kmajor_kernel, dim3(2), dim3(256), 0, s, pa.net[0], pa.net[1], wk);
+        hipLaunchKernelGGL(prop_weights_kmajor_kernel, dim3(2), dim3(256), 0, s, pa.net[0], pa.net[1], wk,
+                           ws_minmax(workspace, num_rays, S));
         pa.wk = wk;
     }
-    const bool small_call = cfg->kernel_family == 2 ||
-                            (cfg->kernel_family == 0 && num_rays < 81920 && !getenv("TN_FORCE_LANE_RAY"));
-    if (!getenv("TN_PROPOSAL_PER_RAY") && !small_call) {
+    const bool small_call = cfg->kernel_family == 2 || (cfg->kernel_family == 0 && num_rays < 81920);
+    if (!small_call) {
         // lane = ray
         PropRaysArgs ra;
         ra.p = pa;
@@ -712,6 +709,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
+    if (prop_smem > 64 * 1024 && !tn_ensure_dynamic_lds<proposal_kernel>(prop_smem)) return TN_ERR_LAUNCH;
     hipLaunchKernelGGL(proposal_kernel, dim3(ray_grid(num_rays, 8)), dim3(kBlock), prop_smem, s, pa, nmax, nbmax);
     TN_LAUNCH_CHECK();
     return TN_OK;
@@ -732,10 +730,11 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
     hipStream_t s = (hipStream_t)stream;
     const float *ws_spacing = reinterpret_cast<const float *>(workspace);
     unsigned *minmax = ws_minmax(workspace, num_rays, S);
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, minmax);
+    // minmax was reset by tn_proposal_sample_fwd, which filled this workspace; the bounds are a function of the edges in
+    // it alone, so re-running the field kernel on the same workspace re-derives the same two values (atomic min/max)
     // the split-precision kernel only exists in the lane = ray form: small calls take the exact-fp32 ray-per-wave kernel
     if (field->prepared_f16x3 && !cfg->training && !out->weights[2] && cfg->kernel_family != 2 &&
-        (num_rays >= 40960 || cfg->kernel_family == 1 || getenv("TN_FORCE_LANE_RAY"))) {
+        (num_rays >= 40960 || cfg->kernel_family == 1)) {
         TN_TRY(launch_main_h3(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
     } else if (field->prepared) {
         TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
@@ -754,9 +753,7 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
         ma.thermal = out->thermal; ma.out_w = out->weights[2]; ma.minmax = minmax;
         const size_t main_smem = (size_t)(two_layer_floats(2 * field->grid.num_levels, HW, 1 + GF) +
                                           heads_floats(GF, field->app_dim)) * sizeof(float);
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_valu_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)main_smem) != hipSuccess)
-            return TN_ERR_LAUNCH;
+        if (!tn_ensure_dynamic_lds<main_valu_kernel>(main_smem)) return TN_ERR_LAUNCH;
         hipLaunchKernelGGL(main_valu_kernel, dim3(ray_grid(num_rays, 2)), dim3(kBlock), main_smem, s, ma);
         TN_LAUNCH_CHECK();
     }

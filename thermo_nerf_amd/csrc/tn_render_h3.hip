@@ -471,9 +471,7 @@ int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, c
     a.thermal = out->thermal; a.minmax = minmax;
     a.early_eps = fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
     const size_t smem = (size_t)H_BLOB_FLOATS * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_h3_rays_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
-        return TN_ERR_LAUNCH;
+    if (!tn_ensure_dynamic_lds<main_h3_rays_kernel>(smem)) return TN_ERR_LAUNCH;
     const long long groups = (num_rays + 63) / 64;
     const long long need = (groups + kWaves - 1) / kWaves;
     const long long cap = 256LL * 2;

@@ -664,18 +664,12 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     a.thermal = out->thermal; a.out_w = out->weights[2]; a.minmax = minmax;
     a.early_eps = cfg->training ? 0.0f : fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
-        return TN_ERR_LAUNCH;
     const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 77 KB each)
     // 1.5 ms floor of the tile march vs 0.16 ms at 4096 rays
-    const bool small_call = cfg->kernel_family == 2 ||
-                            (cfg->kernel_family == 0 && num_rays < 57344 && !getenv("TN_FORCE_LANE_RAY"));
-    if (!cfg->training && !out->weights[2] && !getenv("TN_FORCE_RAY_PER_WAVE") && !small_call) {
+    const bool small_call = cfg->kernel_family == 2 || (cfg->kernel_family == 0 && num_rays < 57344);
+    if (!cfg->training && !out->weights[2] && !small_call) {
         // eval: lane = ray (64 consecutive rays per wave), coherent gathers
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(main_mfma_rays_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return TN_ERR_LAUNCH;
+        if (!tn_ensure_dynamic_lds<main_mfma_rays_kernel>(smem)) return TN_ERR_LAUNCH;
         const long long groups = (num_rays + 63) / 64;
         const long long need = (groups + kWaves - 1) / kWaves;
         const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
@@ -683,6 +677,7 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
         if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
         return TN_OK;
     }
+    if (!tn_ensure_dynamic_lds<main_mfma_kernel>(smem)) return TN_ERR_LAUNCH;
     const long long need = (num_rays + kWaves - 1) / kWaves;
     const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
     hipLaunchKernelGGL(main_mfma_kernel, dim3(grid), dim3(kBlock), smem, stream, a);

@@ -1192,10 +1192,7 @@ int tn_interlevel_loss(const float *c, const float *w, const float *cp, const fl
     if (!c || !w || !cp || !wp || !loss_sum || !d_wp) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1 || p < 1 || p > kMaxP) return TN_ERR_SHAPE;
     const size_t lds = (size_t)(kBlock / 64) * 4 * (p + 2) * sizeof(float);
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(interlevel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return TN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && !tn_ensure_dynamic_lds<interlevel_kernel>(lds)) return TN_ERR_LAUNCH;
     hipLaunchKernelGGL(interlevel_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), lds, (hipStream_t)stream, c, w,
                        cp, wp, (long long)num_rays, n, p, loss_sum, d_wp);
     TN_LAUNCH_CHECK();

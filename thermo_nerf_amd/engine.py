@@ -15,6 +15,7 @@ from torch import Tensor
 
 from . import _hip
 from .samplers import linspace_bins, pdf_positions
+from .nerfacto_config.thermal_nerfacto import KERNEL_FAMILY
 from .thermal_nerf.thermal_nerf_model import ThermalNerfModel
 
 OUTPUT_KEYS = ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal")
@@ -89,7 +90,8 @@ class RayRenderEngine:
         wsn = self._ws.shape[1]
         multi = self.num_streams > 1 and n > self.chunk
         # chunks overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
-        self.rc.kernel_family = 1 if (multi and self.chunk >= 49152) else 0
+        family = KERNEL_FAMILY[self.model.config.kernel_family]
+        self.rc.kernel_family = 1 if (family == 0 and multi and self.chunk >= 49152) else family
         current = torch.cuda.current_stream(dev)
         if multi:
             for st in self._streams:

@@ -78,6 +78,9 @@ class NerfactoModelConfig:
     """eval only; > 0: a wave of 64 rays stops marching once every ray's transmittance is below this value
     (outputs move by <= eps; 0 = off = the reference's behaviour).  Only the lane = ray kernels (calls of ~60 k rays and
     more) implement it; smaller calls run one ray per wave and render exactly."""
+    kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
+    """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
+    one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""
     mlp_precision: Literal["f32", "f16x3"] = "f32"
     """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "f16x3": eval-only, every fp32 product evaluated as three f16
     MFMA products accumulated in fp32 (~2^-22 relative product error; activations must stay below 65504)."""
@@ -95,6 +98,9 @@ class ThermalNerfactoModelConfig(NerfactoModelConfig):
     min_temperature: float = 0.0
     cold: bool = False
     camera_optimizer_mode: Literal["off", "SO3xR3", "SE3"] = "SO3xR3"
+
+
+KERNEL_FAMILY = {"auto": 0, "lane_ray": 1, "ray_per_wave": 2}
 
 
 class ThermalNerfactoModel(nn.Module):

@@ -22,7 +22,7 @@ from torch import Tensor, nn
 
 from .. import _hip
 from ..fields import FieldHeadNames, HashMLPDensityField
-from ..nerfacto_config.thermal_nerfacto import ThermalNerfactoModel, ThermalNerfactoModelConfig
+from ..nerfacto_config.thermal_nerfacto import KERNEL_FAMILY, ThermalNerfactoModel, ThermalNerfactoModelConfig
 from ..rays import RayBundle, RaySamples
 from ..rendered_image_modalities import RenderedImageModality
 from ..renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
@@ -298,6 +298,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         rc.training = 1 if training else 0
         rc.pdf_anneal = float(self.proposal_sampler._anneal)
         rc.early_stop_transmittance = 0.0 if training else float(cfg.early_termination_eps)
+        rc.kernel_family = KERNEL_FAMILY[cfg.kernel_family]
 
         ins = _hip.tn_render_inputs()
         ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()

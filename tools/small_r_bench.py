@@ -1,5 +1,5 @@
 """Render time vs ray count for the two kernel families (lane = ray / one ray per wave).
-usage: python tools/small_r_bench.py   (env TN_PROPOSAL_PER_RAY=1 TN_FORCE_RAY_PER_WAVE=1 selects ray-per-wave)"""
+usage: python tools/small_r_bench.py [auto|lane_ray|ray_per_wave]   (config.kernel_family; default auto)"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, 
 from thermo_nerf_amd.engine import RayRenderEngine  # noqa: E402
 
 dev = torch.device("cuda:0")
-cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=64)
+cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=64, kernel_family=sys.argv[1] if len(sys.argv) > 1 else "auto")
 model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
 synthetic.fill_model_(model, "scene")
 model.to(dev).eval()
