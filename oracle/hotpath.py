@@ -61,6 +61,10 @@ class OracleConfig:
     average_init_density: float = 1.0
     # SURVEY Appendix A.6 [UNSURE]: torch-fallback SHEncoding receives (d+1)/2 unmodified.
     sh_input: str = "shifted"  # "shifted" | "unit"
+    # NS SHEncoding.pytorch_fwd is decorated @torch.no_grad() — in the torch fallback the SH basis is a
+    # constant of the graph and no gradient reaches the ray directions through it.  True = differentiate through the basis
+    # (what a tcnn SH encoding does); the product mirrors this switch as config.sh_direction_gradient.
+    sh_grad: bool = False
 
 
 # ----------------------------------------------------------------------------------------------
@@ -250,7 +254,11 @@ def field_outputs(
     d = (directions + 1.0) / 2.0  # NS get_normalized_directions [REF :117]
     d_flat = d.reshape(-1, 3)
     enc_in = d_flat if cfg.sh_input == "shifted" else directions.reshape(-1, 3)
-    d_enc = sh4(enc_in)  # [REF :119]
+    if cfg.sh_grad:
+        d_enc = sh4(enc_in)  # [REF :119]
+    else:
+        with torch.no_grad():  # NS SHEncoding.pytorch_fwd runs under @torch.no_grad()
+            d_enc = sh4(enc_in)  # [REF :119]
     emb = sd["field.embedding_appearance.embedding.weight"]
     if training:
         app = emb[camera_indices.reshape(-1)]  # [REF :124-125]

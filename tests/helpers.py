@@ -26,6 +26,7 @@ def oracle_config(cfg: ThermalNerfModelConfig) -> H.OracleConfig:
         num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         use_average_appearance_embedding=cfg.use_average_appearance_embedding,
         disable_scene_contraction=cfg.disable_scene_contraction, sh_input=cfg.sh_input,
+        sh_grad=cfg.sh_direction_gradient,
     )
 
 

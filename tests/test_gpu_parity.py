@@ -143,6 +143,77 @@ def test_thermal_renderer_golden_g1(golden_dir):
     np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=2e-6)
 
 
+def test_rgb_renderer_golden_g4(golden_dir):
+    """Against outputs of the REAL reference RGBTRenderer (fixture G4: rgb_concat/rgbt_renderer.py:62-81,159-174, the
+    reference's fork of nerfstudio's RGBRenderer, background "last_sample"): tn_composite_fwd with 3 and 4 channels."""
+    g = np.load(os.path.join(golden_dir, "rgbt_renderer.npz"))
+    rgbt, w = torch.from_numpy(g["rgbt"]).to(DEV), torch.from_numpy(g["weights"]).to(DEV)
+    r = RGBRenderer(background_color="last_sample")
+    for mode in ("eval", "train"):
+        r.train(mode == "train")
+        for c, x in ((3, rgbt[..., :3].contiguous()), (4, rgbt)):
+            got, want = r(x, w).cpu().numpy(), g[f"out{c}_{mode}"]
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+            np.testing.assert_array_equal(np.isinf(got), np.isinf(want))
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=2e-6, err_msg=f"C={c} {mode}")
+
+
+def test_thermal_field_head_golden_g5(golden_dir):
+    """Against outputs of the REAL reference BaseThermalFieldHead (fixture G5: Linear 64 -> 1, no activation)."""
+    from thermo_nerf_amd.thermal_nerf.thermal_field_head import ThermalFieldHead
+
+    g = np.load(os.path.join(golden_dir, "thermal_field_head.npz"))
+    head = ThermalFieldHead(in_dim=64)
+    with torch.no_grad():
+        head.net.weight.copy_(torch.from_numpy(g["weight"]))
+        head.net.bias.copy_(torch.from_numpy(g["bias"]))
+    head.to(DEV)
+    y = head(torch.from_numpy(g["x"]).to(DEV))
+    assert_close(y, torch.from_numpy(g["y"]), 2e-6, 0, "thermal head")
+    y3 = head(torch.from_numpy(g["x"]).to(DEV).view(1, 257, 64))  # leading dims preserved like nn.Linear
+    assert y3.shape == (1, 257, 1)
+
+
+@pytest.mark.parametrize("avg", [1, 0])
+def test_field_wiring_golden_g6(golden_dir, avg):
+    """Against outputs of the REAL reference ThermalNerfactoTField.forward (fixture G6, thermal_field.py:108-201, run over
+    oracle-built nerfstudio base classes): the HIP field, loaded with the fixture's state dict, through Field.forward in
+    eval and train mode, with and without the average appearance embedding."""
+    import json
+
+    from thermo_nerf_amd import SceneContraction
+    from thermo_nerf_amd.thermal_nerf.thermal_field import ThermalNerfactoTField
+
+    g = np.load(os.path.join(golden_dir, "thermal_field_wiring.npz"))
+    c = json.loads(str(g["config"]))
+    f = ThermalNerfactoTField(torch.tensor([[-1.0] * 3, [1.0] * 3]), num_images=c["num_images"], num_levels=c["num_levels"],
+                              base_res=c["base_res"], max_res=c["max_res"], log2_hashmap_size=c["log2_hashmap_size"],
+                              use_average_appearance_embedding=bool(avg),
+                              spatial_distortion=SceneContraction(order=float("inf")), pass_thermal_gradients=True)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    missing, unexpected = f.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("max_res" in m or "num_levels" in m or "log2_hashmap_size" in m) for m in missing), missing
+    f.to(DEV)
+    pos, dirs, cam = (torch.from_numpy(g[k]).to(DEV) for k in ("positions", "directions", "camera_indices"))
+    R, S = pos.shape[:2]
+    N = R * S
+    # frustums whose get_positions() returns the fixture's positions: one sample per "ray", origin = position, start = end = 0
+    fr = Frustums(origins=pos.reshape(N, 1, 3), directions=dirs.reshape(N, 1, 3).contiguous(),
+                  starts=torch.zeros(N, 1, 1, device=DEV), ends=torch.zeros(N, 1, 1, device=DEV))
+    rs = RaySamples(frustums=fr, camera_indices=cam.reshape(N, 1, 1))
+    for mode in ("eval", "train"):
+        f.train(mode == "train")
+        with torch.no_grad():
+            out = f(rs)
+        tag = f"avg{avg}_{mode}"
+        assert set(out.keys()) == {FieldHeadNames.RGB, FieldHeadNames.DENSITY, FieldHeadNamesT.THERMAL}
+        assert_close(out[FieldHeadNames.DENSITY].view(R, S, 1), torch.from_numpy(g[f"density_{tag}"]), 1e-6, 3e-5, f"density {tag}")
+        assert_close(out[FieldHeadNames.RGB].view(R, S, 3), torch.from_numpy(g[f"rgb_{tag}"]), 5e-6, 0, f"rgb {tag}")
+        assert_close(out[FieldHeadNamesT.THERMAL].view(R, S, 1), torch.from_numpy(g[f"thermal_{tag}"]), 1e-5, 0, f"thermal {tag}")
+
+
 @pytest.mark.parametrize("n", [48, 64, 192, 3])
 def test_rgb_depth_accumulation(n):
     g = torch.Generator().manual_seed(77 + n)

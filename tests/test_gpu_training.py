@@ -295,11 +295,14 @@ def test_adam_steps_reduce_the_loss_and_eval_follows():
     assert (got["rgb"].cpu() - want["rgb"]).abs().mean().item() <= 2e-4
 
 
+@pytest.mark.parametrize("sh_grad", [False, True])
 @pytest.mark.parametrize("kind,contraction", [("stress", True), ("scene", True), ("stress", False)])
-def test_ray_gradients_match_autograd_oracle(kind, contraction):
+def test_ray_gradients_match_autograd_oracle(kind, contraction, sh_grad):
     """d loss / d (origins, directions) — what a camera optimizer backpropagates — through the sample positions of all
-    three levels (trilinear offsets, selector, contraction / AABB) and the SH basis."""
+    three levels (trilinear offsets, selector, contraction / AABB) and, with sh_direction_gradient=True, the SH basis
+    (default False: nerfstudio's torch-fallback SHEncoding.pytorch_fwd runs under no_grad)."""
     over = {} if contraction else {"disable_scene_contraction": True}
+    over["sh_direction_gradient"] = sh_grad
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, 48, **over)
     if not contraction:
         o = o * 0.6

@@ -70,6 +70,10 @@ class NerfactoModelConfig:
     nerfstudio module, mirroring the reference's call sequence)."""
     sh_input: Literal["shifted", "unit"] = "shifted"
     """Direction convention fed to the SH basis in the torch fallback (SURVEY A.6 [UNSURE])."""
+    sh_direction_gradient: bool = False
+    """Training: let d loss / d directions flow through the SH basis.  False (default) = nerfstudio's torch fallback, whose
+    SHEncoding.pytorch_fwd runs under @torch.no_grad() (SURVEY A.6): camera-pose gradients then come from the sample
+    positions only.  True = the behaviour of a differentiable (tcnn) SH encoding."""
     dense_grid_budget_mb: int = 0
     """>0: re-lay the coarse hash levels densely within this budget (layout only, bit-identical)."""
     use_mfma: bool = True

@@ -1,15 +1,19 @@
 """Thermal field head [REF thermo_nerf/thermal_nerf/thermal_field_head.py:9-71,
 thermo_nerf/thermal_nerf/thermal_field.py:18-30].
 
-The head is a parameter holder: ``net`` is the ``nn.Linear(in_dim, 1)`` whose weights the fused heads kernel
-(``tn_field_heads_fwd``) consumes; the state-dict key stays ``field_head_thermal.net.{weight,bias}``.
+``net`` is the ``nn.Linear(in_dim, 1)`` whose weights the fused heads kernel (``tn_field_heads_fwd``) consumes on the
+field's own path; called on its own, the head runs ``tn_linear_fwd`` (no activation) like the reference's
+``self.net(in_tensor)``.  The state-dict key stays ``field_head_thermal.net.{weight,bias}``.
 """
 from __future__ import annotations
 
 from enum import Enum
 from typing import Optional
 
+import torch
 from torch import nn
+
+from .. import _hip
 
 
 class FieldHeadNamesT(Enum):
@@ -40,10 +44,13 @@ class BaseThermalFieldHead(nn.Module):
     def forward(self, in_tensor):
         if self.net is None:
             raise SystemError("in_dim not set. Must be provided to constructor, or set_in_dim() should be called.")
-        raise RuntimeError(
-            "ThermalFieldHead is evaluated inside tn_field_heads_fwd together with mlp_thermal; "
-            "call ThermalNerfactoTField.get_outputs()."
-        )
+        # REF thermal_field_head.py:66-69: out = self.net(in_tensor); activation is None for the thermal head
+        x = _hip.require_device_tensor(in_tensor.reshape(-1, self.in_dim), "in_tensor")
+        n = x.shape[0]
+        y = torch.empty((n, self.out_dim), dtype=torch.float32, device=x.device)
+        _hip.check(_hip.load().tn_linear_fwd(x.data_ptr(), self.in_dim, _hip.make_linear(self.net), 0, n, y.data_ptr(),
+                                             self.out_dim, _hip.current_stream()), "tn_linear_fwd")
+        return y.view(*in_tensor.shape[:-1], self.out_dim)
 
 
 class ThermalFieldHead(BaseThermalFieldHead):

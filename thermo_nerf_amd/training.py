@@ -313,6 +313,9 @@ class RenderTrain(torch.autograd.Function):
         ray_grads = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             ray_grads = (torch.zeros_like(ctx.o), torch.zeros_like(ctx.d))
+        # NS SHEncoding.pytorch_fwd is @torch.no_grad(): by default the SH basis passes no gradient to the
+        # directions; config.sh_direction_gradient=True adds that term (a differentiable SH encoding)
+        sh_grads = ray_grads is not None and bool(cfg.sh_direction_gradient)
 
         def zeros(name: str) -> Tensor:
             grads[name] = torch.zeros_like(like[name])
@@ -359,8 +362,8 @@ class RenderTrain(torch.autograd.Function):
                        zeros("field.mlp_head.layers.0.weight"), zeros("field.mlp_head.layers.0.bias"))
             _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, S, g_bo.data_ptr() + 4, ldb,
                                               zeros("field.embedding_appearance.embedding.weight").data_ptr(),
-                                              ctx.d.data_ptr() if ray_grads else None,
-                                              ray_grads[1].data_ptr() if ray_grads else None, _stream()),
+                                              ctx.d.data_ptr() if sh_grads else None,
+                                              ray_grads[1].data_ptr() if sh_grads else None, _stream()),
                        "tn_color_input_bwd")
         g_h1 = _f32((N, W), dev)
         linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False,

@@ -8,6 +8,20 @@ G2  mae_thermal.npz       — inputs + outputs of the REAL reference ``mae_therm
 G3  oracle_regression.npz — small self-consistency vectors from the CPU oracle (NOT reference-pinned): scalings,
                             hash indices, hash-encode, contraction, piecewise bins, PDF resample.
 
+G4  rgbt_renderer.npz     — inputs + outputs of the REAL reference ``RGBTRenderer`` (the reference's fork of nerfstudio's
+                            RGBRenderer, /root/reference/thermo_nerf/rgb_concat/rgbt_renderer.py:62-81,159-174),
+                            background "last_sample", train + eval, 4-channel RGBT and 3-channel RGB inputs, rows with
+                            NaN / +-inf / sum(w) > 1 / sum(w) = 0.  Pins the RGB compositor.
+G5  thermal_field_head.npz — inputs + outputs of the REAL ``BaseThermalFieldHead`` (thermal_field_head.py:50-71: Linear
+                            64 -> 1, no activation) with ``FieldComponent`` stubbed as ``nn.Module``.
+G6  thermal_field_wiring.npz — the REAL ``ThermalNerfactoTField`` (thermal_field.py:33-201: constructor, ``get_outputs``,
+                            ``forward``) executed with nerfstudio's base classes (NerfactoField, MLP, SHEncoding,
+                            Embedding, get_normalized_directions) replaced by modules built from the ORACLE's primitives.
+                            This pins the WIRING of the reference's own file — which positional arguments reach
+                            NerfactoField, concat order [SH | geo | appearance], which MLP sees which tensor, the
+                            train/eval appearance branches, no activation on the thermal head, detach of the thermal
+                            input — NOT nerfstudio's arithmetic, which stays unpinned.
+
 The fixtures are data (inputs and expected outputs); no reference source text is stored.
 """
 from __future__ import annotations
@@ -41,6 +55,15 @@ def _stub_modules() -> None:
     nsu.colors = nsc
     ns.utils = nsu
     sys.modules.update({"nerfstudio": ns, "nerfstudio.utils": nsu, "nerfstudio.utils.colors": nsc})
+    # rgbt_renderer.py imports nerfacc at module level (used only for packed samples, which "last_sample" refuses)
+    sys.modules["nerfacc"] = types.ModuleType("nerfacc")
+    # thermal_field_head.py: FieldComponent is a bare nn.Module base in nerfstudio
+    fc = types.ModuleType("nerfstudio.field_components")
+    bfc = types.ModuleType("nerfstudio.field_components.base_field_component")
+    bfc.FieldComponent = torch.nn.Module
+    fc.base_field_component = bfc
+    ns.field_components = fc
+    sys.modules.update({"nerfstudio.field_components": fc, "nerfstudio.field_components.base_field_component": bfc})
 
 
 def _load(path: str, name: str):
@@ -96,6 +119,284 @@ def g2_mae_thermal() -> None:
     print("G2", tmax, tmin, res)
 
 
+def _weights_with_edge_rows(g, R, S):
+    w = torch.rand(R, S, 1, generator=g)
+    w = w / w.sum(dim=1, keepdim=True) * torch.rand(R, 1, 1, generator=g)  # sum(w) in (0,1)
+    w[0] = 0.0  # sum(w) == 0 -> pure background
+    w[1] = w[1] * 0 + 1.0 / 24.0  # sum(w) == 2 > 1
+    return w
+
+
+def g4_rgbt_renderer() -> None:
+    mod = _load(f"{REF}/thermo_nerf/rgb_concat/rgbt_renderer.py", "ref_rgbt_renderer")
+    g = torch.Generator().manual_seed(2468)
+    R, S = 64, 48
+    rgbt = torch.rand(R, S, 4, generator=g) * 1.4 - 0.2  # exercises the eval clamp on both sides
+    w = _weights_with_edge_rows(g, R, S)
+    rgbt[2, 5, 1] = float("nan")
+    rgbt[3, -1, 0] = float("inf")
+    rgbt[4, 7, 2] = float("-inf")
+    rgbt[5, -1, 3] = float("nan")  # the last sample is the background
+    rend = mod.RGBTRenderer(background_color="last_sample")
+    out = {}
+    for mode in ("train", "eval"):
+        rend.train(mode == "train")
+        out[f"out4_{mode}"] = rend(rgbt.clone(), w.clone()).numpy()
+        out[f"out3_{mode}"] = rend(rgbt[..., :3].clone(), w.clone()).numpy()
+    # blend_background_for_loss_computation with "last_sample": prediction and GT pass through untouched [REF :137-141]
+    pred, gt = torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g)
+    p2, g2 = rend.blend_background_for_loss_computation(pred_image=pred, pred_accumulation=torch.rand(R, 1, generator=g),
+                                                        gt_image=gt)
+    assert torch.equal(p2, pred) and torch.equal(g2, gt)
+    np.savez(os.path.join(OUT, "rgbt_renderer.npz"), rgbt=rgbt.numpy(), weights=w.numpy(), **out)
+    print("G4", {k: v.shape for k, v in out.items()})
+
+
+def g5_thermal_field_head() -> None:
+    mod = _load(f"{REF}/thermo_nerf/thermal_nerf/thermal_field_head.py", "ref_thermal_field_head")
+    g = torch.Generator().manual_seed(1357)
+    head = mod.BaseThermalFieldHead(out_dim=1, field_head_name=mod.FieldHeadNamesT.THERMAL, in_dim=64, activation=None)
+    wt, bs = torch.randn(1, 64, generator=g) * 0.3, torch.randn(1, generator=g)
+    with torch.no_grad():
+        head.net.weight.copy_(wt)
+        head.net.bias.copy_(bs)
+    x = torch.rand(257, 64, generator=g)  # sigmoid outputs of mlp_thermal live in (0,1)
+    with torch.no_grad():
+        y = head(x)
+    late = mod.BaseThermalFieldHead(out_dim=1, field_head_name=mod.FieldHeadNamesT.THERMAL)  # in_dim set later
+    assert late.net is None
+    late.set_in_dim(64)
+    assert tuple(late.net.weight.shape) == (1, 64)
+    np.savez(os.path.join(OUT, "thermal_field_head.npz"), weight=wt.numpy(), bias=bs.numpy(), x=x.numpy(), y=y.numpy(),
+             state_keys=np.array(sorted(head.state_dict().keys())), enum_value=mod.FieldHeadNamesT.THERMAL.value)
+    print("G5", y.shape, sorted(head.state_dict().keys()))
+
+
+def _stub_nerfstudio_field_bases(H) -> dict:
+    """nerfstudio base classes of thermal_field.py, rebuilt from the oracle's primitives (wiring harness, G6).  Returns the
+    record the NerfactoField stub fills with the arguments the reference passes it."""
+    import enum
+
+    rec: dict = {}
+    nn = torch.nn
+
+    class FieldHeadNames(enum.Enum):  # NS field_components.field_heads.FieldHeadNames (values as in nerfstudio)
+        RGB = "rgb"
+        SH = "sh"
+        DENSITY = "density"
+        NORMALS = "normals"
+        PRED_NORMALS = "pred_normals"
+        UNCERTAINTY = "uncertainty"
+        BACKGROUND_RGB = "background_rgb"
+        TRANSIENT_RGB = "transient_rgb"
+        TRANSIENT_DENSITY = "transient_density"
+        SEMANTICS = "semantics"
+        SDF = "sdf"
+        ALPHA = "alpha"
+        GRADIENT = "gradient"
+
+    class MLP(nn.Module):  # NS MLP torch path (SURVEY A.5), forward = oracle.mlp
+        def __init__(self, in_dim, num_layers, layer_width, out_dim=None, skip_connections=None, activation=None,
+                     out_activation=None, implementation="torch"):
+            super().__init__()
+            out_dim = layer_width if out_dim is None else out_dim
+            dims = [in_dim] + [layer_width] * (num_layers - 1) + [out_dim]
+            self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers)])
+            self.out_dim = out_dim
+            assert isinstance(activation, nn.ReLU)
+            self.out_activation = out_activation
+            rec.setdefault("mlp_args", []).append(dict(in_dim=in_dim, num_layers=num_layers, layer_width=layer_width,
+                                                       out_dim=out_dim, out_activation=type(out_activation).__name__,
+                                                       implementation=implementation))
+
+        def get_out_dim(self):
+            return self.out_dim
+
+        def forward(self, x):
+            act = {"NoneType": None, "Sigmoid": "sigmoid"}[type(self.out_activation).__name__]
+            return H.mlp(x, [(l.weight, l.bias) for l in self.layers], act)
+
+    class Embedding(nn.Module):  # NS field_components.embedding.Embedding
+        def __init__(self, in_dim, out_dim):
+            super().__init__()
+            self.embedding = nn.Embedding(in_dim, out_dim)
+
+        def mean(self, dim=0):
+            return self.embedding.weight.mean(dim)
+
+        def forward(self, idx):
+            return self.embedding(idx)
+
+    class SHEncoding(nn.Module):  # NS SHEncoding(levels=4), torch path: oracle.sh4 under no_grad
+        def forward(self, x):
+            with torch.no_grad():
+                return H.sh4(x)
+
+    class HashMLP(nn.Module):  # NS MLPWithHashEncoding: .encoder.hash_table/.scalings + .mlp
+        def __init__(self, num_levels, base_res, max_res, log2_hashmap_size, features_per_level, num_layers, width, out_dim):
+            super().__init__()
+            enc = nn.Module()
+            enc.hash_table = nn.Parameter(torch.zeros((2**log2_hashmap_size) * num_levels, features_per_level))
+            enc.register_buffer("scalings", H.hash_scalings(num_levels, base_res, max_res))
+            self.encoder = enc
+            self.log2 = log2_hashmap_size
+            self.mlp = MLP(num_levels * features_per_level, num_layers, width, out_dim, activation=nn.ReLU())
+
+        def forward(self, p):
+            return self.mlp(H.hash_encode(p, self.encoder.hash_table, self.encoder.scalings, self.log2))
+
+    class NerfactoField(nn.Module):
+        """NS NerfactoField (1.1.5) positional signature; builds the sub-modules ThermalNerfactoTField.get_outputs uses."""
+
+        def __init__(self, aabb, num_images, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_levels=16, base_res=16,
+                     max_res=2048, log2_hashmap_size=19, num_layers_color=3, num_layers_transient=2, features_per_level=2,
+                     hidden_dim_color=64, hidden_dim_transient=64, appearance_embedding_dim=32, transient_embedding_dim=16,
+                     use_transient_embedding=False, use_semantics=False, num_semantic_classes=100,
+                     pass_semantic_gradients=False, use_pred_normals=False, use_average_appearance_embedding=False,
+                     spatial_distortion=None, average_init_density=1.0, implementation="tcnn"):
+            super().__init__()
+            rec["nerfacto_args"] = dict(num_images=num_images, num_layers=num_layers, hidden_dim=hidden_dim,
+                                        geo_feat_dim=geo_feat_dim, num_levels=num_levels, base_res=base_res, max_res=max_res,
+                                        log2_hashmap_size=log2_hashmap_size, num_layers_color=num_layers_color,
+                                        features_per_level=features_per_level, hidden_dim_color=hidden_dim_color,
+                                        appearance_embedding_dim=appearance_embedding_dim,
+                                        use_average_appearance_embedding=use_average_appearance_embedding,
+                                        average_init_density=average_init_density, implementation=implementation)
+            self.register_buffer("aabb", aabb)
+            self.geo_feat_dim = geo_feat_dim
+            self.appearance_embedding_dim = appearance_embedding_dim
+            self.use_average_appearance_embedding = use_average_appearance_embedding
+            self.use_transient_embedding = use_transient_embedding
+            self.spatial_distortion = spatial_distortion
+            self.average_init_density = average_init_density
+            self.embedding_appearance = Embedding(num_images, appearance_embedding_dim)
+            self.direction_encoding = SHEncoding()
+            self.mlp_base = HashMLP(num_levels, base_res, max_res, log2_hashmap_size, features_per_level, num_layers,
+                                    hidden_dim, 1 + geo_feat_dim)
+            self.mlp_head = MLP(16 + geo_feat_dim + appearance_embedding_dim, num_layers_color, hidden_dim_color, 3,
+                                activation=nn.ReLU(), out_activation=nn.Sigmoid())
+
+        def get_density(self, ray_samples):  # NS NerfactoField.get_density, from oracle primitives
+            pos = ray_samples.frustums.get_positions()
+            contract = self.spatial_distortion is not None  # SceneContraction(order=inf) vs SceneBox normalisation
+            p, selector = H.normalized_positions(pos, H.OracleConfig(disable_scene_contraction=not contract), self.aabb)
+            h = self.mlp_base(p.view(-1, 3)).view(*pos.shape[:-1], -1)
+            raw, geo = torch.split(h, [1, self.geo_feat_dim], dim=-1)
+            density = self.average_init_density * H.trunc_exp(raw)
+            return density * selector[..., None], geo
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("nerfstudio.cameras")
+    mod("nerfstudio.cameras.rays", RaySamples=object)
+    mod("nerfstudio.field_components.field_heads", FieldHeadNames=FieldHeadNames)
+    mod("nerfstudio.field_components.mlp", MLP=MLP)
+    mod("nerfstudio.field_components.spatial_distortions", SpatialDistortion=torch.nn.Module)
+    mod("nerfstudio.fields")
+    mod("nerfstudio.fields.base_field", get_normalized_directions=lambda d: (d + 1.0) / 2.0)
+    mod("nerfstudio.fields.nerfacto_field", NerfactoField=NerfactoField)
+    rec["FieldHeadNames"] = FieldHeadNames
+    return rec
+
+
+def g6_thermal_field_wiring() -> None:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import hotpath as H
+    from thermo_nerf_amd.synthetic import counter_uniform
+
+    rec = _stub_nerfstudio_field_bases(H)
+    # the reference module imports its own package by name: make `thermo_nerf.thermal_nerf.thermal_field_head` resolvable
+    head = _load(f"{REF}/thermo_nerf/thermal_nerf/thermal_field_head.py", "thermo_nerf.thermal_nerf.thermal_field_head")
+    for name in ("thermo_nerf", "thermo_nerf.thermal_nerf"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["thermo_nerf.thermal_nerf.thermal_field_head"] = head
+    tf = _load(f"{REF}/thermo_nerf/thermal_nerf/thermal_field.py", "ref_thermal_field")
+
+    L, T, NIMG = 16, 10, 5
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    out = {}
+    for avg in (True, False):
+        # keyword construction as at [REF thermal_nerf_model.py:106-125]
+        field = tf.ThermalNerfactoTField(aabb, hidden_dim=64, num_levels=L, max_res=2048, base_res=16, features_per_level=2,
+                                         log2_hashmap_size=T, hidden_dim_color=64, hidden_dim_transient=64,
+                                         spatial_distortion=torch.nn.Identity(),  # stands for SceneContraction(order=inf)
+                                         num_images=NIMG, use_pred_normals=False,
+                                         use_average_appearance_embedding=avg, appearance_embedding_dim=32,
+                                         implementation="torch", use_transient_embedding=False, pass_thermal_gradients=True)
+        na = rec["nerfacto_args"]
+        assert na["average_init_density"] == 1.0 and na["implementation"] == "torch", na  # [REF thermal_field.py:62-88]
+        assert na["num_images"] == NIMG and na["log2_hashmap_size"] == T and na["geo_feat_dim"] == 15, na
+        th = [m for m in rec["mlp_args"] if m["in_dim"] == 15][-1]  # mlp_thermal [REF :90-98]
+        assert th == dict(in_dim=15, num_layers=2, layer_width=64, out_dim=64, out_activation="Sigmoid",
+                          implementation="torch"), th
+        # deterministic weights (counter hash), sized so that activations are not saturated
+        seed = 100
+        with torch.no_grad():
+            for name, prm in sorted(field.named_parameters()):
+                seed += 1
+                u = counter_uniform(prm.numel(), seed).view(prm.shape) * 2 - 1
+                scale = 1.0 if "embedding" in name else (0.5 if "hash_table" in name else 0.35)
+                prm.copy_(u * scale)
+        sd = {k: v.detach().clone() for k, v in field.state_dict().items()}
+        R, S = 9, 7
+        pos = (counter_uniform(R * S * 3, 31).view(R, S, 3) * 2 - 1) * 1.5  # some points outside the unit box
+        dirs = counter_uniform(R * 3, 32).view(R, 1, 3) * 2 - 1
+        dirs = (dirs / dirs.norm(dim=-1, keepdim=True)).expand(R, S, 3).contiguous()
+        cam = (counter_uniform(R, 33) * NIMG).long().clamp(0, NIMG - 1).view(R, 1, 1).expand(R, S, 1).contiguous()
+
+        class Fr:
+            directions = dirs
+
+            @staticmethod
+            def get_positions():
+                return pos
+
+        class RS:
+            frustums = Fr
+            camera_indices = cam
+
+        FH = rec["FieldHeadNames"]
+        for mode in ("eval", "train"):
+            field.train(mode == "train")
+            with torch.no_grad():
+                o = field(RS)  # the reference's forward: get_density -> get_outputs -> dict
+            assert set(o.keys()) == {FH.RGB, FH.DENSITY, tf.FieldHeadNamesT.THERMAL}, o.keys()
+            tag = f"avg{int(avg)}_{mode}"
+            out[f"rgb_{tag}"] = o[FH.RGB].numpy()
+            out[f"thermal_{tag}"] = o[tf.FieldHeadNamesT.THERMAL].numpy()
+            out[f"density_{tag}"] = o[FH.DENSITY].numpy()
+        if avg:
+            # pass_thermal_gradients=False detaches the thermal branch's input [REF :171-172]
+            field.train(True)
+            field.pass_thermal_gradients = False
+            field.zero_grad()
+            field(RS)[tf.FieldHeadNamesT.THERMAL].sum().backward()
+            assert field.mlp_base.mlp.layers[0].weight.grad is None or float(field.mlp_base.mlp.layers[0].weight.grad.abs().sum()) == 0.0
+            assert float(field.mlp_thermal.layers[0].weight.grad.abs().sum()) > 0.0
+            field.pass_thermal_gradients = True
+            # missing camera indices raise [REF :114-115]
+            class RS2(RS):
+                camera_indices = None
+            try:
+                field(RS2)
+                raise SystemExit("expected AttributeError")
+            except AttributeError as e:
+                out["missing_cam_message"] = np.array(str(e))
+            out.update({f"sd.{k}": v.numpy() for k, v in sd.items()})
+            out["state_keys"] = np.array(sorted(sd.keys()))
+            out["positions"], out["directions"], out["camera_indices"] = pos.numpy(), dirs.numpy(), cam.numpy()
+    out["config"] = np.array(json.dumps(dict(num_levels=L, log2_hashmap_size=T, num_images=NIMG, base_res=16, max_res=2048)))
+    np.savez_compressed(os.path.join(OUT, "thermal_field_wiring.npz"), **out)
+    print("G6", sorted(k for k in out if not k.startswith("sd.")))
+
+
 def g3_oracle_regression() -> None:
     sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
     from oracle import hotpath as H
@@ -134,3 +435,6 @@ if __name__ == "__main__":
     _stub_modules()
     g1_thermal_renderer()
     g2_mae_thermal()
+    g4_rgbt_renderer()
+    g5_thermal_field_head()
+    g6_thermal_field_wiring()
