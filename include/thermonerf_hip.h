@@ -314,6 +314,12 @@ int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, 
 int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
                    float *d_densities, void *stream);
 
+/* NS scale_gradients_by_distance_squared [REF thermal_nerf_model.py:228-231, use_gradient_scaling]: the forward is the
+ * identity; in the backward the gradient of EVERY field output of a sample (density [n], rgb [n,3], thermal [n]; any may
+ * be NULL) is multiplied in place by clamp(((start + end) / 2)^2, 0, 1).  starts/ends [n]. */
+int tn_gradient_scale_bwd(const float *starts, const float *ends, int64_t n, float *d_density, float *d_rgb,
+                          float *d_thermal, void *stream);
+
 /* backward of tn_composite_fwd in training mode (no nan_to_num / clamp): d_out [R,C], accumulation [R] ->
  * d_values [R,n,C] (=), d_weights [R,n] (+=). */
 int tn_composite_bwd(const float *values, const float *weights, const float *accumulation, const float *d_out,

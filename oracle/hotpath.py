@@ -65,6 +65,8 @@ class OracleConfig:
     # constant of the graph and no gradient reaches the ray directions through it.  True = differentiate through the basis
     # (what a tcnn SH encoding does); the product mirrors this switch as config.sh_direction_gradient.
     sh_grad: bool = False
+    use_same_proposal_network: bool = False  # [REF thermal_nerf_model.py:127-139]: one network for every proposal level
+    use_gradient_scaling: bool = False  # [REF :228-231]: NS scale_gradients_by_distance_squared on the field outputs
 
 
 # ----------------------------------------------------------------------------------------------
@@ -214,10 +216,31 @@ class _TruncExp(torch.autograd.Function):
 trunc_exp = _TruncExp.apply
 
 
+class _GradientScaler(torch.autograd.Function):
+    """NS model_components.losses._GradientScaler: identity forward, gradient times ``scaling`` backward."""
+
+    @staticmethod
+    def forward(ctx, value, scaling):
+        ctx.save_for_backward(scaling)
+        return value, scaling
+
+    @staticmethod
+    def backward(ctx, output_grads, grad_scaling):
+        (scaling,) = ctx.saved_tensors
+        return output_grads * scaling, grad_scaling
+
+
+def scale_gradients_by_distance_squared(outputs: Dict[str, Tensor], starts: Tensor, ends: Tensor) -> Dict[str, Tensor]:
+    """NS losses.scale_gradients_by_distance_squared, applied at [REF thermal_nerf_model.py:228-231] to EVERY field output."""
+    ray_dist = (starts + ends) / 2
+    scaling = torch.square(ray_dist).clamp(0, 1)
+    return {k: _GradientScaler.apply(v, scaling)[0] for k, v in outputs.items()}
+
+
 def proposal_density(sd: Dict[str, Tensor], level: int, positions: Tensor, cfg: OracleConfig) -> Tensor:
     """NS HashMLPDensityField.density_fn/get_density (a5), built at [REF thermal_nerf_model.py:136-149].
     positions [...,3] -> density [...,1]."""
-    pre = f"proposal_networks.{level}"
+    pre = f"proposal_networks.{0 if cfg.use_same_proposal_network else level}"
     args = cfg.proposal_net_args_list[min(level, len(cfg.proposal_net_args_list) - 1)]
     shape = positions.shape[:-1]
     p, selector = normalized_positions(positions, cfg, sd.get(f"{pre}.aabb"))
@@ -493,6 +516,9 @@ def get_outputs(
     dirs = directions[:, None, :].expand(-1, pos.shape[1], -1)
     cam = None if camera_indices is None else camera_indices[:, None, :].expand(-1, pos.shape[1], -1)
     rgb_s, thermal_s = field_outputs(sd, dirs, geo, cam, cfg, training)
+    if cfg.use_gradient_scaling:  # [REF :228-231]
+        scaled = scale_gradients_by_distance_squared({"rgb": rgb_s, "thermal": thermal_s, "density": density}, s.starts, s.ends)
+        rgb_s, thermal_s, density = scaled["rgb"], scaled["thermal"], scaled["density"]
     weights = get_weights(s.deltas, density)  # [REF :233]
     weights_list.append(weights)
     samples_list.append(s)

@@ -26,7 +26,8 @@ def oracle_config(cfg: ThermalNerfModelConfig) -> H.OracleConfig:
         num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         use_average_appearance_embedding=cfg.use_average_appearance_embedding,
         disable_scene_contraction=cfg.disable_scene_contraction, sh_input=cfg.sh_input,
-        sh_grad=cfg.sh_direction_gradient,
+        sh_grad=cfg.sh_direction_gradient, use_same_proposal_network=cfg.use_same_proposal_network,
+        use_gradient_scaling=cfg.use_gradient_scaling,
     )
 
 
@@ -34,6 +35,9 @@ def oracle_config(cfg: ThermalNerfModelConfig) -> H.OracleConfig:
 def build(kind: str = "stress", S: int = 48, small: bool = True, num_images: int = 8, **over):
     """Returns (cpu_model, cpu_state_dict, oracle_cfg).  Cached: treat the results as read-only."""
     kw = dict(SMALL) if small else {}
+    if over.pop("one_proposal_network", False):  # (lru_cache needs hashable arguments: a flag instead of a list of dicts)
+        nets = kw.get("proposal_net_args_list") or ThermalNerfModelConfig().proposal_net_args_list
+        kw.update(use_same_proposal_network=True, proposal_net_args_list=[nets[-1]])
     kw.update(over)
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, **kw)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=num_images)

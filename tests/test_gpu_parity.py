@@ -552,6 +552,20 @@ def test_engine_chunks_on_two_streams_match_one_stream():
     assert (a["rgb"][:700].cpu() - want["rgb"]).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("form", ["fused", "modular", "fused_ray_per_wave"])
+def test_same_proposal_network(form):
+    """use_same_proposal_network [REF thermal_nerf_model.py:122-139]: one HashMLPDensityField serves both proposal levels."""
+    gm, sd, ocfg = gpu_model("stress", 48, family="ray_per_wave" if form == "fused_ray_per_wave" else "lane_ray",
+                             one_proposal_network=True)
+    assert len(gm.proposal_networks) == 1 and "proposal_networks.1.mlp_base.encoder.hash_table" not in sd
+    gm.config.fused = form != "modular"
+    o, d = helpers.rays(13, 11, view=5)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    check_outputs(got, want, f"same proposal network, {form}")
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_small_calls_take_the_ray_per_wave_kernels(precision):
     """Automatic dispatch: below ~60-80 k rays the one-ray-per-wave kernels run (a 64-ray tile marches serially, so the

@@ -614,6 +614,24 @@ density_act_bwd_kernel(const float *__restrict__ raw, int ld, const float *__res
         d_raw[i * ldd] = dd[i] * sel[i] * avg * expf(fminf(raw[i * ld], 15.0f));
 }
 
+// NS scale_gradients_by_distance_squared (use_gradient_scaling, REF thermal_nerf_model.py:228-231): backward-only —
+// every field output's gradient is multiplied by clamp(((start + end) / 2)^2, 0, 1) of its sample.
+__global__ void __launch_bounds__(kBlock)
+gradient_scale_kernel(const float *__restrict__ starts, const float *__restrict__ ends, long long n, float *__restrict__ d_density,
+                      float *__restrict__ d_rgb, float *__restrict__ d_thermal) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float dist = (starts[i] + ends[i]) / 2.0f;
+        const float s = fminf(fmaxf(dist * dist, 0.0f), 1.0f);
+        if (d_density) d_density[i] *= s;
+        if (d_rgb) {
+            d_rgb[i * 3 + 0] *= s;
+            d_rgb[i * 3 + 1] *= s;
+            d_rgb[i * 3 + 2] *= s;
+        }
+        if (d_thermal) d_thermal[i] *= s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // get_weights backward: one wave per ray, chunks of 64 samples walked back to front.
 //   a_i = delta_i sigma_i,  T_i = exp(-sum_{j<i} a_j),  w_i = (1 - e^{-a_i}) T_i
@@ -1087,6 +1105,17 @@ int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, 
     if (n < 0 || ld_raw < 1 || ld_d_raw < 1) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(density_act_bwd_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, raw,
                        ld_raw, selector, average_init_density, d_density, (long long)n, d_raw, ld_d_raw);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_gradient_scale_bwd(const float *starts, const float *ends, int64_t n, float *d_density, float *d_rgb,
+                          float *d_thermal, void *stream) {
+    if (n == 0) return TN_OK;
+    if (!starts || !ends) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(gradient_scale_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, starts,
+                       ends, (long long)n, d_density, d_rgb, d_thermal);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

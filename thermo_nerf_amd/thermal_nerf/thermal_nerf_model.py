@@ -165,8 +165,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
 
     def _fusable(self) -> bool:
         cfg = self.config
-        return (cfg.fused and cfg.num_proposal_iterations == 2 and not cfg.use_same_proposal_network
-                and not cfg.predict_normals and not cfg.use_gradient_scaling)
+        # use_gradient_scaling only rescales gradients (backward); use_same_proposal_network hands one network to both levels
+        return cfg.fused and cfg.num_proposal_iterations == 2 and not cfg.predict_normals
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
@@ -231,8 +231,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns,
                                                                             jitter=jitter)
         field_outputs = self.field.forward(ray_samples, compute_normals=self.config.predict_normals)
-        if self.config.use_gradient_scaling:
-            raise NotImplementedError("use_gradient_scaling only rescales gradients (backward); forward is unchanged")
+        # REF :228-231 use_gradient_scaling: scale_gradients_by_distance_squared is the identity in the forward pass
         weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
         weights_list.append(weights)
         ray_samples_list.append(ray_samples)
@@ -269,7 +268,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
         key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.config.use_mfma,
                                                                               self.config.mlp_precision)
         if self._struct_key != key:
-            self._structs = (self.proposal_networks[0].c_struct(), self.proposal_networks[1].c_struct(),
+            nets = len(self.proposal_networks)  # 1 with use_same_proposal_network [REF :127-139]
+            self._structs = (self.proposal_networks[0].c_struct(), self.proposal_networks[min(1, nets - 1)].c_struct(),
                              self.field.c_struct(prepare=self.config.use_mfma, precision=self.config.mlp_precision))
             self._struct_key = key
         return self._structs

@@ -183,7 +183,9 @@ class RenderTrain(torch.autograd.Function):
         R = o.shape[0]
         P = tuple(cfg.num_proposal_samples_per_ray)
         S = cfg.num_nerf_samples_per_ray
-        prop_structs = [model.proposal_networks[i].c_struct() for i in range(2)]
+        # use_same_proposal_network: ONE HashMLPDensityField serves both levels [REF thermal_nerf_model.py:127-139]
+        nets = len(model.proposal_networks)
+        prop_structs = [model.proposal_networks[min(i, nets - 1)].c_struct() for i in range(2)]
         fld = model.field.c_struct(prepare=False)
         anneal = float(model.proposal_sampler._anneal)
 
@@ -337,6 +339,10 @@ class RenderTrain(torch.autograd.Function):
                                             g_th.contiguous().data_ptr(), R, S, 1, g_th_s.data_ptr(), g_w.data_ptr(),
                                             _stream()), "tn_composite_bwd")
         g_density = weights_bwd(f.deltas, f.density.view(R, S), g_w)
+        if cfg.use_gradient_scaling:  # REF :228-231: field_outputs = scale_gradients_by_distance_squared(field_outputs, ray_samples)
+            starts, ends = f.eucl[:, :-1].contiguous(), f.eucl[:, 1:].contiguous()
+            _hip.check(lib.tn_gradient_scale_bwd(starts.data_ptr(), ends.data_ptr(), N, g_density.data_ptr(), _hip.ptr(g_rgb_s),
+                                                 _hip.ptr(g_th_s), _stream()), "tn_gradient_scale_bwd")
         ldb = bo.shape[1]
         g_bo = torch.zeros((N, ldb), dtype=torch.float32, device=dev)
         _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density,
@@ -382,8 +388,9 @@ class RenderTrain(torch.autograd.Function):
                 if g is None:
                     continue
                 t = ctx.tapes[lvl]
-                net = model.proposal_networks[lvl].c_struct()
-                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{lvl}", like,
+                which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
+                net = model.proposal_networks[which].c_struct()
+                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", like,
                                     ray_grads)
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
@@ -455,10 +462,9 @@ def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) 
 def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """Train-mode ``get_outputs`` with gradients [REF thermal_nerf_model.py:210-275]."""
     cfg = model.config
-    if (cfg.num_proposal_iterations != 2 or cfg.use_same_proposal_network or cfg.predict_normals
-            or cfg.use_gradient_scaling or not cfg.use_single_jitter):
-        raise NotImplementedError("the training path implements the reference configuration: two proposal networks, "
-                                  "single jitter, no predicted normals, no gradient scaling")
+    if cfg.num_proposal_iterations != 2 or cfg.predict_normals or not cfg.use_single_jitter:
+        raise NotImplementedError("the training path implements two proposal iterations, single jitter and no predicted "
+                                  "normals (the reference configuration)")
     o = _hip.require_device_tensor(ray_bundle.origins, "origins")
     d = _hip.require_device_tensor(ray_bundle.directions, "directions")
     R, dev = o.shape[0], o.device
