@@ -134,6 +134,11 @@ def test_dataset_items(tmp_path):
     assert torch.equal(item["thermal"][..., 0], torch.from_numpy((raw / 255.0).astype(np.float32)))
     rgb = np.array(Image.open(out.image_filenames[2]))
     assert torch.equal(item["image"], torch.from_numpy(rgb.astype(np.float32) / 255.0))
+    # NS InputDataset deep-copies the cameras: a second dataset on the same outputs does not rescale them again
+    fx0 = float(out.cameras.fx.reshape(-1)[0])
+    a, b = ThermalDataset(out, scale_factor=0.5), ThermalDataset(out, scale_factor=0.5)
+    assert float(out.cameras.fx.reshape(-1)[0]) == fx0
+    assert float(a.cameras.fx.reshape(-1)[0]) == float(b.cameras.fx.reshape(-1)[0]) == 0.5 * fx0
     out.metadata.pop("thermal")
     with pytest.raises(AssertionError):
         ThermalDataset(out)  # REF thermal_dataset.py:30
@@ -149,6 +154,20 @@ def test_reference_thermal_image_and_temperature_bounds():
     assert 0.0 <= t.min().item() < t.max().item() <= 1.0
     half = ThermalDataset.get_thermal_tensors_from_path(GOLDEN / "IMG_3561.PNG", scale_factor=0.5)
     assert half.shape == (320, 240, 1) and abs(half.mean().item() - t.mean().item()) < 0.01
+    # cv2.resize INTER_LINEAR [REF thermal_dataset.py:66-70] at exactly 1/2: source coordinate 2d + 0.5 -> the un-antialiased
+    # bilinear tap is the mean of the 2x2 block
+    blocks = t[..., 0].view(320, 2, 240, 2)
+    want = (blocks[:, 0, :, 0] + blocks[:, 0, :, 1] + blocks[:, 1, :, 0] + blocks[:, 1, :, 1]) / 4
+    assert (half[..., 0] - want).abs().max().item() < 1e-6
+    third = ThermalDataset.get_thermal_tensors_from_path(GOLDEN / "IMG_3561.PNG", scale_factor=0.3)
+    assert third.shape == (192, 144, 1)
+    # 0.3: source x = (d + 0.5) / 0.3 - 0.5; check one interior tap by hand (no antialiasing: exactly 4 source pixels)
+    sy, sx = (7 + 0.5) * (640 / 192) - 0.5, (11 + 0.5) * (480 / 144) - 0.5
+    y0, x0 = int(sy), int(sx)
+    fy, fx = sy - y0, sx - x0
+    g = t[..., 0]
+    hand = ((1 - fy) * ((1 - fx) * g[y0, x0] + fx * g[y0, x0 + 1]) + fy * ((1 - fx) * g[y0 + 1, x0] + fx * g[y0 + 1, x0 + 1]))
+    assert abs(third[7, 11, 0].item() - hand.item()) < 1e-5
     bounds = json.loads((GOLDEN / "temperature_bounds.json").read_text())
     lo, hi = bounds["absolute_min_temperature"], bounds["absolute_max_temperature"]
     celsius = t * (hi - lo) + lo  # the mapping mae_thermal applies [REF thermal_metrics.py:29-33]

@@ -427,6 +427,26 @@ def test_camera_ray_bundle_chunking_matches_single_call():
     check_outputs(flat(got), flat(want), "chunked")
 
 
+def test_camera_ray_bundle_keeps_planes_already_on_the_bundle():
+    """NS SceneCollider.forward leaves nears/fars alone when the bundle carries them: the engine path of
+    get_outputs_for_camera_ray_bundle does too, and a collider edited after the first render is picked up."""
+    gm, sd, ocfg = gpu_model("scene", 48)
+    gm.config.eval_num_rays_per_chunk = 100
+    o, d, _ = synthetic.orbit_camera_rays(9, 11, view=2)
+    base = gm.get_outputs_for_camera_ray_bundle(RayBundle(origins=o, directions=d))
+    same = gm.get_outputs_for_camera_ray_bundle(RayBundle(origins=o, directions=d, nears=torch.zeros(9, 11, 1),
+                                                          fars=torch.full((9, 11, 1), 1000.0)))
+    for k in ("rgb", "thermal", "depth"):
+        assert torch.equal(base[k], same[k]), k
+    moved = gm.get_outputs_for_camera_ray_bundle(RayBundle(origins=o, directions=d, nears=torch.full((9, 11, 1), 0.4),
+                                                           fars=torch.full((9, 11, 1), 6.0)))
+    assert float(moved["depth"].min()) >= 0.4 and float(moved["depth"].max()) <= 6.0
+    assert not torch.equal(base["depth"], moved["depth"])
+    gm.collider.far_plane = 6.0  # the engine's cached plane buffers follow the collider
+    edited = gm.get_outputs_for_camera_ray_bundle(RayBundle(origins=o, directions=d))
+    assert float(edited["depth"].max()) <= 6.0 and not torch.equal(base["depth"], edited["depth"])
+
+
 @pytest.mark.parametrize("use_mfma", [True, False])
 def test_fused_is_deterministic_and_matches_modular(use_mfma):
     gm, _, _ = gpu_model("stress", 64)

@@ -532,10 +532,14 @@ def test_thermoscenes_style_tree_to_training_steps(tmp_path):
     assert Image.open(tmp_path / "eval" / "images" / "img_00000.jpg").size == (64, 32)  # ground truth | prediction
 
 
-def test_eval_follows_fused_optimizer_updates():
+@pytest.mark.parametrize("dense_mb", [0, 8])
+def test_eval_follows_fused_optimizer_updates(dense_mb):
     """torch.optim.Adam(fused=True) changes parameters without bumping their version counters; the prepared MFMA blobs
-    must still be rebuilt before the next eval render."""
+    (and, with a dense-grid budget, the dense re-layout of the coarse hash levels) must still be rebuilt before the next
+    eval render."""
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48)
+    for mod in [gm.field] + list(gm.proposal_networks):
+        mod.dense_budget_bytes = dense_mb << 20
     rb = RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=torch.zeros_like(cam).to(DEV))
     gm.eval()
     with torch.no_grad():

@@ -2,6 +2,7 @@
 item i = {"image_idx", "image" [H,W,3] float32 in [0,1], "thermal" [H,W,1] float32 in [0,1]}."""
 from __future__ import annotations
 
+import copy
 from pathlib import Path
 from typing import Dict, List
 
@@ -21,7 +22,8 @@ class ThermalDataset:
         assert RenderedImageModality.THERMAL.value in self.metadata.keys()  # REF :30
         self.thermal_filenames: List[Path] = self.metadata[RenderedImageModality.THERMAL.value]
         self.kernel_size = kernel_size
-        self.cameras = dataparser_outputs.cameras
+        # NS InputDataset deep-copies the cameras: two datasets built from one DataparserOutputs must not rescale twice
+        self.cameras = copy.deepcopy(dataparser_outputs.cameras)
         self.scene_box = dataparser_outputs.scene_box
         if scale_factor != 1.0:
             self.cameras.rescale_output_resolution(scale_factor)
@@ -62,8 +64,11 @@ class ThermalDataset:
         image = (np.asarray(pil, dtype=np.uint8) / 255.0).astype(np.float32)
         if scale_factor != 1.0:
             h, w = image.shape
-            size = (int(w * scale_factor), int(h * scale_factor))
-            image = np.array(Image.fromarray(image, mode="F").resize(size, resample=Image.Resampling.BILINEAR), dtype=np.float32)
+            # cv2.resize's default INTER_LINEAR [REF :66-70] is NOT antialiased (PIL's BILINEAR is, when shrinking): plain
+            # bilinear taps at half-pixel centres = torch's bilinear interpolation with align_corners=False
+            size = (int(h * scale_factor), int(w * scale_factor))
+            image = torch.nn.functional.interpolate(torch.from_numpy(image)[None, None], size=size, mode="bilinear",
+                                                    align_corners=False, antialias=False)[0, 0].numpy()
         return torch.from_numpy(np.ascontiguousarray(image[:, :, np.newaxis]))
 
     def get_metadata(self, data: Dict) -> Dict[str, torch.Tensor]:

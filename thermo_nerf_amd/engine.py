@@ -47,6 +47,7 @@ class RayRenderEngine:
         self._streams: List[torch.cuda.Stream] = []
         self._ws: Optional[Tensor] = None
         self._nf: Optional[Tuple[Tensor, Tensor]] = None
+        self._nf_key = None
         self.timings: List[Tuple[torch.cuda.Event, torch.cuda.Event, torch.cuda.Event]] = []
 
     def _buffers(self, dev) -> None:
@@ -55,12 +56,15 @@ class RayRenderEngine:
         if self._ws is None or self._ws.shape[1] < need or self._ws.device != dev:
             self._ws = torch.empty((self.num_streams, need), dtype=torch.uint8, device=dev)
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.num_streams)]
-        if self._nf is None or self._nf[0].device != dev:
-            # NS NearFarCollider in eval: near plane reset to 0
-            col = self.model.collider
-            near = col.near_plane if not col.reset_near_plane else 0.0
-            self._nf = (torch.full((self.chunk,), float(near), dtype=torch.float32, device=dev),
+        # NS NearFarCollider in eval: near plane reset to 0; keyed on the planes, so a collider edited after
+        # the first render is picked up
+        col = self.model.collider
+        near = float(col.near_plane if not col.reset_near_plane else 0.0)
+        key = (near, float(col.far_plane), str(dev), self.chunk)
+        if self._nf is None or self._nf_key != key:
+            self._nf = (torch.full((self.chunk,), near, dtype=torch.float32, device=dev),
                         torch.full((self.chunk,), float(col.far_plane), dtype=torch.float32, device=dev))
+            self._nf_key = key
 
     def allocate_outputs(self, n: int, dev) -> Dict[str, Tensor]:
         out = {"rgb": torch.empty((n, 3), dtype=torch.float32, device=dev)}
@@ -70,8 +74,11 @@ class RayRenderEngine:
 
     @torch.no_grad()
     def render(self, origins: Tensor, directions: Tensor, out: Optional[Dict[str, Tensor]] = None,
-               record_events: bool = False) -> Dict[str, Tensor]:
-        """origins/directions [N,3] resident on the device -> dict of [N,C] tensors (keys = OUTPUT_KEYS)."""
+               record_events: bool = False, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """origins/directions [N,3] resident on the device -> dict of [N,C] tensors (keys = OUTPUT_KEYS).  ``nears`` / ``fars``
+        [N] or [N,1]: per-ray planes already set on the bundle are honoured (NS SceneCollider.forward keeps them); absent,
+        the model's NearFarCollider fills them.  ``expected_depth`` is clipped to the mid-point range of its CHUNK, exactly
+        like the reference's per-chunk forward: it depends on ``chunk`` (the other outputs do not)."""
         o = _hip.require_device_tensor(origins, "origins")
         d = _hip.require_device_tensor(directions, "directions")
         n, dev = o.shape[0], o.device
@@ -80,7 +87,13 @@ class RayRenderEngine:
             out = self.allocate_outputs(n, dev)
         prop0, prop1, fld = self.model._c_structs()
         ins = _hip.tn_render_inputs()
-        ins.nears, ins.fars = self._nf[0].data_ptr(), self._nf[1].data_ptr()
+        if (nears is None) != (fars is None):
+            raise ValueError("pass both nears and fars, or neither")
+        if nears is not None:
+            nears = _hip.require_device_tensor(nears.reshape(-1), "nears")
+            fars = _hip.require_device_tensor(fars.reshape(-1), "fars")
+            if nears.shape[0] != n or fars.shape[0] != n:
+                raise ValueError("nears/fars must hold one value per ray")
         ins.camera_indices = None
         ins.jitter = None
         ins.lin_bins0 = linspace_bins(self.P0, dev).data_ptr()
@@ -103,6 +116,10 @@ class RayRenderEngine:
             stream = st.cuda_stream
             ws = self._ws[slot].data_ptr()
             ins.origins, ins.directions = o.data_ptr() + 12 * i, d.data_ptr() + 12 * i
+            if nears is not None:
+                ins.nears, ins.fars = nears.data_ptr() + 4 * i, fars.data_ptr() + 4 * i
+            else:
+                ins.nears, ins.fars = self._nf[0].data_ptr(), self._nf[1].data_ptr()
             outs.rgb = out["rgb"].data_ptr() + 12 * i
             for k in OUTPUT_KEYS[1:]:
                 setattr(outs, k, out[k].data_ptr() + 4 * i)

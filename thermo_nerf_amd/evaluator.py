@@ -49,7 +49,12 @@ class Evaluator:
             rb = cams.generate_rays(idx, device=self.device)
             h, w = rb.origins.shape[:2]
             flat = rb.flatten()
-            model.camera_optimizer.apply_to_raybundle(flat)  # REF :68-76 (indices address the optimizer's table)
+            # REF :68-76: the eval loader hands ONE camera at a time and the reference builds camera_indices =
+            # arange(cameras.camera_to_worlds.shape[0]) = [0] for it, so every eval image is adjusted with row 0 of the
+            # optimizer's table (never with the eval-split index, which may exceed num_train_data)
+            if flat.camera_indices is not None:
+                flat.camera_indices = torch.zeros_like(flat.camera_indices)
+            model.camera_optimizer.apply_to_raybundle(flat)
             rb = RayBundle(origins=flat.origins.view(h, w, 3), directions=flat.directions.view(h, w, 3),
                            pixel_area=rb.pixel_area, camera_indices=rb.camera_indices)
             outputs = model.get_outputs_for_camera_ray_bundle(rb)

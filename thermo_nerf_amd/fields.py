@@ -146,9 +146,11 @@ class HashMLPDensityField(nn.Module):
                                             num_layers, hidden_dim, 1)
         self.dense_budget_bytes = 0
 
-    def c_struct(self) -> _hip.tn_density_field:
+    def c_struct(self, dense: bool = True) -> _hip.tn_density_field:
+        """``dense=False`` (the training path): never the dense re-layout of the coarse levels — it is a derived copy of
+        the table, and the table is about to change."""
         f = _hip.tn_density_field()
-        f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes)
+        f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes if dense else 0)
         f.l0 = _hip.make_linear(self.mlp_base.mlp.layers[0])
         f.l1 = _hip.make_linear(self.mlp_base.mlp.layers[1])
         f.space = _hip.make_space(self.spatial_distortion is not None, self.aabb, owner=self)

@@ -92,9 +92,9 @@ class ThermalNerfactoTField(nn.Module):
         self._prepared_key = None
 
     # ------------------------------------------------------------------------------------------------
-    def c_struct(self, prepare: bool = False, precision: str = "f32") -> _hip.tn_thermal_field:
+    def c_struct(self, prepare: bool = False, precision: str = "f32", dense: bool = True) -> _hip.tn_thermal_field:
         f = _hip.tn_thermal_field()
-        f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes)
+        f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes if dense else 0)
         f.base0 = _hip.make_linear(self.mlp_base.mlp.layers[0])
         f.base1 = _hip.make_linear(self.mlp_base.mlp.layers[1])
         f.head0 = _hip.make_linear(self.mlp_head.layers[0])

@@ -186,7 +186,12 @@ class ThermalNerfModel(ThermalNerfactoModel):
         o = camera_ray_bundle.origins.reshape(-1, 3).to(self.device)
         d = camera_ray_bundle.directions.reshape(-1, 3).to(self.device)
         eng.rc.pdf_anneal = float(self.proposal_sampler._anneal)
-        out = eng.render(o, d)
+        nears, fars = camera_ray_bundle.nears, camera_ray_bundle.fars
+        if nears is not None and fars is not None:  # planes already on the bundle win over the collider's constants
+            nears, fars = nears.reshape(-1).to(self.device), fars.reshape(-1).to(self.device)
+        else:
+            nears = fars = None
+        out = eng.render(o, d, nears=nears, fars=fars)
         return {k: v.view(h, w, -1) for k, v in out.items()}
 
     # ------------------------------------------------------------------------------------------------
@@ -252,6 +257,13 @@ class ThermalNerfModel(ThermalNerfactoModel):
             outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
         outputs[RenderedImageModality.THERMAL.value] = self.thermal_renderer(field_outputs[FieldHeadNamesT.THERMAL], weights)
         return outputs
+
+    def train(self, mode: bool = True):
+        """Every switch between training and evaluation drops the derived weight copies: a fused optimizer may have stepped
+        since they were built (it does not bump Parameter._version), and the eval kernels must never see a stale blob or
+        dense re-layout."""
+        self.invalidate_prepared()
+        return super().train(mode)
 
     def invalidate_prepared(self) -> None:
         """Drop every derived copy of the weights (MFMA blobs, dense re-layouts, cached C structs).  The caches key on

@@ -134,6 +134,7 @@ class Trainer:
         for name, opt in self.optimizers.items():
             opt.step()
             self.schedulers[name].step()
+        model.invalidate_prepared()  # fused optimizers do not bump Parameter._version: derived copies are stale from here on
         return loss.detach(), loss_dict, metrics_dict
 
     def train(self, num_iterations: Optional[int] = None, checkpoint_dir=None, log_every: int = 0) -> List[float]:

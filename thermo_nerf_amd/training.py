@@ -185,8 +185,8 @@ class RenderTrain(torch.autograd.Function):
         S = cfg.num_nerf_samples_per_ray
         # use_same_proposal_network: ONE HashMLPDensityField serves both levels [REF thermal_nerf_model.py:127-139]
         nets = len(model.proposal_networks)
-        prop_structs = [model.proposal_networks[min(i, nets - 1)].c_struct() for i in range(2)]
-        fld = model.field.c_struct(prepare=False)
+        prop_structs = [model.proposal_networks[min(i, nets - 1)].c_struct(dense=False) for i in range(2)]
+        fld = model.field.c_struct(prepare=False, dense=False)
         anneal = float(model.proposal_sampler._anneal)
 
         # ---- proposal levels ---------------------------------------------------------------------------------
@@ -308,7 +308,7 @@ class RenderTrain(torch.autograd.Function):
         h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s = ctx.acts
         R, S = f.weights.shape
         N = R * S
-        fld = model.field.c_struct(prepare=False)
+        fld = model.field.c_struct(prepare=False, dense=False)
         like = ctx.params
         grads: Dict[str, Tensor] = {}
         # camera-pose optimisation: the ray origins / directions carry gradient (NS CameraOptimizer.apply_to_raybundle)
@@ -389,7 +389,7 @@ class RenderTrain(torch.autograd.Function):
                     continue
                 t = ctx.tapes[lvl]
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
-                net = model.proposal_networks[which].c_struct()
+                net = model.proposal_networks[which].c_struct(dense=False)
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", like,
                                     ray_grads)
 
