@@ -21,12 +21,12 @@ def fake_render(o, d):
     return out
 
 
-def _worker(rank, world, port, h, w, q):
+def _worker(rank, world, port, h, w, q, chunk=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         o, d, _ = synthetic.orbit_camera_rays(h, w, view=1)
-        full = D.render_frame_sharded(fake_render, o, d)
+        full = D.render_frame_sharded(fake_render, o, d, chunk=chunk)
         want = fake_render(o.reshape(-1, 3), d.reshape(-1, 3))
         ok = all(torch.equal(full[k].reshape(-1, full[k].shape[-1]), want[k]) for k in D.OUTPUT_KEYS)
         lo, hi = D.reduce_depth_bounds(torch.tensor(float(rank + 1)), torch.tensor(float(rank + 1)))
@@ -36,14 +36,15 @@ def _worker(rank, world, port, h, w, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w", [(16, 12), (7, 5)])  # even and uneven row blocks
-def test_row_sharded_frame_gathers_back(h, w):
+# even and uneven row blocks; chunk-aligned sharding: even chunk counts, a short last chunk, fewer chunks than ranks
+@pytest.mark.parametrize("h,w,chunk", [(16, 12, None), (7, 5, None), (16, 12, 48), (16, 12, 50), (7, 5, 64)])
+def test_row_sharded_frame_gathers_back(h, w, chunk):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, h, w, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, h, w, q, chunk)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -62,6 +63,17 @@ def test_row_blocks_partition_the_image():
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
             sizes = [b[1] - b[0] for b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_chunk_blocks_partition_the_frame_on_chunk_boundaries():
+    for n, chunk in ((640000, 65536), (2073600, 65536), (100, 64), (64, 64), (5, 64)):
+        for world in (1, 2, 3, 8):
+            blocks = [D.chunk_block(n, chunk, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            assert all(b[0] % chunk == 0 for b in blocks if b[0] < n)  # every shard starts on a reference chunk boundary
+            per = [-(-(b[1] - b[0]) // chunk) for b in blocks]
+            assert max(per) - min(per) <= 1
 
 
 def test_pack_unpack_roundtrip():

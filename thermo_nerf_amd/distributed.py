@@ -3,8 +3,12 @@
 The hot path has no cross-ray term, so a frame shards by contiguous ROW BLOCKS (keeps the ray
 coherence the field kernel's gathers rely on), weights are replicated (one broadcast at load, ~78 MB), and the only
 exchange is ONE all-gather of the rendered pixels: 9 floats = 36 B per ray.  The single cross-ray quantity of the
-reference — DepthRenderer("expected") clips to the call-global [min, max] of the sample mid-points — is reproduced by
-an all-reduce(min/max) of two floats when ``exact_depth_clip`` is requested.
+reference — DepthRenderer("expected") clips to the [min, max] of the sample mid-points of its CALL, i.e. of one
+``eval_num_rays_per_chunk`` chunk of the row-major frame — is reproduced exactly by sharding on CHUNK boundaries
+(``render_frame_sharded(..., chunk=eval_num_rays_per_chunk)``): every rank renders whole chunks of the reference's own
+chunking, so the sharded frame equals the single-device frame bit for bit, expected depth included, with no extra
+collective.  (Row-block sharding, ``chunk=None``, clips per rank-local chunk instead; ``reduce_depth_bounds`` is the
+two-scalar all-reduce for callers that want one frame-global clip.)
 
 The reference itself only ever renders on one device [REF thermo_nerf/render/renderer.py:182-187]; nerfstudio's DDP is
 training-only, so there is no NCCL call pattern to mirror here.
@@ -35,6 +39,15 @@ def shard_camera_rays(origins: Tensor, directions: Tensor, rank: int, world: int
     return (origins[r0:r1].reshape(-1, 3).contiguous(), directions[r0:r1].reshape(-1, 3).contiguous(), r0, r1)
 
 
+def chunk_block(num_rays: int, chunk: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rays [start, end) of a row-major frame owned by ``rank`` when the frame is cut on the boundaries of the reference's
+    chunks (``eval_num_rays_per_chunk`` rays each, REF config_thermal_nerf.py:30): contiguous runs of whole chunks, counts
+    differing by at most one chunk; the frame's last (short) chunk belongs to the last rank that owns any."""
+    n_chunks = (num_rays + chunk - 1) // chunk
+    c0, c1 = row_block(n_chunks, rank, world)
+    return min(c0 * chunk, num_rays), min(c1 * chunk, num_rays)
+
+
 def pack_outputs(out: Dict[str, Tensor]) -> Tensor:
     """dict of [n,C] -> [n,9] (the 36 B/ray tuple that crosses xGMI)."""
     return torch.cat([out[k] for k in OUTPUT_KEYS], dim=1)
@@ -48,11 +61,13 @@ def unpack_outputs(packed: Tensor) -> Dict[str, Tensor]:
     return res
 
 
-def gather_frame(local: Dict[str, Tensor], height: int, width: int, group=None) -> Dict[str, Tensor]:
-    """All-gather the per-rank row blocks into full [H,W,C] images on every rank (uneven row counts supported)."""
+def gather_frame(local: Dict[str, Tensor], height: int, width: int, group=None, counts=None) -> Dict[str, Tensor]:
+    """All-gather the per-rank ray ranges into full [H,W,C] images on every rank.  ``counts``: rays per rank in rank order
+    (default: row blocks); uneven counts are supported."""
     world = dist.get_world_size(group)
     packed = pack_outputs(local).contiguous()
-    counts = [(row_block(height, r, world)[1] - row_block(height, r, world)[0]) * width for r in range(world)]
+    if counts is None:
+        counts = [(row_block(height, r, world)[1] - row_block(height, r, world)[0]) * width for r in range(world)]
     if len(set(counts)) == 1:
         full = torch.empty((sum(counts), packed.shape[1]), dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(full, packed, group=group)
@@ -76,18 +91,32 @@ def reduce_depth_bounds(lo: Tensor, hi: Tensor, group=None) -> Tuple[Tensor, Ten
 
 
 def render_frame_sharded(render_fn: Callable[[Tensor, Tensor], Dict[str, Tensor]], origins: Tensor, directions: Tensor,
-                         group=None, device: Optional[torch.device] = None) -> Dict[str, Tensor]:
-    """Render one [H,W] camera ray bundle with the rows sharded over the process group.
+                         group=None, device: Optional[torch.device] = None, chunk: Optional[int] = None) -> Dict[str, Tensor]:
+    """Render one [H,W] camera ray bundle sharded over the process group; every rank returns the full [H,W,C] images.
 
-    ``render_fn(origins[n,3], directions[n,3]) -> dict of [n,C]`` is the per-rank renderer (RayRenderEngine.render on
-    the GPU box).  Every rank returns the full [H,W,C] images."""
+    ``render_fn(origins[n,3], directions[n,3]) -> dict of [n,C]`` is the per-rank renderer (``RayRenderEngine.render`` on
+    the GPU box).  ``chunk=None``: contiguous row blocks.  ``chunk=k``: contiguous runs of whole k-ray chunks of the
+    row-major frame — with ``k = eval_num_rays_per_chunk`` and an engine of the same chunk size every rank renders exactly
+    the calls the single-device loop makes [REF render/renderer.py:182-187], so the result is identical to it."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     h, w = origins.shape[:2]
-    o, d, _, _ = shard_camera_rays(origins, directions, rank, world)
+    if chunk is None:
+        o, d, _, _ = shard_camera_rays(origins, directions, rank, world)
+        counts = None
+    else:
+        n = h * w
+        r0, r1 = chunk_block(n, int(chunk), rank, world)
+        o = origins.reshape(-1, 3)[r0:r1].contiguous()
+        d = directions.reshape(-1, 3)[r0:r1].contiguous()
+        counts = [chunk_block(n, int(chunk), r, world)[1] - chunk_block(n, int(chunk), r, world)[0] for r in range(world)]
     if device is not None:
         o, d = o.to(device), d.to(device)
-    local = render_fn(o, d)
-    return gather_frame(local, h, w, group=group)
+    if o.shape[0] == 0:  # more ranks than chunks: this rank idles and only takes part in the gather
+        dev = o.device
+        local = {k: torch.empty((0, wd), dtype=torch.float32, device=dev) for k, wd in zip(OUTPUT_KEYS, OUTPUT_WIDTHS)}
+    else:
+        local = render_fn(o, d)
+    return gather_frame(local, h, w, group=group, counts=counts)
 
 
 class PipelinedFrameGather:
