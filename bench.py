@@ -1,20 +1,26 @@
-"""bench.py — rays/sec of the ThermoNeRF rendering hot path on MI355X (BASELINE.json metric, config 2).
+"""bench.py — rays/sec of the ThermoNeRF rendering hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A *step* is one pass of the hot path over one synthetic 800x800 frame (640 000 rays, forward-only, eval mode:
-proposal sampling 256+96 -> hash-grid+MLP field at S samples/ray -> alpha-composited RGB + thermal + depths),
-rendered with eval_num_rays_per_chunk = the frame (one proposal + one field launch per frame; --chunk 65536
-reproduces the reference config's chunking, REF config_thermal_nerf.py:30).  Rays and weights are resident in HBM
-before the timed region.  With N ranks every rank renders its own frame (view = rank; weak
-scaling, rays shard with no data-path dependency) and the rendered pixels (36 B/ray) are all-gathered over
-RCCL inside the timed region.
+Default workload = the configuration BASELINE.json's `metric` is quoted on: a synthetic 800x800 RGB+thermal scene at
+192 samples/ray, exact fp32.  A *step* is one pass of the hot path over one frame (640 000 rays, forward-only, eval mode:
+proposal sampling 256+96 -> hash-grid+MLP field at S samples/ray -> alpha-composited RGB + thermal + depths), rendered
+with eval_num_rays_per_chunk = the frame (one proposal + one field launch per frame).  Rays and weights are resident in
+HBM before the timed region.  On rank 0 at N = 1 the line also carries, under `variants`, BASELINE config 2 (S = 64), the
+reference config's chunking (eval_num_rays_per_chunk = 65 536, REF config_thermal_nerf.py:30), the opt-in f16x3 and
+early-termination forms, and the training step at S = 48 and S = 192 — each its own measurement, none of them `value`.
+
+N ranks (--shard weak, default): every rank renders its own frame (view = rank; rays shard with no data-path dependency)
+and the rendered pixels (36 B/ray) are all-gathered over RCCL inside the timed region, asynchronously.
+--shard frame (BASELINE config 4): ONE 1920x1080 frame, ray-sharded on the reference's chunk boundaries over the N ranks
+and all-gathered, every step; `value` = frame rays / frame latency, `scaling` = "strong".
 
 The JSON line also carries
-  roofline      the dominant kernel's achieved algorithmic HBM rate (HIP events on the launch stream, timed region)
-  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference path) timed on a bounded sample of the
-                same rays on this box's host cores (rank 0, N=1 only)
+  roofline      the dominant kernel's achieved rate (HIP events on the launch stream inside the timed region) against its
+                bound: fp32 MFMA flops for the exact-fp32 field kernel, with the HBM view alongside
+  cpu_baseline  the CPU oracle (torch fp32 restatement of the reference path) timed on a bounded sample of the same rays
+                on this box's host cores: best torch pool size AND one thread, CPU model stated (rank 0, N = 1 only)
 """
 from __future__ import annotations
 
@@ -33,7 +39,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate (= the FP32 vector rate)
 FIELD_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 63 * 64 + 64 * 64 + 64 * 3 + 15 * 64 + 64 * 64 + 64 * 1)  # 33 024
+PROP_FLOPS_PER_SAMPLE = 2 * (10 * 16 + 16)  # 352
 P0, P1 = 256, 96
+REF_CHUNK = 1 << 16  # REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:30
 
 
 def algorithmic_bytes_per_ray(S: int):
@@ -43,19 +51,29 @@ def algorithmic_bytes_per_ray(S: int):
     return prop, main, prop + main + 72
 
 
+def algorithmic_flops_per_ray(S: int) -> int:
+    return (P0 + P1) * PROP_FLOPS_PER_SAMPLE + FIELD_FLOPS_PER_SAMPLE * S
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", default="render", choices=["render", "train"],
-                    help="render (default): the BASELINE metric on config 2.  train: one optimisation step per 'step' "
+                    help="render (default): the BASELINE metric.  train: one optimisation step per 'step' "
                          "(BASELINE configs 3/5; with N ranks every rank trains its own scene replica, no collective)")
-    ap.add_argument("--samples", type=int, default=64, help="num_nerf_samples_per_ray (config 2: 64)")
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--shard", default="weak", choices=["weak", "frame"],
+                    help="N > 1 render: weak = one frame per rank (default); frame = ONE 1920x1080 frame ray-sharded over the "
+                         "ranks on chunk boundaries + all-gather (BASELINE config 4, strong scaling)")
+    ap.add_argument("--samples", type=int, default=None,
+                    help="num_nerf_samples_per_ray: 192 = the metric's configuration (default for render), 64 = config 2, "
+                         "48 = the reference default (default for --mode train and --shard frame)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=0,
-                    help="rays per launch = eval_num_rays_per_chunk; 0 (default) = the whole frame in one launch pair")
+                    help="rays per launch = eval_num_rays_per_chunk; 0 (default) = the whole frame in one launch pair "
+                         "(--shard frame: 65 536, the reference config)")
     ap.add_argument("--weights", default="scene", choices=["init", "stress", "scene"])
     ap.add_argument("--dense-mb", type=int, default=0)
     ap.add_argument("--no-mfma", action="store_true")
@@ -64,11 +82,26 @@ def parse():
     ap.add_argument("--early-eps", type=float, default=0.0,
                     help="early ray termination threshold (0 = off = the reference's arithmetic; NOT used for `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (profiling runs)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per CPU-baseline repeat")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int):
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int, S: int):
+    """the torch-CPU oracle on a strided sample of the same frame; reports the best torch pool size and the
+    one-thread figure, with the CPU model and the thread counts actually used."""
     from oracle import hotpath as H
 
     n = min(rays_per_rep, o.shape[0])
@@ -92,14 +125,33 @@ def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int):
                 break
         torch.set_num_threads(cores)
         reps, t_total, out = 0, 0.0, None
-        while reps < 2 or (t_total < 12.0 and reps < 10):
+        while reps < 2 or (t_total < 10.0 and reps < 10):
             t = time.perf_counter()
             out = H.get_outputs(sd, oc, dc, None, ocfg)
             t_total += time.perf_counter() - t
             reps += 1
+        # one thread (BASELINE.md §4 asks for both): a smaller sample, one warm-up + timed repeats of ~5 s in total
+        torch.set_num_threads(1)
+        n1 = min(256, n)
+        H.get_outputs(sd, oc[:32], dc[:32], None, ocfg)
+        reps1, t1 = 0, 0.0
+        while reps1 < 1 or (t1 < 5.0 and reps1 < 4):
+            t = time.perf_counter()
+            H.get_outputs(sd, oc[:n1], dc[:n1], None, ocfg)
+            t1 += time.perf_counter() - t
+            reps1 += 1
+        torch.set_num_threads(cores)
     return {"value": n * reps / t_total, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {n} rays strided over the same 800x800 frame, one oracle call per {n} rays, torch fp32 "
-                      f"CPU oracle, {cores} of {avail} host threads (fastest of the probed pool sizes)"}, idx, out
+            "cpu_model": cpu_model_name(), "host_threads": avail,
+            "single_thread": {"value": n1 * reps1 / t1, "unit": "rays/s", "cores": 1,
+                              "sample": f"{reps1} x {n1} rays of the same strided sample, torch.set_num_threads(1)"},
+            "sample": f"{reps} x {n} rays strided over the same 800x800 frame at {S} samples/ray, one oracle call per {n} rays, "
+                      f"torch fp32 CPU oracle, {cores} of {avail} host threads (fastest of the probed pool sizes)"}, idx, out
+
+
+def load_profile_json(name: str):
+    p = os.path.join(ROOT, "profiles", name)
+    return json.load(open(p)) if os.path.exists(p) else {}
 
 
 def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, warmup: int = 6, start_step: int = 5000,
@@ -145,9 +197,25 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
         step(start_step + warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / steps
+    _, _, b_all = algorithmic_bytes_per_ray(samples)
+    f_all = algorithmic_flops_per_ray(samples)
+    # a training step moves ~3x the forward's algorithmic bytes (forward reads + backward read-modify-write
+    # of the touched table entries) and does ~3x its MLP flops (forward + dx + dW).  The step is bound by HBM-side atomics
+    # and launch chains, so the whole step is priced against both ceilings; the dominant kernel (from the committed rocprof
+    # trace of tools/train_bench.py) is named beside it.
+    hbm = 3 * b_all * R / dt / 1e9
+    tfl = 3 * f_all * R / dt / 1e12
     res = {"what": "train step: taped forward + losses + backward + Adam, %d rays/step, P=(256,96)+%d samples/ray, "
                    "steps %d.. (proposal nets updated every 6th step), camera optimizer SO3xR3" % (R, samples, start_step),
-           "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps}
+           "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "roofline": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_ray": 3 * b_all, "algorithmic_flops_per_ray": 3 * f_all,
+                        "mfma_view": {"achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tfl / MFMA_F32_PEAK_TFLOPS},
+                        "kernel": "whole step (all launches between two optimizer steps)"}}
+    prof = load_profile_json("train_kernels.json").get("S%d" % samples)
+    if prof:
+        res["roofline"]["dominant_kernel"] = prof
     if cpu:
         from oracle import training as T
         from tests import helpers
@@ -163,9 +231,81 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
         T.loss_and_grads(sd_cpu, o_cpu[:n], d_cpu[:n], cam_cpu[:n], b, ocfg, jit)
         ct = time.perf_counter() - t
         res["cpu_baseline"] = {"value": n / ct, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "cpu_model": cpu_model_name(),
                                "sample": "1 x %d rays forward+backward (torch autograd over the CPU oracle), no optimizer "
                                          "step" % n}
+    del model, opt
+    torch.cuda.empty_cache()
     return res
+
+
+def build_render(dev, S, chunk, args, want_cpu_sd=False, streams=None):
+    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=chunk,
+                                 dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma,
+                                 mlp_precision=args.precision, early_termination_eps=args.early_eps)
+    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+    synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box
+    model.eval()
+    sd_cpu = synthetic.model_state_dict_cpu(model) if want_cpu_sd else None
+    model = model.to(dev)
+    return model, cfg, sd_cpu, RayRenderEngine(model, chunk=chunk, streams=streams)
+
+
+def timed_frames(engine, o, d, out, steps, warmup, after_step=None, barrier=None):
+    """W untimed + K timed renders of the resident ray set; returns (elapsed seconds, proposal ms list, field ms list)."""
+    def sync():
+        if barrier is not None:
+            barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        engine.render(o, d, out=out)
+        if after_step is not None:
+            after_step(out)
+    sync()
+    engine.timings = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        engine.render(o, d, out=out, record_events=True)
+        if after_step is not None:
+            after_step(out)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prop_ms, main_ms = engine.drain_timings()
+    return elapsed, prop_ms, main_ms
+
+
+def roofline_of(S, n_rays, steps, prop_ms, main_ms, precision, no_mfma, value_per_gpu):
+    b_prop, b_main, b_all = algorithmic_bytes_per_ray(S)
+    launches = len(main_ms)
+    rays_per_launch = n_rays * steps / launches  # a launch processes `chunk` rays (the last chunk of a frame is shorter)
+    avg_prop, avg_main = sum(prop_ms) / launches, sum(main_ms) / launches
+    dominant = "field_render" if avg_main >= avg_prop else "proposal_sample"
+    dom_ms = max(avg_main, avg_prop)
+    dom_bytes = (b_main + 36 + 24 + 4 * (S + 1)) if dominant == "field_render" else (b_prop + 24 + 4 * (S + 1) + 8)
+    achieved = dom_bytes * rays_per_launch / (dom_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": None, "kernel": dominant, "avg_launch_ms": dom_ms, "rays_per_launch": rays_per_launch,
+         "algorithmic_bytes_per_ray": dom_bytes, "proposal_ms": avg_prop, "field_ms": avg_main,
+         "path_bytes_per_ray": b_all, "path_frac": value_per_gpu * b_all / 1e9 / HBM_PEAK_GBS}
+    if dominant == "field_render" and precision == "f32" and not no_mfma:
+        # the exact-fp32 field kernel is bound by the matrix pipe, not by HBM (tables sit in L2/MALL; the f32-input MFMA
+        # runs at the FP32 vector rate and does not co-execute with VALU work, DESIGN.md 5.2): report THAT roofline and
+        # keep the HBM view alongside.  Algorithmic flops = the MLP MACs of the reference's field x 2, per sample.
+        tflops = FIELD_FLOPS_PER_SAMPLE * S * rays_per_launch / (dom_ms * 1e-3) / 1e12
+        r["hbm"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"]}
+        r.update({"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": tflops / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_ray": FIELD_FLOPS_PER_SAMPLE * S})
+    # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command (FETCH_SIZE + WRITE_SIZE of the
+    # dominant kernel, scaled to this launch size); see profiles/ for the raw counters
+    t = load_profile_json("pmc_traffic.json").get("%s@S%d%s" % (dominant, S, "" if precision == "f32" else "_f16x3"))
+    if t:
+        r["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1024.0 * rays_per_launch / t["rays_per_launch"]
+        r["traffic_source"] = t["source"]
+    return r
 
 
 def main():
@@ -173,6 +313,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -189,14 +330,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback exists in thermo_nerf_amd)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    solo = rank == 0 and world == 1
 
     if args.mode == "train":
         # per-GPU scene assignment (BASELINE config 5): independent replicas, no data-path collective; the timed region is
         # bracketed by barriers like the render mode and `value` is all ranks' rays over the slowest rank's time
         if world > 1:
             dist.barrier()
-        res = measure_train_step(dev, args.samples if args.samples != 64 else 48, steps=max(args.steps, 1),
-                                 warmup=max(args.warmup, 1), cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        res = measure_train_step(dev, args.samples or 48, steps=max(args.steps, 1), warmup=max(args.warmup, 1),
+                                 cpu=(solo and not args.no_cpu_baseline))
         t = torch.tensor([res["ms_per_step"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,7 +347,8 @@ def main():
             line = {"metric": "rays/sec (train step: forward + losses + backward + Adam) @ 4096 rays/step", "value": world * 4096 / (ms * 1e-3),
                     "unit": "rays/s", "n_gpus": world, "steps": res["steps"], "warmup": max(args.warmup, 1), "ms_per_step": ms,
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                    "config": {"workload": res["what"], "parallelism": "scene replica per rank x%d, no collective" % world}}
+                    "config": {"workload": res["what"], "parallelism": "scene replica per rank x%d, no collective" % world},
+                    "roofline": res["roofline"]}
             if "cpu_baseline" in res:
                 line["cpu_baseline"] = res["cpu_baseline"]
             print(json.dumps(line), flush=True)
@@ -213,26 +356,80 @@ def main():
             dist.destroy_process_group()
         return
 
-    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
-    from thermo_nerf_amd.engine import OUTPUT_KEYS, RayRenderEngine
+    from thermo_nerf_amd import synthetic
 
-    S = args.samples
+    if args.shard == "frame":
+        # BASELINE config 4: one 1920x1080 camera-path frame, ray-sharded on the reference's chunk boundaries
+        from thermo_nerf_amd import distributed as D
+
+        S = args.samples or 48
+        H_, W_ = args.height or 1080, args.width or 1920
+        chunk = args.chunk or REF_CHUNK
+        model, cfg, _, engine = build_render(dev, S, chunk, args)
+        o3, d3, _ = synthetic.orbit_camera_rays(H_, W_, view=3)
+        n_rays = H_ * W_
+        if world > 1:
+            r0, r1 = D.chunk_block(n_rays, chunk, rank, world)
+            counts = [D.chunk_block(n_rays, chunk, r, world)[1] - D.chunk_block(n_rays, chunk, r, world)[0] for r in range(world)]
+        else:
+            r0, r1, counts = 0, n_rays, [n_rays]
+        o = o3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
+        d = d3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
+        out = engine.allocate_outputs(max(r1 - r0, 1), dev)
+        frame = [None]
+
+        def step():
+            if r1 > r0:
+                engine.render(o, d, out=out)
+            local = {k: v[: r1 - r0] for k, v in out.items()}
+            # the frame exists (on every rank) once the gather is done: it is inside the step, not pipelined away
+            frame[0] = D.gather_frame(local, H_, W_, counts=counts) if world > 1 else local
+
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            _, _, b_all = algorithmic_bytes_per_ray(S)
+            value = n_rays * args.steps / elapsed
+            print(json.dumps({
+                "metric": "rays/sec (forward-only render, ONE frame ray-sharded over the GPUs) @ %dx%d, %d samples/ray" % (W_, H_, S),
+                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "frame_latency_ms": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "config 4: synthetic %dx%d camera-path frame, P=(256,96)+%d samples/ray, chunk %d, shards = "
+                                       "contiguous runs of whole chunks per rank (rays per rank: %s), all-gather of 36 B/ray in "
+                                       "the timed step" % (W_, H_, S, chunk, counts),
+                           "rays_per_step": n_rays, "parallelism": "one frame ray-sharded x%d + all_gather" % world},
+                "roofline": {"bound": "hbm", "achieved": value * b_all / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": value * b_all / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                             "kernel": "whole path, all ranks", "path_bytes_per_ray": b_all}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    S = args.samples or 192
+    H_, W_ = args.height or 800, args.width or 800
     if args.chunk <= 0:
-        args.chunk = args.height * args.width
-    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=args.chunk,
-                                 dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma,
-                                 mlp_precision=args.precision, early_termination_eps=args.early_eps)
-    model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
-    synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box
-    model.eval()
-    sd_cpu = synthetic.model_state_dict_cpu(model) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    model = model.to(dev)
-
-    o_cpu, d_cpu, _ = synthetic.orbit_camera_rays(args.height, args.width, view=rank % 8)
+        args.chunk = H_ * W_
+    model, cfg, sd_cpu, engine = build_render(dev, S, args.chunk, args, want_cpu_sd=(solo and not args.no_cpu_baseline))
+    o_cpu, d_cpu, _ = synthetic.orbit_camera_rays(H_, W_, view=rank % 8)
     o_cpu, d_cpu = o_cpu.reshape(-1, 3).contiguous(), d_cpu.reshape(-1, 3).contiguous()
     o, d = o_cpu.to(dev), d_cpu.to(dev)
     n_rays = o.shape[0]
-    engine = RayRenderEngine(model, chunk=args.chunk)
     out = engine.allocate_outputs(n_rays, dev)
     pipe = None
     if world > 1:
@@ -240,128 +437,113 @@ def main():
 
         pipe = PipelinedFrameGather(n_rays, world, dev)
 
-    def step(record: bool):
-        engine.render(o, d, out=out, record_events=record)
-        if pipe is not None:
-            # the exchange step of the path: rendered pixels (9 floats = 36 B per ray) all-gathered over RCCL/xGMI,
-            # asynchronously: the next frame renders while this one is on the links (double-buffered)
-            pipe.submit(out)
-
     def barrier():
         if pipe is not None:
             pipe.finish()  # every gather of the timed region completes inside it
             dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the exchange step of the path (N > 1): rendered pixels (9 floats = 36 B per ray) all-gathered over RCCL/xGMI,
+    # asynchronously: the next frame renders while this one is on the links (double-buffered)
+    elapsed, prop_ms, main_ms = timed_frames(engine, o, d, out, args.steps, args.warmup,
+                                             after_step=(pipe.submit if pipe is not None else None), barrier=barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prop_ms, main_ms = engine.drain_timings()
 
     if rank == 0:
-        total_rays = world * n_rays * args.steps
-        value = total_rays / elapsed
-        b_prop, b_main, b_all = algorithmic_bytes_per_ray(S)
-        # per-launch figures: a launch processes `chunk` rays (the last chunk of a frame is shorter; weight by rays)
-        launches = len(main_ms)
-        rays_per_launch = n_rays * args.steps / launches
-        avg_prop, avg_main = sum(prop_ms) / launches, sum(main_ms) / launches
-        dominant = "field_render" if avg_main >= avg_prop else "proposal_sample"
-        dom_ms = max(avg_main, avg_prop)
-        dom_bytes = (b_main + 36 + 24 + 4 * (S + 1)) if dominant == "field_render" else (b_prop + 24 + 4 * (S + 1) + 8)
-        achieved = dom_bytes * rays_per_launch / (dom_ms * 1e-3) / 1e9
+        value = world * n_rays * args.steps / elapsed
         line = {
-            "metric": "rays/sec (forward-only render) @ 800x800, %d samples/ray" % S,
+            "metric": "rays/sec (forward-only render) @ %dx%d, %d samples/ray" % (W_, H_, S),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via 3xf16-split MFMA products",
             "data": "synthetic",
-            "config": {"workload": "config 2: synthetic %dx%d RGB+thermal scene, P=(256,96)+%d samples/ray, chunk %d, "
-                                   "forward-only eval, %s weights%s" % (args.height, args.width, S, args.chunk, args.weights,
-                                                                         "" if args.early_eps <= 0 else
-                                                                         ", early ray termination eps=%g" % args.early_eps),
+            "config": {"workload": "%s: synthetic %dx%d RGB+thermal scene, P=(256,96)+%d samples/ray, chunk %d, "
+                                   "forward-only eval, %s weights%s" % (
+                                       "BASELINE metric configuration (configs[2]'s 192 samples/ray on the 800x800 frame of configs[1])"
+                                       if S == 192 else ("config 2" if S == 64 else "custom"),
+                                       W_, H_, S, args.chunk, args.weights,
+                                       "" if args.early_eps <= 0 else ", early ray termination eps=%g" % args.early_eps),
                        "rays_per_step_per_gpu": n_rays, "parallelism": "ray-shard x%d (one frame per rank)" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dominant,
-                         "avg_launch_ms": dom_ms, "rays_per_launch": rays_per_launch,
-                         "algorithmic_bytes_per_ray": dom_bytes,
-                         "proposal_ms": avg_prop, "field_ms": avg_main,
-                         "path_bytes_per_ray": b_all, "path_frac": value / world * b_all / 1e9 / HBM_PEAK_GBS},
+            "roofline": roofline_of(S, n_rays, args.steps, prop_ms, main_ms, args.precision, args.no_mfma, value / world),
         }
-        if dominant == "field_render" and args.precision == "f32" and not args.no_mfma:
-            # the exact-fp32 field kernel is bound by the matrix pipe, not by HBM (tables sit in L2/MALL; the f32-input MFMA
-            # runs at the FP32 vector rate and does not co-execute with VALU work): report THAT roofline and
-            # keep the HBM view alongside.  Algorithmic flops = the MLP MACs of the reference's field x 2, per sample.
-            tflops = FIELD_FLOPS_PER_SAMPLE * S * rays_per_launch / (dom_ms * 1e-3) / 1e12
-            r = line["roofline"]
-            r["hbm"] = {"achieved": r["achieved"], "peak": r["peak"], "unit": "GB/s", "frac": r["frac"]}
-            r.update({"bound": "mfma", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": tflops / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_ray": FIELD_FLOPS_PER_SAMPLE * S})
         if sd_cpu is not None:
             from tests import helpers  # oracle-side plumbing: only imported on the cpu_baseline leg
 
             ocfg = helpers.oracle_config(cfg)
-            base, idx, want = cpu_baseline(sd_cpu, ocfg, o_cpu, d_cpu, args.cpu_rays)
+            base, idx, want = cpu_baseline(sd_cpu, ocfg, o_cpu, d_cpu, args.cpu_rays, S)
             line["cpu_baseline"] = base
             # matched quality: the GPU frame vs the oracle on the very rays the baseline timed.  NOTE the oracle
             # clips expected_depth per call, the engine per chunk; rgb/thermal are chunk-independent.
-            got_rgb, got_th = out["rgb"][idx.to(dev)].cpu(), out["thermal"][idx.to(dev)].cpu()
-            line["parity"] = {"rgb_mae": float((got_rgb - want["rgb"]).abs().mean()),
-                              "thermal_mae": float((got_th - want["thermal"]).abs().mean()),
+            gidx = idx.to(dev)
+
+            def err(o_):
+                g_rgb, g_th = o_["rgb"][gidx].cpu(), o_["thermal"][gidx].cpu()
+                return float((g_rgb - want["rgb"]).abs().mean()), float((g_th - want["thermal"]).abs().mean()), g_rgb
+
+            rgb_mae, th_mae, got_rgb = err(out)
+            line["parity"] = {"rgb_mae": rgb_mae, "thermal_mae": th_mae,
                               "rgb_psnr_db_vs_oracle": float(10 * torch.log10(1.0 / ((got_rgb - want["rgb"]) ** 2).mean().clamp_min(1e-20)))}
             line["speedup_vs_cpu"] = value / base["value"]
-            if args.precision == "f32":
-                # secondary line: the opt-in split-precision field kernel on the same frame (NOT the headline value)
-                model.config.mlp_precision = "f16x3"
-                engine.render(o, d, out=out)
+        if solo and not args.no_variants and args.precision == "f32" and args.early_eps <= 0:
+            variants = {}
+
+            def quick(eng, reps=3):
+                eng.render(o, d, out=out)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(3):
-                    engine.render(o, d, out=out)
+                for _ in range(reps):
+                    eng.render(o, d, out=out)
                 torch.cuda.synchronize()
-                v = 3 * n_rays / (time.perf_counter() - t1)
-                g_rgb, g_th = out["rgb"][idx.to(dev)].cpu(), out["thermal"][idx.to(dev)].cpu()
-                line["variants"] = {"f16x3": {
-                    "what": "field MLP products as 3 f16 MFMA products each, fp32 accumulate (mlp_precision=f16x3)",
-                    "value": v, "unit": "rays/s", "rgb_mae": float((g_rgb - want["rgb"]).abs().mean()),
-                    "thermal_mae": float((g_th - want["thermal"]).abs().mean())}}
-                model.config.mlp_precision = "f32"
-                if args.early_eps <= 0:
-                    # opt-in early ray termination (wave-wide transmittance vote), exact-fp32 kernels; outputs move by <= eps
-                    engine.rc.early_stop_transmittance = 1e-3
-                    engine.render(o, d, out=out)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        engine.render(o, d, out=out)
-                    torch.cuda.synchronize()
-                    v = 3 * n_rays / (time.perf_counter() - t1)
-                    g_rgb, g_th = out["rgb"][idx.to(dev)].cpu(), out["thermal"][idx.to(dev)].cpu()
-                    line["variants"]["early_termination_1e-3"] = {
-                        "what": "early_termination_eps=1e-3 (a 64-ray tile stops once every ray's transmittance is below it)",
-                        "value": v, "unit": "rays/s", "rgb_mae": float((g_rgb - want["rgb"]).abs().mean()),
-                        "thermal_mae": float((g_th - want["thermal"]).abs().mean())}
-                    engine.rc.early_stop_transmittance = 0.0
-                del engine, out
+                return reps * n_rays / (time.perf_counter() - t1)
+
+            # the opt-in split-precision field kernel on the same frame (NOT the headline value)
+            model.config.mlp_precision = "f16x3"
+            v = quick(engine)
+            variants["f16x3"] = {"what": "field MLP products as 3 f16 MFMA products each, fp32 accumulate (mlp_precision=f16x3), "
+                                         "same %d-sample frame" % S, "value": v, "unit": "rays/s"}
+            if sd_cpu is not None:
+                variants["f16x3"]["rgb_mae"], variants["f16x3"]["thermal_mae"], _ = err(out)
+            model.config.mlp_precision = "f32"
+            # opt-in early ray termination (wave-wide transmittance vote), exact-fp32 kernels; outputs move by <= eps
+            engine.rc.early_stop_transmittance = 1e-3
+            v = quick(engine)
+            variants["early_termination_1e-3"] = {
+                "what": "early_termination_eps=1e-3 (a 64-ray tile stops once every ray's transmittance is below it), same "
+                        "%d-sample frame" % S, "value": v, "unit": "rays/s"}
+            if sd_cpu is not None:
+                variants["early_termination_1e-3"]["rgb_mae"], variants["early_termination_1e-3"]["thermal_mae"], _ = err(out)
+            engine.rc.early_stop_transmittance = 0.0
+            # the reference config's chunking: eval_num_rays_per_chunk = 65 536 (two HIP streams alternate the chunks)
+            from thermo_nerf_amd.engine import RayRenderEngine
+
+            eng_c = RayRenderEngine(model, chunk=REF_CHUNK)
+            e_c, p_c, m_c = timed_frames(eng_c, o, d, out, max(3, args.steps // 2), 1)
+            variants["reference_chunking_65536"] = {
+                "what": "same frame in eval_num_rays_per_chunk = 65 536 launches (REF config_thermal_nerf.py:30), chunks "
+                        "alternating over %d HIP streams" % eng_c.num_streams,
+                "value": n_rays * max(3, args.steps // 2) / e_c, "unit": "rays/s",
+                "ms_per_frame": e_c / max(3, args.steps // 2) * 1e3, "launch_pairs_per_frame": len(m_c) // max(3, args.steps // 2)}
+            del eng_c
+            if S != 64:
+                # BASELINE config 2 (64 samples/ray) on the same frame and rays, with its own roofline
+                del engine
                 torch.cuda.empty_cache()
-                line["variants"]["train_step"] = measure_train_step(dev, 48)
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command (FETCH_SIZE +
-            # WRITE_SIZE of the dominant kernel, scaled to this launch size); see profiles/ for the raw counters
-            t = json.load(open(pmc)).get(dominant if args.precision == "f32" else dominant + "_f16x3")
-            if t:
-                line["roofline"]["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1024.0 * rays_per_launch / t["rays_per_launch"]
-                line["roofline"]["traffic_source"] = t["source"]
+                m64, _, _, e64 = build_render(dev, 64, args.chunk, args)
+                k64 = max(5, args.steps)
+                el, p64, f64 = timed_frames(e64, o, d, out, k64, 2)
+                v64 = n_rays * k64 / el
+                variants["config2_S64"] = {"what": "BASELINE config 2: same 800x800 frame at 64 samples/ray, one launch pair per frame",
+                                           "value": v64, "unit": "rays/s", "ms_per_step": el / k64 * 1e3, "steps": k64,
+                                           "roofline": roofline_of(64, n_rays, k64, p64, f64, "f32", args.no_mfma, v64)}
+                del m64, e64
+            del model, out
+            torch.cuda.empty_cache()
+            cpu_train = sd_cpu is not None
+            variants["train_step_S48"] = measure_train_step(dev, 48, cpu=cpu_train)
+            variants["train_step_S192"] = measure_train_step(dev, 192, cpu=False)
+            line["variants"] = variants
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

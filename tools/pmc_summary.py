@@ -1,6 +1,8 @@
 """Summarise rocprofv3 --pmc csv passes into profiles/<name>.txt and refresh profiles/pmc_traffic.json.
 
-usage: python tools/pmc_summary.py <dir with pass sub-dirs a/ b/ c/> <out.txt> <f32|f16x3> "<title>"
+usage: python tools/pmc_summary.py <dir with pass sub-dirs a/ b/ c/> <out.txt> <f32|f16x3> "<title>" [samples_per_ray=192]
+(run in the build container on the csv files gpurun merged back; the summary is stamped with `git rev-parse HEAD` — commit
+the kernels BEFORE the gpurun call that collects the counters, so the stamp is the commit that was measured)
 Each pass dir holds *_counter_collection.csv written by
     rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir>/<pass> -o <pass> -- python bench.py ...
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are reported in KB, and on gfx950
@@ -24,8 +26,22 @@ def short(name):
     return None
 
 
+def head_stamp():
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "thermo_nerf_amd", "bench.py"], cwd=root,
+                               capture_output=True, text=True, check=True).stdout.strip()
+        return head + (" (+ uncommitted changes under thermo_nerf_amd/ or bench.py)" if dirty else "")
+    except Exception:
+        return "unknown"
+
+
 def main():
     d, dst, prec, title = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    S = int(sys.argv[5]) if len(sys.argv) > 5 else 192
     acc = defaultdict(list)  # (kernel, counter) -> per-dispatch values
     for p in sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))):
         per = defaultdict(float)  # (dispatch, kernel, counter) -> summed over instances
@@ -36,7 +52,7 @@ def main():
         for (_, k, c), v in per.items():
             acc[(k, c)].append(v)
     with open(dst, "w") as out:
-        out.write(f"# {title}\n")
+        out.write(f"# {title}\n# measured at commit {head_stamp()}\n")
         out.write("# separate --pmc passes (one sub-directory each); mean per dispatch.  GRBM_GUI_ACTIVE is summed over the 8 XCDs;\n"
                   "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles; FETCH_SIZE / WRITE_SIZE in KB as reported.\n")
         out.write("kernel,counter,dispatches,mean_per_dispatch\n")
@@ -47,8 +63,9 @@ def main():
     for k, name in KEY.items():
         f, w = acc.get((k, "FETCH_SIZE")), acc.get((k, "WRITE_SIZE"))
         if f and w:
-            traffic[name + ("" if prec == "f32" else "_f16x3")] = {
+            traffic[name + "@S%d" % S + ("" if prec == "f32" else "_f16x3")] = {
                 "fetch_kb": 2.0 * sum(f) / len(f), "write_kb": sum(w) / len(w), "rays_per_launch": 640000,
+                "commit": head_stamp(),
                 "source": f"profiles/{os.path.basename(dst)} (2 x FETCH_SIZE per the MI355X_MICROARCH.md gfx950 note + "
                           "WRITE_SIZE, KB; 8-byte gathers, uncalibrated)"}
     json.dump(traffic, open(tj, "w"), indent=1)

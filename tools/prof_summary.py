@@ -5,6 +5,8 @@ import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 
 def from_db(path, out):
     con = sqlite3.connect(path)
@@ -28,7 +30,9 @@ def main():
     d, dst = sys.argv[1], sys.argv[2]
     title = sys.argv[3] if len(sys.argv) > 3 else d
     with open(dst, "w") as out:
-        out.write(f"# {title}\n")
+        from pmc_summary import head_stamp  # same directory
+
+        out.write(f"# {title}\n# measured at commit {head_stamp()}\n")
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         for p in dbs:
             out.write(f"# source: {os.path.basename(p)}\n")
