@@ -25,6 +25,12 @@ __device__ __forceinline__ float nan_to_num(float x) {
     return x;
 }
 
+// ReLU of a value that comes out of an MFMA accumulator.  fmaxf(x, 0) lowers to v_max_f32 x, x (canonicalise) + v_max_f32 x, 0:
+// hipcc cannot see that matrix-core results are already canonical.  The signed-integer max of the bit pattern is ONE v_max_i32:
+// negative floats (sign bit set, -0 included) are negative integers -> +0, everything else passes through unchanged (a NaN
+// with a clear sign bit stays NaN, like torch.relu).  Same value as fmaxf for every non-NaN input.
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 // ---- arithmetic flavour -------------------------------------------------------------------------------
 // FAST = false (default; every plugin-surface kernel): IEEE division, full-precision expf, torch's three-rounding
 // interpolation — the op order of the torch reference.
@@ -168,19 +174,41 @@ __device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, f
         // coordinates are >= 0: ceil = floor + (offset > 0), so the ceil corner's hash product is the floor corner's plus
         // 0 or the prime (mod 2^32) — two quarter-rate integer multiplies instead of four, no v_ceil / second convert
         const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
-        const unsigned cx = fx + (ox > 0.0f ? 1u : 0u);
+        // FAST: the reference's ceil corner is floor + 1 unless the coordinate sits exactly on a grid plane — and there its
+        // interpolation weight (the offset) is exactly 0, so whichever finite entry is read the result is the same bit for
+        // bit: always read floor + 1 (no compare / select per axis).  The torch-order kernels keep the reference's index.
+        const unsigned cx = fx + ((FAST || ox > 0.0f) ? 1u : 0u);
         const unsigned hfy = fy * TN_P1, hfz = fz * TN_P2;
-        const unsigned hcy = hfy + (oy > 0.0f ? TN_P1 : 0u), hcz = hfz + (oz > 0.0f ? TN_P2 : 0u);
-        const float2 *t = g.table + (size_t)l * g.tsize;
-        const unsigned m = g.mask;
-        f0 = t[(cx ^ hcy ^ hcz) & m];
-        f1 = t[(cx ^ hfy ^ hcz) & m];
-        f2 = t[(fx ^ hfy ^ hcz) & m];
-        f3 = t[(fx ^ hcy ^ hcz) & m];
-        f4 = t[(cx ^ hcy ^ hfz) & m];
-        f5 = t[(cx ^ hfy ^ hfz) & m];
-        f6 = t[(fx ^ hfy ^ hfz) & m];
-        f7 = t[(fx ^ hcy ^ hfz) & m];
+        const unsigned hcy = hfy + ((FAST || oy > 0.0f) ? TN_P1 : 0u), hcz = hfz + ((FAST || oz > 0.0f) ? TN_P2 : 0u);
+        if (FAST) {
+            // byte offsets straight from the hash: ((x ^ y P1 ^ z P2) & (T-1)) * 8 == (8x ^ y (8 P1) ^ z (8 P2)) & (8 (T-1))
+            // (mod 2^32; log2 T <= 24 keeps the masked bits below 2^27).  A wave-uniform level base + a 32-bit lane offset is
+            // the scalar-base form of global_load (no 64-bit address arithmetic per corner).
+            const unsigned x0 = fx << 3, x1 = x0 + 8u;
+            const unsigned y0 = fy * (TN_P1 << 3), y1 = y0 + (TN_P1 << 3);
+            const unsigned z0 = fz * (TN_P2 << 3), z1 = z0 + (TN_P2 << 3);
+            const unsigned m8 = g.mask << 3;
+            const char *tb = reinterpret_cast<const char *>(g.table + (size_t)l * g.tsize);
+            f0 = *reinterpret_cast<const float2 *>(tb + ((x1 ^ y1 ^ z1) & m8));
+            f1 = *reinterpret_cast<const float2 *>(tb + ((x1 ^ y0 ^ z1) & m8));
+            f2 = *reinterpret_cast<const float2 *>(tb + ((x0 ^ y0 ^ z1) & m8));
+            f3 = *reinterpret_cast<const float2 *>(tb + ((x0 ^ y1 ^ z1) & m8));
+            f4 = *reinterpret_cast<const float2 *>(tb + ((x1 ^ y1 ^ z0) & m8));
+            f5 = *reinterpret_cast<const float2 *>(tb + ((x1 ^ y0 ^ z0) & m8));
+            f6 = *reinterpret_cast<const float2 *>(tb + ((x0 ^ y0 ^ z0) & m8));
+            f7 = *reinterpret_cast<const float2 *>(tb + ((x0 ^ y1 ^ z0) & m8));
+        } else {
+            const float2 *t = g.table + (size_t)l * g.tsize;
+            const unsigned m = g.mask;
+            f0 = t[(cx ^ hcy ^ hcz) & m];
+            f1 = t[(cx ^ hfy ^ hcz) & m];
+            f2 = t[(fx ^ hfy ^ hcz) & m];
+            f3 = t[(fx ^ hcy ^ hcz) & m];
+            f4 = t[(cx ^ hcy ^ hfz) & m];
+            f5 = t[(cx ^ hfy ^ hfz) & m];
+            f6 = t[(fx ^ hfy ^ hfz) & m];
+            f7 = t[(fx ^ hcy ^ hfz) & m];
+        }
     }
     float2 r;
     {

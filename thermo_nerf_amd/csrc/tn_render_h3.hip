@@ -140,7 +140,7 @@ __device__ __forceinline__ HL split8(const f32x16 &x, int q) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float v = x[8 * q + e];
-        if (RELU) v = fmaxf(v, 0.0f);
+        if (RELU) v = relu_bits(v);
         const _Float16 hh = (_Float16)v;
         r.hi[e] = hh;
         r.lo[e] = (_Float16)(v - (float)hh);
@@ -230,8 +230,8 @@ __device__ __forceinline__ float2 out_dot_fast(const float *wrow, int h, const f
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a0 = x[mt][0][4 * q + e], a1 = x[mt][1][4 * q + e];
-                const float v0 = ACT ? fast_sigmoid(a0) : fmaxf(a0, 0.0f);
-                const float v1 = ACT ? fast_sigmoid(a1) : fmaxf(a1, 0.0f);
+                const float v0 = ACT ? fast_sigmoid(a0) : relu_bits(a0);
+                const float v1 = ACT ? fast_sigmoid(a1) : relu_bits(a1);
                 p0 = fmaf(ww[e], v0, p0);
                 p1 = fmaf(ww[e], v1, p1);
             }

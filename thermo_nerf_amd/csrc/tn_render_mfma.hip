@@ -11,9 +11,18 @@
 // register carries is baked into the pre-permuted A fragments by tn_field_prepare).  No activation ever goes
 // through LDS; the hash-grid features enter the first layer through 16 v_permlane32_swap.
 //
-// Work per 64 samples: 448 MFMAs (base 32->64: 64, 64->16: 64, geo->colour/thermal hidden: 32+32, 64->64: 128+128)
-// = 28.7 k MFMA cycles per SIMD; SH + appearance fold into a per-RAY bias of the colour layer; the 64->3 and
+// Work per 64 samples: 384 32x32x2 MFMAs (base 32->64: 64, geo->colour/thermal hidden: 32+32, 64->64: 128+128) + 64
+// 16x16x4 MFMAs (base 64->16: its 16 output rows fill a 16x16 tile exactly; as a 32-row tile half the matrix work would be
+// zero rows) = 26.6 k MFMA cycles per SIMD; SH + appearance fold into a per-RAY bias of the colour layer; the 64->3 and
 // 64->1 output layers are VALU dot products on the accumulator registers.
+//
+// Layout changes between the two tile shapes cost one v_permlane16_swap per two registers:
+//   32x32 C/D -> 16x16x4 B:  swap16(R, R') of two accumulator registers = [R.row0 R'.row0 R.row2 R'.row2] and
+//                            [R.row1 R'.row1 R.row3 R'.row3] (row = 16 lanes): samples 0-15 resp. 16-31 of the 32-sample
+//                            tile, each with four features in the four 16-lane groups = one k-step of 16x16x4 for each of
+//                            the two 16-sample tiles
+//   16x16 C/D -> 32x32x2 B:  swap16(G_2n[q], G_2n+1[q]) = rows (q | 8+q) and (4+q | 12+q) of the 32 samples of tile n in the
+//                            lower | upper 32 lanes = two k-steps of the geo -> hidden layers
 #include "tn_field_eval.h"
 
 using namespace tn;
@@ -21,6 +30,7 @@ using namespace tn;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / TN_WAVE;
@@ -31,7 +41,7 @@ constexpr int GF = 15, APP = 32, L16 = 16, IN0 = 16 + GF + APP;
 constexpr int LG = TN_LEVEL_GROUP;  // hash levels whose gathers are in flight together
 
 // ---- prepared blob / LDS layout (floats) ---------------------------------------------------------------
-constexpr int A_BASE1 = 0, A_BASE2 = 32, A_C1 = 64, A_T1 = 80, A_C2 = 96, A_T2 = 160, A_SH = 224, A_COMBOS = 240;
+constexpr int A_BASE1 = 0, A_BASE2 = 32, A_C1 = 48, A_T1 = 64, A_C2 = 80, A_T2 = 144, A_SH = 208, A_COMBOS = 224;
 constexpr int OFF_A = 0;
 constexpr int OFF_B_BASE1 = A_COMBOS * 64;        // [64]
 constexpr int OFF_B_BASE2 = OFF_B_BASE1 + 64;     // [32] rows 0..15 valid
@@ -50,6 +60,8 @@ constexpr int LDS_FLOATS = OFF_SCRATCH + kWaves * 64;
 static_assert(BLOB_FLOATS % 4 == 0, "blob must be float4-copyable");
 
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// geo row (0 = raw density, 1..15 = geo features) fed by k-step j of the geo -> hidden layers in lane half h (see swap16 above)
+__device__ __forceinline__ int grow(int j, int h) { return (j >> 1) + ((j & 1) ? 4 : 0) + 8 * h; }
 
 struct RawField {
     const float *b0w, *b0b, *b1w, *b1b, *h0w, *h0b, *h1w, *h1b, *h2w, *h2b, *t0w, *t0b, *t1w, *t1b, *thw, *thb;
@@ -66,14 +78,14 @@ __global__ void field_prepare_kernel(RawField w, float *__restrict__ blob) {
         if (combo < A_BASE2) {  // mlp_base layer 0: [64,32]; k-step s feeds features (2s, 2s+1)
             const int mt = combo >> 4, s = combo & 15;
             v = w.b0w[(i + 32 * mt) * 32 + 2 * s + h];
-        } else if (combo < A_C1) {  // mlp_base layer 1: [16,64]
-            const int c = combo - A_BASE2, mi = c >> 4, s = c & 15;
-            v = (i < 1 + GF) ? w.b1w[i * 64 + 32 * mi + crow(s, h)] : 0.0f;
+        } else if (combo < A_C1) {  // mlp_base layer 1: [16,64] as 16x16x4 A fragments: lane = (out row l&15, k slot l>>4)
+            const int c = combo - A_BASE2, mi = c >> 3, rp = c & 7, slot = lane >> 4;
+            v = w.b1w[(lane & 15) * 64 + 32 * mi + crow(2 * rp + (slot & 1), slot >> 1)];
         } else if (combo < A_T1) {  // mlp_head layer 0, geo columns [16, 16+GF); row 0 of the input is the raw density
-            const int c = combo - A_C1, mt = c >> 3, s = c & 7, row = crow(s, h);
+            const int c = combo - A_C1, mt = c >> 3, j = c & 7, row = grow(j, h);
             v = (row >= 1) ? w.h0w[(i + 32 * mt) * IN0 + 16 + (row - 1)] : 0.0f;
         } else if (combo < A_C2) {  // mlp_thermal layer 0: [64,15]
-            const int c = combo - A_T1, mt = c >> 3, s = c & 7, row = crow(s, h);
+            const int c = combo - A_T1, mt = c >> 3, j = c & 7, row = grow(j, h);
             v = (row >= 1) ? w.t0w[(i + 32 * mt) * GF + (row - 1)] : 0.0f;
         } else if (combo >= A_SH) {  // mlp_head layer 0, SH columns [0,16): k-step s feeds SH comps (2s, 2s+1)
             const int c = combo - A_SH, mt = c >> 3, s = c & 7;
@@ -143,6 +155,7 @@ struct MfmaArgs {
 };
 
 #define MFMA32(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
+#define MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
 
 // accumulator init from a natural-order bias vector in LDS: reg r <- bias[32*mt + crow(r,h)]
 __device__ __forceinline__ f32x16 bias_frag(const float *bias, int mt, int h) {
@@ -165,6 +178,41 @@ __device__ __forceinline__ void swap32(float a, float b, float &lo, float &hi) {
     hi = __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ void swap16(float a, float b, float &even, float &odd) {
+    // even = [a.row0 b.row0 a.row2 b.row2], odd = [a.row1 b.row1 a.row3 b.row3]   (row = 16 lanes)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    even = __uint_as_float(r[0]);
+    odd = __uint_as_float(r[1]);
+}
+
+// mlp_base layer 1 (64 -> 1 + geo = 16 rows, no activation) on relu(h1), then its outputs re-laid as the B operands of the
+// eight k-steps of the geo -> hidden layers: gb[nt][j] (k rows grow(j, 0) | grow(j, 1)).  gb[nt][0] lanes 0-31 = raw density.
+__device__ __forceinline__ void base2_geo(const float *A, const float *bias16, int lane, const f32x16 (&h1)[2][2],
+                                          float (&gb)[2][8]) {
+    const float4 bq = *reinterpret_cast<const float4 *>(bias16 + 4 * (lane >> 4));  // C rows 4 (l >> 4) + q
+    const f32x4 b4 = {bq.x, bq.y, bq.z, bq.w};
+    f32x4 G[4] = {b4, b4, b4, b4};  // 16-sample tiles 0..3
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const float aw = A[(A_BASE2 + mi * 8 + rp) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float lo, hi;
+                swap16(relu_bits(h1[mi][nt][2 * rp]), relu_bits(h1[mi][nt][2 * rp + 1]), lo, hi);
+                MFMA16(G[2 * nt], aw, lo);
+                MFMA16(G[2 * nt + 1], aw, hi);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) swap16(G[2 * nt][q], G[2 * nt + 1][q], gb[nt][2 * q], gb[nt][2 * q + 1]);
+    }
+}
+
 // one 64 -> 64 layer: out[mt][nt] = bias + sum over (mi, s) A[mt][mi][s] x relu(in[mi][nt][s])
 __device__ __forceinline__ void layer64(const float *A, int combo0, const float *bias, int lane, int h,
                                         const f32x16 (&in)[2][2], f32x16 (&out)[2][2]) {
@@ -177,7 +225,7 @@ __device__ __forceinline__ void layer64(const float *A, int combo0, const float 
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float b0 = fmaxf(in[mi][0][s], 0.0f), b1 = fmaxf(in[mi][1][s], 0.0f);
+            const float b0 = relu_bits(in[mi][0][s]), b1 = relu_bits(in[mi][1][s]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const float a = A[(combo0 + mt * 32 + mi * 16 + s) * 64 + lane];
@@ -190,7 +238,7 @@ __device__ __forceinline__ void layer64(const float *A, int combo0, const float 
 
 // geo (rows 1..15 of g) -> 64 hidden: out[mt][nt] = bias + sum_s A[mt][s] x g[nt][s], s = 0..7
 __device__ __forceinline__ void layer_geo(const float *A, int combo0, const float *bias, int lane, int h,
-                                          const f32x16 (&g)[2], f32x16 (&out)[2][2]) {
+                                          const float (&g)[2][8], f32x16 (&out)[2][2]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         out[mt][0] = bias_frag(bias, mt, h);
@@ -220,8 +268,8 @@ __device__ __forceinline__ float2 out_dot(const float *wrow, int h, const f32x16
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a0 = x[mt][0][4 * q + e], a1 = x[mt][1][4 * q + e];
-                const float v0 = ACT ? sigmoidf(a0) : fmaxf(a0, 0.0f);
-                const float v1 = ACT ? sigmoidf(a1) : fmaxf(a1, 0.0f);
+                const float v0 = ACT ? sigmoidf(a0) : relu_bits(a0);
+                const float v1 = ACT ? sigmoidf(a1) : relu_bits(a1);
                 p0 = fmaf(ww[e], v0, p0);
                 p1 = fmaf(ww[e], v1, p1);
             }
@@ -329,20 +377,10 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
                     MFMA32(h1[mt][1], aw, bt1[s]);
                 }
             }
-            // ---- mlp_base layer 1: 64 -> 16 (rows 0..15 of one M tile) -------------------------------------
-            f32x16 g[2];
-            g[0] = bias_frag(lds + OFF_B_BASE2, 0, h);
-            g[1] = g[0];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float aw = A[(A_BASE2 + mi * 16 + s) * 64 + lane];
-                    MFMA32(g[0], aw, fmaxf(h1[mi][0][s], 0.0f));
-                    MFMA32(g[1], aw, fmaxf(h1[mi][1][s], 0.0f));
-                }
-            }
-            // row 0 (reg 0 of the lower half) is the raw density of sample l&31 of each tile -> lane = sample
+            // ---- mlp_base layer 1: 64 -> 16 on 16x16x4 tiles, outputs re-laid for the geo -> hidden layers ----
+            float g[2][8];
+            base2_geo(A, lds + OFF_B_BASE2, lane, h1, g);
+            // row 0 (lanes 0-31 of k-step 0) is the raw density of sample l&31 of each tile -> lane = sample
             float raw, unused;
             swap32(g[0][0], g[1][0], raw, unused);
             const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
@@ -439,7 +477,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
 // form spreads its 64 lanes along one ray: every fine-level gather is 64 distinct lines and the kernel was bound
 // by the random-access rate of TCP/L2).  Compositing becomes a per-lane running sum — no cross-lane scan at all.
 // The per-ray SH(dir) contribution of the colour layer rides along as 8 extra k-steps (B operands built once per
-// ray group), so a pass is 480 MFMAs; the appearance term is folded into the bias by tn_field_prepare (eval).
+// ray group), so a pass is 416 32x32x2 + 64 16x16x4 MFMAs; the appearance term is folded into the bias by tn_field_prepare (eval).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_sigmoid(float x) {
     // v_exp_f32 / v_rcp_f32 (1 ulp each): |error| < 3e-7 absolute on a value in (0,1)
@@ -458,8 +496,8 @@ __device__ __forceinline__ float2 out_dot_fast(const float *wrow, int h, const f
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a0 = x[mt][0][4 * q + e], a1 = x[mt][1][4 * q + e];
-                const float v0 = ACT ? fast_sigmoid(a0) : fmaxf(a0, 0.0f);
-                const float v1 = ACT ? fast_sigmoid(a1) : fmaxf(a1, 0.0f);
+                const float v0 = ACT ? fast_sigmoid(a0) : relu_bits(a0);
+                const float v1 = ACT ? fast_sigmoid(a1) : relu_bits(a1);
                 p0 = fmaf(ww[e], v0, p0);
                 p1 = fmaf(ww[e], v1, p1);
             }
@@ -468,6 +506,7 @@ __device__ __forceinline__ float2 out_dot_fast(const float *wrow, int h, const f
     return make_float2(p0, p1);
 }
 
+template <bool DENSE>
 __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -519,7 +558,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
 #pragma unroll
             for (int l0 = 0; l0 < L16; l0 += LG) {
                 float2 f[LG];
-                if (a.g.num_dense == 0) {
+                if (!DENSE) {  // compile-time: the hashed instantiation carries none of the dense-level arguments
 #pragma unroll
                     for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);
                 } else {
@@ -545,18 +584,8 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
                     MFMA32(h1[mt][1], aw, bt1[s]);
                 }
             }
-            f32x16 g[2];
-            g[0] = bias_frag(lds + OFF_B_BASE2, 0, h);
-            g[1] = g[0];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float aw = A[(A_BASE2 + mi * 16 + s) * 64 + lane];
-                    MFMA32(g[0], aw, fmaxf(h1[mi][0][s], 0.0f));
-                    MFMA32(g[1], aw, fmaxf(h1[mi][1][s], 0.0f));
-                }
-            }
+            float g[2][8];
+            base2_geo(A, lds + OFF_B_BASE2, lane, h1, g);
             float raw, unused;
             swap32(g[0][0], g[1][0], raw, unused);
             const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
@@ -669,11 +698,16 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     const bool small_call = cfg->kernel_family == 2 || (cfg->kernel_family == 0 && num_rays < 57344);
     if (!cfg->training && !out->weights[2] && !small_call) {
         // eval: lane = ray (64 consecutive rays per wave), coherent gathers
-        if (!tn_ensure_dynamic_lds<main_mfma_rays_kernel>(smem)) return TN_ERR_LAUNCH;
+        const bool dense = a.g.num_dense > 0;
+        if (!(dense ? tn_ensure_dynamic_lds<main_mfma_rays_kernel<true>>(smem) : tn_ensure_dynamic_lds<main_mfma_rays_kernel<false>>(smem)))
+            return TN_ERR_LAUNCH;
         const long long groups = (num_rays + 63) / 64;
         const long long need = (groups + kWaves - 1) / kWaves;
         const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
-        hipLaunchKernelGGL(main_mfma_rays_kernel, dim3(grid), dim3(kBlock), smem, stream, a);
+        if (dense)
+            hipLaunchKernelGGL(main_mfma_rays_kernel<true>, dim3(grid), dim3(kBlock), smem, stream, a);
+        else
+            hipLaunchKernelGGL(main_mfma_rays_kernel<false>, dim3(grid), dim3(kBlock), smem, stream, a);
         if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
         return TN_OK;
     }

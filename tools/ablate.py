@@ -18,6 +18,13 @@ def variant(name: str, src: str) -> str:
         return src.replace("            // ---- hash grid: 32 features",
                            "            px = __shfl(px, 0, 64); py = __shfl(py, 0, 64); pz = __shfl(pz, 0, 64);\n"
                            "            // ---- hash grid: 32 features")
+    if name == "coherent_rays":  # lane = ray kernel: every lane hashes lane 0's position (one cache line per gather)
+        a = src.index("__global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel")
+        k = src[a:]
+        old = "            float bt0[16], bt1[16];\n"
+        assert k.count(old) == 1
+        k = k.replace(old, "            px = __shfl(px, 0, 64); py = __shfl(py, 0, 64); pz = __shfl(pz, 0, 64);\n" + old)
+        return src[:a] + k
     if name == "nomlp":
         i0 = src.index("            // ---- mlp_base layer 0: 32 -> 64")
         i1 = src.index("            // ---- compositing (lane = sample)")
@@ -46,7 +53,7 @@ def variant(name: str, src: str) -> str:
         return v.replace("for (int l0 = 0; l0 < L16; l0 += LG) {", "for (int l0 = 8; l0 < L16; l0 += LG) {").replace(
             "float bt0[16], bt1[16];", "float bt0[16] = {}, bt1[16] = {};")
     if name == "timing":  # per-section wave-cycle sums of main_mfma_rays_kernel -> 8 uint64 counters after minmax[0..1]
-        a = src.index("__global__ void __launch_bounds__(kRBlock, 2) main_mfma_rays_kernel")
+        a = src.index("__global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel")
         b = src.index("inline bool mfma_supported")
         k = src[a:b]
         k = k.replace("    float smin = INFINITY, smax = -INFINITY;\n",
@@ -64,7 +71,7 @@ def variant(name: str, src: str) -> str:
     if name == "mlponly":  # rays kernel: no hash gathers, no VALU output layers: the bare MFMA chain + relu operands
         v = variant("nohash", src)
         a = v.index("__global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel")
-        b = v.index("// ------------------------------------------------------------------------------------------------------\n// main_mfma_t32_kernel")
+        b = v.index("inline bool mfma_supported")
         k = v[a:b]
         k = k.replace("cr = fast_sigmoid(combine_halves(out_dot_fast<0>(w3, h, x2)) + w3[192]);", "cr = x2[0][0][0] + x2[1][1][3];")
         k = k.replace("cg = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 64, h, x2)) + w3[193]);", "cg = x2[0][1][1];")
@@ -77,12 +84,40 @@ def variant(name: str, src: str) -> str:
     raise SystemExit(f"unknown variant {name}")
 
 
+def header_variant(name: str, dev: str) -> str:
+    """variants that patch tn_device.h (the hash-grid gather of the FAST flavour)"""
+    if name == "nogather":  # index arithmetic + interpolation kept, the 8 loads replaced by bit-casts of the offsets
+        for k, expr in enumerate(["(x1 ^ y1 ^ z1)", "(x1 ^ y0 ^ z1)", "(x0 ^ y0 ^ z1)", "(x0 ^ y1 ^ z1)", "(x1 ^ y1 ^ z0)",
+                                  "(x1 ^ y0 ^ z0)", "(x0 ^ y0 ^ z0)", "(x0 ^ y1 ^ z0)"]):
+            old = f"f{k} = *reinterpret_cast<const float2 *>(tb + ({expr} & m8));"
+            assert dev.count(old) == 1, old
+            dev = dev.replace(old, f"f{k} = make_float2(__uint_as_float(({expr} & m8) | 0x30000000u), ox);")
+        return dev
+    if name == "onecorner":  # all 8 corners read the SAME entry (1/8 of the distinct addresses, same instruction count)
+        for k, expr in enumerate(["(x1 ^ y1 ^ z1)", "(x1 ^ y0 ^ z1)", "(x0 ^ y0 ^ z1)", "(x0 ^ y1 ^ z1)", "(x1 ^ y1 ^ z0)",
+                                  "(x1 ^ y0 ^ z0)", "(x0 ^ y1 ^ z0)"]):
+            dev = dev.replace(f"tb + ({expr} & m8)", "tb + ((x0 ^ y0 ^ z0) & m8)")
+        return dev
+    return dev
+
+
+HEADER_VARIANTS = ("nogather", "onecorner")
+
+
 def main():
-    src = open(os.path.join(CSRC, "tn_render_mfma.hip")).read().replace(
-        '#include "tn_field_eval.h"', f'#include "{CSRC}/tn_field_eval.h"')
     for name in sys.argv[1:]:
+        inc = CSRC
+        if name in HEADER_VARIANTS:
+            inc = f"/tmp/abl_inc_{name}"
+            os.makedirs(inc, exist_ok=True)
+            open(os.path.join(inc, "tn_device.h"), "w").write(
+                header_variant(name, open(os.path.join(CSRC, "tn_device.h")).read()).replace(
+                    '#include "../../include/thermonerf_hip.h"', f'#include "{ROOT}/include/thermonerf_hip.h"'))
+            open(os.path.join(inc, "tn_field_eval.h"), "w").write(open(os.path.join(CSRC, "tn_field_eval.h")).read())
+        src = open(os.path.join(CSRC, "tn_render_mfma.hip")).read().replace(
+            '#include "tn_field_eval.h"', f'#include "{inc}/tn_field_eval.h"')
         tmp = f"/tmp/abl_{name}.hip"
-        open(tmp, "w").write(variant(name, src))
+        open(tmp, "w").write(src if name in HEADER_VARIANTS else variant(name, src))
         others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip")]
         out = os.path.join(ROOT, f"ab_{name}.so")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)

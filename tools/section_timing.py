@@ -4,7 +4,8 @@ sys.path.insert(0, ".")
 from tests import helpers
 from thermo_nerf_amd import synthetic
 from thermo_nerf_amd.engine import RayRenderEngine
-model, _, _ = helpers.build("scene", 64, small=False)
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model, _, _ = helpers.build("scene", S, small=False)
 gm = copy.deepcopy(model).to("cuda:0").eval()
 o, d, _ = synthetic.orbit_camera_rays(800, 800)
 o, d = o.reshape(-1, 3).cuda(), d.reshape(-1, 3).cuda()
@@ -12,9 +13,9 @@ eng = RayRenderEngine(gm, chunk=640000)
 eng.render(o, d); torch.cuda.synchronize()
 eng._ws.zero_()
 eng.render(o, d); torch.cuda.synchronize()
-nb = ((640000 + 63) // 64) * 64 * 65 * 4
+nb = ((640000 + 63) // 64) * 64 * (S + 1) * 4
 off = (nb + 255) // 256 * 256
-c = eng._ws[off + 8: off + 8 + 64].view(torch.int64).cpu().tolist()
+c = eng._ws[0][off + 8: off + 8 + 64].view(torch.int64).cpu().tolist()
 names = ["hash(+pos)", "base L1", "base L2", "dens+colour", "thermal", "composite", "iters"]
 it = c[6]
 print("iterations", it)
