@@ -226,6 +226,56 @@ __device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, f
     return r;
 }
 
+// ---- the FAST hashed level in three stages (index arithmetic | the 8 gathers | interpolation) -----------------------------
+// Same arithmetic as encode_level<false, true>; split so that a kernel can put a scheduling barrier between the stages and
+// keep the gathers of SEVERAL levels in flight together: left to itself hipcc drains the load queue after every level
+// (8 gathers, s_waitcnt vmcnt(0), interpolate), which exposes one memory round trip per level.
+struct HashTaps {
+    unsigned off[8];  // byte offsets of the 8 corners inside the level's table, in the f0..f7 order of encode_level
+    float ox, oy, oz;
+};
+__device__ __forceinline__ void hash_taps(const Grid &g, int l, float px, float py, float pz, HashTaps &t) {
+    const float s = g.scal[l];
+    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+    t.ox = __builtin_amdgcn_fractf(sx);
+    t.oy = __builtin_amdgcn_fractf(sy);
+    t.oz = __builtin_amdgcn_fractf(sz);
+    const unsigned fx = (unsigned)(int)sx, fy = (unsigned)(int)sy, fz = (unsigned)(int)sz;
+    const unsigned x0 = fx << 3, x1 = x0 + 8u;
+    const unsigned y0 = fy * (TN_P1 << 3), y1 = y0 + (TN_P1 << 3);
+    const unsigned z0 = fz * (TN_P2 << 3), z1 = z0 + (TN_P2 << 3);
+    const unsigned m8 = g.mask << 3;
+    t.off[0] = (x1 ^ y1 ^ z1) & m8;
+    t.off[1] = (x1 ^ y0 ^ z1) & m8;
+    t.off[2] = (x0 ^ y0 ^ z1) & m8;
+    t.off[3] = (x0 ^ y1 ^ z1) & m8;
+    t.off[4] = (x1 ^ y1 ^ z0) & m8;
+    t.off[5] = (x1 ^ y0 ^ z0) & m8;
+    t.off[6] = (x0 ^ y0 ^ z0) & m8;
+    t.off[7] = (x0 ^ y1 ^ z0) & m8;
+}
+__device__ __forceinline__ void hash_gather(const Grid &g, int l, const HashTaps &t, float2 (&f)[8]) {
+    const char *tb = reinterpret_cast<const char *>(g.table + (size_t)l * g.tsize);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2 *>(tb + t.off[k]);
+}
+__device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f)[8]) {
+    float2 r;
+    {
+        const float f03 = lerp_t<true>(f[0].x, f[3].x, t.ox), f12 = lerp_t<true>(f[1].x, f[2].x, t.ox);
+        const float f56 = lerp_t<true>(f[5].x, f[6].x, t.ox), f47 = lerp_t<true>(f[4].x, f[7].x, t.ox);
+        const float f0312 = lerp_t<true>(f03, f12, t.oy), f4756 = lerp_t<true>(f47, f56, t.oy);
+        r.x = lerp_t<true>(f0312, f4756, t.oz);
+    }
+    {
+        const float f03 = lerp_t<true>(f[0].y, f[3].y, t.ox), f12 = lerp_t<true>(f[1].y, f[2].y, t.ox);
+        const float f56 = lerp_t<true>(f[5].y, f[6].y, t.ox), f47 = lerp_t<true>(f[4].y, f[7].y, t.ox);
+        const float f0312 = lerp_t<true>(f03, f12, t.oy), f4756 = lerp_t<true>(f47, f56, t.oy);
+        r.y = lerp_t<true>(f0312, f4756, t.oz);
+    }
+    return r;
+}
+
 template <bool FAST = false>
 __device__ __forceinline__ float2 encode_level_any(const Grid &g, int l, float px, float py, float pz) {
     if (l < g.num_dense) return encode_level<true, FAST>(g, l, px, py, pz);

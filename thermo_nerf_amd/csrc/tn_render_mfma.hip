@@ -555,19 +555,48 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             float bt0[16], bt1[16];
+            if (!DENSE) {
+                // hashed levels, software-pipelined over groups of LG levels: the 8*LG gathers of group g+1 are issued before
+                // group g is interpolated, so two groups (2 x 8*LG gathers) are in flight and the memory round trip is paid
+                // about once per pass instead of once per level.  The scheduling barriers pin the stage order
+                // (index arithmetic | gathers | interpolation); nothing else distinguishes this from encode_level.
+                constexpr int NG = L16 / LG;
+                HashTaps taps[2][LG];
+                float2 fv[2][LG][8];
 #pragma unroll
-            for (int l0 = 0; l0 < L16; l0 += LG) {
-                float2 f[LG];
-                if (!DENSE) {  // compile-time: the hashed instantiation carries none of the dense-level arguments
+                for (int q = 0; q < LG; ++q) hash_taps(a.g, q, px, py, pz, taps[0][q]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);
-                } else {
+                for (int q = 0; q < LG; ++q) hash_gather(a.g, q, taps[0][q], fv[0][q]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const int cur = gi & 1, nxt = cur ^ 1;
+                    if (gi + 1 < NG) {
+#pragma unroll
+                        for (int q = 0; q < LG; ++q) hash_taps(a.g, (gi + 1) * LG + q, px, py, pz, taps[nxt][q]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < LG; ++q) hash_gather(a.g, (gi + 1) * LG + q, taps[nxt][q], fv[nxt][q]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < LG; ++q) {
+                        const float2 f = hash_blend(taps[cur][q], fv[cur][q]);
+                        swap32(f.x, f.y, bt0[gi * LG + q], bt1[gi * LG + q]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int l0 = 0; l0 < L16; l0 += LG) {
+                    float2 f[LG];
 #pragma unroll
                     for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, l0 + q, px, py, pz);
-                }
 #pragma unroll
-                for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             f32x16 h1[2][2];
 #pragma unroll

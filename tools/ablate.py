@@ -98,27 +98,41 @@ def header_variant(name: str, dev: str) -> str:
                                   "(x1 ^ y0 ^ z0)", "(x0 ^ y1 ^ z0)"]):
             dev = dev.replace(f"tb + ({expr} & m8)", "tb + ((x0 ^ y0 ^ z0) & m8)")
         return dev
+    if name in ("hash_idx", "hash_ceil"):  # index-based addressing (hash_idx), and additionally the compare-based ceil corner
+        a = dev.index("        if (FAST) {\n            // byte offsets straight from the hash")
+        b = dev.index("        } else {\n            const float2 *t = g.table + (size_t)l * g.tsize;")
+        c = dev.index("            f7 = t[(fx ^ hcy ^ hfz) & m];\n        }\n") + len("            f7 = t[(fx ^ hcy ^ hfz) & m];\n        }\n")
+        body = dev[b + len("        } else {\n"):c - len("        }\n")]
+        dev = dev[:a] + "        {\n" + body + "        }\n" + dev[c:]
+        if name == "hash_ceil":
+            dev = dev.replace("(FAST || ox > 0.0f)", "(ox > 0.0f)").replace("(FAST || oy > 0.0f)", "(oy > 0.0f)").replace(
+                "(FAST || oz > 0.0f)", "(oz > 0.0f)")
+        return dev
     return dev
 
 
-HEADER_VARIANTS = ("nogather", "onecorner")
+HEADER_VARIANTS = ("nogather", "onecorner", "hash_idx", "hash_ceil")
 
 
 def main():
+    """names: a tn_render_mfma.hip source variant, a header variant (applied to the field kernels), or `prop_<header variant>`
+    (the same header patch applied to tn_render.hip = the proposal kernels only)."""
     for name in sys.argv[1:]:
+        target = "tn_render.hip" if name.startswith("prop_") else "tn_render_mfma.hip"
+        hname = name[5:] if name.startswith("prop_") else name
         inc = CSRC
-        if name in HEADER_VARIANTS:
+        if hname in HEADER_VARIANTS:
             inc = f"/tmp/abl_inc_{name}"
             os.makedirs(inc, exist_ok=True)
             open(os.path.join(inc, "tn_device.h"), "w").write(
-                header_variant(name, open(os.path.join(CSRC, "tn_device.h")).read()).replace(
+                header_variant(hname, open(os.path.join(CSRC, "tn_device.h")).read()).replace(
                     '#include "../../include/thermonerf_hip.h"', f'#include "{ROOT}/include/thermonerf_hip.h"'))
             open(os.path.join(inc, "tn_field_eval.h"), "w").write(open(os.path.join(CSRC, "tn_field_eval.h")).read())
-        src = open(os.path.join(CSRC, "tn_render_mfma.hip")).read().replace(
-            '#include "tn_field_eval.h"', f'#include "{inc}/tn_field_eval.h"')
+        src = open(os.path.join(CSRC, target)).read().replace('#include "tn_field_eval.h"', f'#include "{inc}/tn_field_eval.h"')
         tmp = f"/tmp/abl_{name}.hip"
-        open(tmp, "w").write(src if name in HEADER_VARIANTS else variant(name, src))
-        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip")]
+        open(tmp, "w").write(src if hname in HEADER_VARIANTS else variant(name, src))
+        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_mfma.hip",
+                                                  "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip") if f != target]
         out = os.path.join(ROOT, f"ab_{name}.so")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)
         print("built", out)
