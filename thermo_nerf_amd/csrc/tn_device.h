@@ -230,11 +230,20 @@ __device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, f
 // Same arithmetic as encode_level<false, true>; split so that a kernel can put a scheduling barrier between the stages and
 // keep the gathers of SEVERAL levels in flight together: left to itself hipcc drains the load queue after every level
 // (8 gathers, s_waitcnt vmcnt(0), interpolate), which exposes one memory round trip per level.
+// Stage fence: the scheduling barrier stops the machine scheduler; the empty asm with a memory clobber keeps instruction
+// selection from placing the (side-effect-free) gathers after it — sched_barrier alone is IntrNoMem and does not hold loads.
+#define TN_STAGE_FENCE()                        \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
 struct HashTaps {
     unsigned off[8];  // byte offsets of the 8 corners inside the level's table, in the f0..f7 order of encode_level
     float ox, oy, oz;
 };
-__device__ __forceinline__ void hash_taps(const Grid &g, int l, float px, float py, float pz, HashTaps &t) {
+template <typename G>
+__device__ __forceinline__ void hash_taps(const G &g, int l, float px, float py, float pz, HashTaps &t) {
     const float s = g.scal[l];
     const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
     t.ox = __builtin_amdgcn_fractf(sx);
@@ -254,10 +263,17 @@ __device__ __forceinline__ void hash_taps(const Grid &g, int l, float px, float 
     t.off[6] = (x0 ^ y0 ^ z0) & m8;
     t.off[7] = (x0 ^ y1 ^ z0) & m8;
 }
-__device__ __forceinline__ void hash_gather(const Grid &g, int l, const HashTaps &t, float2 (&f)[8]) {
+template <typename G>
+__device__ __forceinline__ void hash_gather(const G &g, int l, const HashTaps &t, float2 (&f)[8]) {
     const char *tb = reinterpret_cast<const char *>(g.table + (size_t)l * g.tsize);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2 *>(tb + t.off[k]);
+}
+// Pins the interpolation of a level BELOW the point where this is called: the interpolation weights pass through an opaque
+// asm, so the (pure) arithmetic that reads them cannot be placed earlier — without it instruction selection emits each
+// level's interpolation right behind its own eight gathers and the load queue drains once per level.
+__device__ __forceinline__ void hash_hold(HashTaps &t) {
+    asm volatile("" : "+v"(t.ox), "+v"(t.oy), "+v"(t.oz)::"memory");
 }
 __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f)[8]) {
     float2 r;
@@ -274,6 +290,41 @@ __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f
         r.y = lerp_t<true>(f0312, f4756, t.oz);
     }
     return r;
+}
+
+// NL hashed levels of one position (FAST flavour), software-pipelined over groups of LG levels: the 8*LG gathers of group
+// g+1 are issued before group g is interpolated, so two groups (2 x 8*LG gathers, <= 64 = the vmcnt range) are in flight and
+// the memory round trip is paid about once per position instead of once per level.  Levels base .. base+NL-1;
+// emit(level - base, features) is called in level order.  Values are those of encode_level<false, true>, bit for bit.
+template <int NL, int LG, typename G, typename Emit>
+__device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, float py, float pz, Emit emit, int base = 0) {
+    static_assert(NL % LG == 0 && 16 * LG <= 64, "two groups of 8*LG gathers must fit the 6-bit vmcnt counter");
+    constexpr int NG = NL / LG;
+    HashTaps taps[2][LG];
+    float2 fv[2][LG][8];
+#pragma unroll
+    for (int q = 0; q < LG; ++q) hash_taps(g, base + q, px, py, pz, taps[0][q]);
+    TN_STAGE_FENCE();
+#pragma unroll
+    for (int q = 0; q < LG; ++q) hash_gather(g, base + q, taps[0][q], fv[0][q]);
+    TN_STAGE_FENCE();
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int cur = gi & 1, nxt = cur ^ 1;
+        if (gi + 1 < NG) {
+#pragma unroll
+            for (int q = 0; q < LG; ++q) hash_taps(g, base + (gi + 1) * LG + q, px, py, pz, taps[nxt][q]);
+            TN_STAGE_FENCE();
+#pragma unroll
+            for (int q = 0; q < LG; ++q) hash_gather(g, base + (gi + 1) * LG + q, taps[nxt][q], fv[nxt][q]);
+        }
+#pragma unroll
+        for (int q = 0; q < LG; ++q) hash_hold(taps[cur][q]);  // group gi is interpolated below group gi+1's gathers
+        TN_STAGE_FENCE();
+#pragma unroll
+        for (int q = 0; q < LG; ++q) emit(gi * LG + q, hash_blend(taps[cur][q], fv[cur][q]));
+        TN_STAGE_FENCE();
+    }
 }
 
 template <bool FAST = false>

@@ -312,27 +312,36 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // ---- hash grid -> two K=16 steps of B operands per N tile --------------------------------------
             HL e0[2], e1[2];  // [ks] for tile 0 / tile 1
+            if (a.g.num_dense == 0) {
+                // hashed levels: index arithmetic | gathers | interpolation in explicit stages; two groups of 2 levels (2 x 16
+                // gathers) in flight — this kernel has ~30 fewer free VGPRs than the fp32 one
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float v[16];
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[16];
+                    hash_encode_pipelined<8, 2>(a.g, px, py, pz, [&](int l, float2 f) {
+                        v[2 * l] = f.x;
+                        v[2 * l + 1] = f.y;
+                    }, 8 * ks);
+                    pack_step(v, e0[ks], e1[ks]);
+                }
+            } else {
 #pragma unroll
-                for (int l0 = 0; l0 < 8; l0 += LG) {
-                    float2 f[LG];
-                    if (a.g.num_dense == 0) {
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[16];
 #pragma unroll
-                        for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, 8 * ks + l0 + q, px, py, pz);
-                    } else {
+                    for (int l0 = 0; l0 < 8; l0 += LG) {
+                        float2 f[LG];
 #pragma unroll
                         for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, 8 * ks + l0 + q, px, py, pz);
-                    }
 #pragma unroll
-                    for (int q = 0; q < LG; ++q) {
-                        v[2 * (l0 + q)] = f[q].x;
-                        v[2 * (l0 + q) + 1] = f[q].y;
+                        for (int q = 0; q < LG; ++q) {
+                            v[2 * (l0 + q)] = f[q].x;
+                            v[2 * (l0 + q) + 1] = f[q].y;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    pack_step(v, e0[ks], e1[ks]);
                 }
-                pack_step(v, e0[ks], e1[ks]);
             }
             // ---- mlp_base layer 0: 32 -> 64 ---------------------------------------------------------------
             f32x16 h1[2][2];

@@ -345,21 +345,18 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // ---- hash grid: 32 features of this lane's sample -> B operands of the two N tiles -------------
             float bt0[16], bt1[16];
-            // LG levels per scheduling group: their 8*LG gathers are issued together (latency paid 16/LG times per
-            // pass); the barrier keeps the scheduler from hoisting all 128 gathers at once (that spills ~450 VGPRs)
+            if (a.g.num_dense == 0) {
+                hash_encode_pipelined<L16, 2>(a.g, px, py, pz, [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });
+            } else {
 #pragma unroll
-            for (int l0 = 0; l0 < L16; l0 += LG) {
-                float2 f[LG];
-                if (a.g.num_dense == 0) {
-#pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);
-                } else {
+                for (int l0 = 0; l0 < L16; l0 += LG) {
+                    float2 f[LG];
 #pragma unroll
                     for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, l0 + q, px, py, pz);
-                }
 #pragma unroll
-                for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // ---- mlp_base layer 0: 32 -> 64 ---------------------------------------------------------------
             f32x16 h1[2][2];
@@ -556,37 +553,8 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             float bt0[16], bt1[16];
             if (!DENSE) {
-                // hashed levels, software-pipelined over groups of LG levels: the 8*LG gathers of group g+1 are issued before
-                // group g is interpolated, so two groups (2 x 8*LG gathers) are in flight and the memory round trip is paid
-                // about once per pass instead of once per level.  The scheduling barriers pin the stage order
-                // (index arithmetic | gathers | interpolation); nothing else distinguishes this from encode_level.
-                constexpr int NG = L16 / LG;
-                HashTaps taps[2][LG];
-                float2 fv[2][LG][8];
-#pragma unroll
-                for (int q = 0; q < LG; ++q) hash_taps(a.g, q, px, py, pz, taps[0][q]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < LG; ++q) hash_gather(a.g, q, taps[0][q], fv[0][q]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    const int cur = gi & 1, nxt = cur ^ 1;
-                    if (gi + 1 < NG) {
-#pragma unroll
-                        for (int q = 0; q < LG; ++q) hash_taps(a.g, (gi + 1) * LG + q, px, py, pz, taps[nxt][q]);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int q = 0; q < LG; ++q) hash_gather(a.g, (gi + 1) * LG + q, taps[nxt][q], fv[nxt][q]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < LG; ++q) {
-                        const float2 f = hash_blend(taps[cur][q], fv[cur][q]);
-                        swap32(f.x, f.y, bt0[gi * LG + q], bt1[gi * LG + q]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                // hashed levels: index arithmetic | gathers | interpolation in explicit stages, two groups of LG levels in flight
+                hash_encode_pipelined<L16, LG>(a.g, px, py, pz, [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });
             } else {
 #pragma unroll
                 for (int l0 = 0; l0 < L16; l0 += LG) {
