@@ -314,6 +314,18 @@ int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, 
 int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
                    float *d_densities, void *stream);
 
+/* The final level's field forward of a training step in ONE launch [REF thermal_field.py:183-201 in train mode]: what the
+ * chain tn_hash_encode_fwd -> tn_linear_fwd (mlp_base x2) -> tn_density_act_fwd -> tn_color_input_fwd -> tn_linear_fwd
+ * (mlp_head x3, mlp_thermal x2, head) computes, with every activation the backward differentiates written to its tape
+ * buffer in the same row-major layout: positions [N,3] (N = num_rays * n, ray-major), directions [R,3], camera_indices [R];
+ * enc [N,32], selector [N], h1 [N,64] (ReLU applied), bo [N,16] (raw density | geo), density [N], c1, c2 [N,64] (ReLU),
+ * rgb [N,3] (sigmoid), t1 [N,64] (ReLU), t2 [N,64] (sigmoid), thermal [N].  Needs field->prepared (tn_field_prepare on the
+ * CURRENT weights); the reference geometry only (16 levels, geo 15, appearance 32). */
+int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, const float *directions,
+                       const int32_t *camera_indices, int64_t num_rays, int32_t n, float *enc, float *selector, float *h1,
+                       float *bo, float *density, float *c1, float *c2, float *rgb, float *t1, float *t2, float *thermal,
+                       void *stream);
+
 /* NS scale_gradients_by_distance_squared [REF thermal_nerf_model.py:228-231, use_gradient_scaling]: the forward is the
  * identity; in the backward the gradient of EVERY field output of a sample (density [n], rgb [n,3], thermal [n]; any may
  * be NULL) is multiplied in place by clamp(((start + end) / 2)^2, 0, 1).  starts/ends [n]. */

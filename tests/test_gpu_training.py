@@ -211,15 +211,17 @@ def _gpu_step(gm, o, d, jit, cam, batch):
 ONE_NET = {"one_proposal_network": True}  # helpers.build: use_same_proposal_network + a one-entry proposal_net_args_list
 
 
-@pytest.mark.parametrize("variant", ["default", "gradient_scaling", "same_proposal_network"])
+@pytest.mark.parametrize("variant", ["default", "stage_forward", "gradient_scaling", "same_proposal_network"])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 @pytest.mark.parametrize("S", [48, 64, 192])  # 192 = BASELINE config 3 (multi-chunk scans in every per-ray kernel)
 def test_training_step_matches_autograd_oracle(kind, S, variant):
     """variant: the reference's config switches on this path — use_gradient_scaling [REF thermal_nerf_model.py:228-231] and
     use_same_proposal_network [REF :122-139] — next to the default configuration."""
-    if variant != "default" and S != 48:
+    if variant not in ("default", "stage_forward") and S != 48:
         pytest.skip("config variants are checked at the reference's default sample count")
-    over = {"gradient_scaling": {"use_gradient_scaling": True}, "same_proposal_network": ONE_NET}.get(variant, {})
+    # default = the final level's forward as one fused MFMA kernel (tn_field_fwd_taped); stage_forward = one launch per module
+    over = {"gradient_scaling": {"use_gradient_scaling": True}, "same_proposal_network": ONE_NET,
+            "stage_forward": {"fused_train_forward": False}}.get(variant, {})
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, **over)
     if variant == "same_proposal_network":
         assert len(gm.proposal_networks) == 1
@@ -251,6 +253,50 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
         assert rel(gg, gw) <= 2e-3, f"{name}: rel {rel(gg, gw):.2e} (|g| {gw.norm().item():.2e})"
         checked += 1
     assert checked >= (13 if variant == "same_proposal_network" else 18)
+
+
+@pytest.mark.parametrize("hw", [(12, 12), (7, 5), (1, 1)])  # 6912 (a multiple of 64), 1680 and 48 samples
+def test_fused_field_forward_writes_the_stage_chain_tape(hw):
+    """tn_field_fwd_taped against the chain of stage entry points it replaces, tape tensor by tape tensor."""
+    from thermo_nerf_amd import _hip
+
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48, R_hw=hw)
+    lib = _hip.load()
+    R, S = o.shape[0], 48
+    N = R * S
+    dd, cc = d.to(DEV), cam.to(DEV).reshape(-1).to(torch.int32)
+    pos = (torch.rand(N, 3, generator=torch.Generator().manual_seed(3)) * 3 - 1.5).to(DEV)  # inside and outside the unit box
+    fld = gm.field.c_struct(prepare=True, dense=False)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=DEV)
+    enc, sel, dens, h1, bo = f32(N, 32), f32(N), f32(N), f32(N, 64), f32(N, 16)
+    c1, c2, rgb, t1, t2, th = f32(N, 64), f32(N, 64), f32(N, 3), f32(N, 64), f32(N, 64), f32(N, 1)
+    _hip.check(lib.tn_field_fwd_taped(fld, pos.data_ptr(), dd.data_ptr(), cc.data_ptr(), R, S, enc.data_ptr(), sel.data_ptr(),
+                                      h1.data_ptr(), bo.data_ptr(), dens.data_ptr(), c1.data_ptr(), c2.data_ptr(), rgb.data_ptr(),
+                                      t1.data_ptr(), t2.data_ptr(), th.data_ptr(), _hip.current_stream()), "tn_field_fwd_taped")
+    # the chain it replaces
+    enc_s, sel_s = TR.hash_encode_fwd(fld.grid, fld.space, pos)
+    h1_s = TR.linear_fwd(enc_s, 0, 32, fld.base0, TR.ACT_RELU, N)
+    bo_s = TR.linear_fwd(h1_s, 0, 64, fld.base1, TR.ACT_NONE, N)
+    dens_s = f32(N)
+    _hip.check(lib.tn_density_act_fwd(bo_s.data_ptr(), 16, sel_s.data_ptr(), fld.average_init_density, N, dens_s.data_ptr(),
+                                      _hip.current_stream()), "tn_density_act_fwd")
+    cin = f32(N, 64)
+    _hip.check(lib.tn_color_input_fwd(fld, dd.data_ptr(), bo_s.data_ptr() + 4, 16, cc.data_ptr(), 1, R, S, cin.data_ptr(),
+                                      _hip.current_stream()), "tn_color_input_fwd")
+    c1_s = TR.linear_fwd(cin, 0, 64, fld.head0, TR.ACT_RELU, N)
+    c2_s = TR.linear_fwd(c1_s, 0, 64, fld.head1, TR.ACT_RELU, N)
+    rgb_s = TR.linear_fwd(c2_s, 0, 64, fld.head2, TR.ACT_SIGMOID, N)
+    t1_s = TR.linear_fwd(bo_s, 1, 16, fld.th0, TR.ACT_RELU, N)
+    t2_s = TR.linear_fwd(t1_s, 0, 64, fld.th1, TR.ACT_SIGMOID, N)
+    th_s = TR.linear_fwd(t2_s, 0, 64, fld.thead, TR.ACT_NONE, N)
+    torch.cuda.synchronize()
+    assert torch.equal(sel, sel_s)
+    for name, got, want, tol in (("enc", enc, enc_s, 2e-6), ("h1", h1, h1_s, 1e-5), ("bo", bo, bo_s, 2e-5), ("c1", c1, c1_s, 2e-5),
+                                 ("c2", c2, c2_s, 3e-5), ("rgb", rgb, rgb_s, 1e-5), ("t1", t1, t1_s, 2e-5), ("t2", t2, t2_s, 1e-5),
+                                 ("thermal", th, th_s, 2e-5)):
+        err = (got - want).abs().max().item()
+        assert err <= tol * max(1.0, want.abs().max().item()), f"{name}: {err:.3e}"
+    assert rel(dens, dens_s) <= 1e-5
 
 
 def test_proposal_networks_frozen_between_updates():

@@ -180,6 +180,7 @@ SIGNATURES = {
     "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _vp, _i64, _vp, _i32, _vp]),
     "tn_weights_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tn_gradient_scale_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tn_field_fwd_taped": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32] + [_vp] * 12),
     "tn_composite_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "tn_color_input_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     "tn_color_input_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),

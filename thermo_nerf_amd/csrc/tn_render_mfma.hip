@@ -187,11 +187,12 @@ __device__ __forceinline__ void swap16(float a, float b, float &even, float &odd
 
 // mlp_base layer 1 (64 -> 1 + geo = 16 rows, no activation) on relu(h1), then its outputs re-laid as the B operands of the
 // eight k-steps of the geo -> hidden layers: gb[nt][j] (k rows grow(j, 0) | grow(j, 1)).  gb[nt][0] lanes 0-31 = raw density.
-__device__ __forceinline__ void base2_geo(const float *A, const float *bias16, int lane, const f32x16 (&h1)[2][2],
-                                          float (&gb)[2][8]) {
+// G[T][q]: row 4 (l >> 4) + q of mlp_base's 16 outputs for sample 16 T + (l & 15)
+__device__ __forceinline__ void base2_tiles(const float *A, const float *bias16, int lane, const f32x16 (&h1)[2][2],
+                                            f32x4 (&G)[4]) {
     const float4 bq = *reinterpret_cast<const float4 *>(bias16 + 4 * (lane >> 4));  // C rows 4 (l >> 4) + q
     const f32x4 b4 = {bq.x, bq.y, bq.z, bq.w};
-    f32x4 G[4] = {b4, b4, b4, b4};  // 16-sample tiles 0..3
+    G[0] = b4; G[1] = b4; G[2] = b4; G[3] = b4;  // 16-sample tiles 0..3
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -206,11 +207,19 @@ __device__ __forceinline__ void base2_geo(const float *A, const float *bias16, i
             }
         }
     }
+}
+__device__ __forceinline__ void geo_relayout(const f32x4 (&G)[4], float (&gb)[2][8]) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) swap16(G[2 * nt][q], G[2 * nt + 1][q], gb[nt][2 * q], gb[nt][2 * q + 1]);
     }
+}
+__device__ __forceinline__ void base2_geo(const float *A, const float *bias16, int lane, const f32x16 (&h1)[2][2],
+                                          float (&gb)[2][8]) {
+    f32x4 G[4];
+    base2_tiles(A, bias16, lane, h1, G);
+    geo_relayout(G, gb);
 }
 
 // one 64 -> 64 layer: out[mt][nt] = bias + sum over (mi, s) A[mt][mi][s] x relu(in[mi][nt][s])
@@ -663,6 +672,208 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// field_fwd_taped_kernel — the final level's field forward of a TRAINING step in one launch: hash
+// encoding -> mlp_base -> density | [SH, geo, appearance] -> mlp_head | geo -> mlp_thermal -> head, for N = rays x samples
+// flat samples, with every activation the backward needs written to the tape in the row-major [N, width] layout of the
+// stage-by-stage entry points (tn_hash_encode_fwd, tn_linear_fwd ...), which it replaces: nine Linear launches + encode +
+// activation, each streaming [N, 64] matrices through HBM, become one MFMA chain whose activations leave the registers
+// only as tape stores.  Differences to the eval kernels: per-SAMPLE camera (the appearance embedding enters as 16 k-steps
+// of the colour layer, B operands gathered from the embedding table) and per-sample direction (SH as 8 k-steps).
+// A C/D register quad r = 4q..4q+3 holds four CONSECUTIVE features (32 mt + 8 q + 4 h + 0..3) of one sample: one 16-byte
+// store per quad.
+// ------------------------------------------------------------------------------------------------------
+struct TapedArgs {
+    Grid g;
+    tn_space space;
+    const float *blob;
+    const float *appearance;  // [num_images, 32]
+    float avg;
+    int sh_shifted;
+    const float *positions;   // [N,3]
+    const float *dirs;        // [R,3]
+    const int *cam;           // [R]
+    long long N;
+    int n;                    // samples per ray
+    float *enc, *sel, *h1, *bo, *density, *c1, *c2, *rgb, *t1, *t2, *thermal;
+};
+
+template <int ACT>  // 1 relu, 2 sigmoid (exact flavour: the tape is what the backward differentiates)
+__device__ __forceinline__ void tape_store(float *dst, long long row0, long long N, int lane, int h, f32x16 (&x)[2][2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const long long row = row0 + 32 * nt + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                float *pv = &v.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = x[mt][nt][4 * q + e];
+                    const float y = ACT == 1 ? relu_bits(a) : sigmoidf(a);
+                    x[mt][nt][4 * q + e] = y;  // the next layer consumes the ACTIVATED value (relu_bits there is idempotent)
+                    pv[e] = y;
+                }
+                if (row < N) *reinterpret_cast<float4 *>(dst + row * 64 + 32 * mt + 8 * q + 4 * h) = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.blob);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *A = lds + OFF_A;
+    const Space sp = make_space(a.space);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const long long passes = (a.N + 63) >> 6;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long ps = (long long)blockIdx.x * kWaves + wave; ps < passes; ps += stride) {
+        const long long row0 = ps * 64;
+        const long long i = row0 + lane;
+        const bool live = i < a.N;
+        const long long ic = live ? i : a.N - 1;
+        const long long ray = ic / a.n;
+        float px, py, pz;
+        const float sel = normalize_position(sp, a.positions[ic * 3], a.positions[ic * 3 + 1], a.positions[ic * 3 + 2], px, py, pz);
+        // ---- hash encoding (lane = sample): features to the tape and, through 16 permlane swaps, to the B operands ----
+        float bt0[16], bt1[16];
+        if (a.g.num_dense == 0) {
+            hash_encode_pipelined<L16, 2>(a.g, px, py, pz, [&](int l, float2 f) {
+                if (live) *reinterpret_cast<float2 *>(a.enc + ic * 32 + 2 * l) = f;
+                swap32(f.x, f.y, bt0[l], bt1[l]);
+            });
+        } else {
+#pragma unroll
+            for (int l = 0; l < L16; ++l) {
+                const float2 f = encode_level_any<true>(a.g, l, px, py, pz);
+                if (live) *reinterpret_cast<float2 *>(a.enc + ic * 32 + 2 * l) = f;
+                swap32(f.x, f.y, bt0[l], bt1[l]);
+            }
+        }
+        if (live) a.sel[ic] = sel;
+        // ---- mlp_base layer 0 -------------------------------------------------------------------------------------------
+        f32x16 h1[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            h1[mt][0] = bias_frag(lds + OFF_B_BASE1, mt, h);
+            h1[mt][1] = h1[mt][0];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float aw = A[(A_BASE1 + mt * 16 + s) * 64 + lane];
+                MFMA32(h1[mt][0], aw, bt0[s]);
+                MFMA32(h1[mt][1], aw, bt1[s]);
+            }
+        }
+        tape_store<1>(a.h1, row0, a.N, lane, h, h1);
+        // ---- mlp_base layer 1: [N,16] = raw density | geo ------------------------------------------------------------
+        f32x4 G[4];
+        base2_tiles(A, lds + OFF_B_BASE2, lane, h1, G);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const long long row = row0 + 16 * T + (lane & 15);
+            if (row < a.N) *reinterpret_cast<float4 *>(a.bo + row * 16 + 4 * (lane >> 4)) = float4{G[T][0], G[T][1], G[T][2], G[T][3]};
+        }
+        float g[2][8];
+        geo_relayout(G, g);
+        float raw, unused;
+        swap32(g[0][0], g[1][0], raw, unused);
+        if (live) a.density[ic] = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+        // ---- colour branch: [geo | SH(dir) | appearance[cam]] -> 64 -> 64 -> 3 ----------------------------------------
+        {
+            f32x16 x1[2][2], x2[2][2];
+            layer_geo(A, A_C1, lds + OFF_B_C1_RAW, lane, h, g, x1);
+            {   // SH of this lane's ray direction: 8 k-steps
+                float sx = a.dirs[ray * 3], sy = a.dirs[ray * 3 + 1], sz = a.dirs[ray * 3 + 2];
+                if (a.sh_shifted) {
+                    sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
+                }
+                float c[16];
+                sh16(sx, sy, sz, c);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    float b0, b1;
+                    swap32(c[2 * s], c[2 * s + 1], b0, b1);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const float aw = A[(A_SH + mt * 8 + s) * 64 + lane];
+                        MFMA32(x1[mt][0], aw, b0);
+                        MFMA32(x1[mt][1], aw, b1);
+                    }
+                }
+            }
+            {   // appearance embedding of this lane's camera: 16 k-steps; A read from the natural [k][f] layout of W_app
+                const float4 *emb = reinterpret_cast<const float4 *>(a.appearance + (long long)a.cam[ray] * APP);
+#pragma unroll
+                for (int s4 = 0; s4 < APP / 4; ++s4) {
+                    const float4 e = emb[s4];
+                    float b0, b1, b2, b3;
+                    swap32(e.x, e.y, b0, b1);
+                    swap32(e.z, e.w, b2, b3);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const float a0 = lds[OFF_W_APP + (4 * s4 + h) * 64 + 32 * mt + (lane & 31)];
+                        const float a1 = lds[OFF_W_APP + (4 * s4 + 2 + h) * 64 + 32 * mt + (lane & 31)];
+                        MFMA32(x1[mt][0], a0, b0);
+                        MFMA32(x1[mt][1], a0, b1);
+                        MFMA32(x1[mt][0], a1, b2);
+                        MFMA32(x1[mt][1], a1, b3);
+                    }
+                }
+            }
+            tape_store<1>(a.c1, row0, a.N, lane, h, x1);
+            layer64(A, A_C2, lds + OFF_B_C2, lane, h, x1, x2);
+            tape_store<1>(a.c2, row0, a.N, lane, h, x2);
+            const float *w3 = lds + OFF_W3;
+            const float cr = sigmoidf(combine_halves(out_dot<0>(w3, h, x2)) + w3[192]);
+            const float cg = sigmoidf(combine_halves(out_dot<0>(w3 + 64, h, x2)) + w3[193]);
+            const float cb = sigmoidf(combine_halves(out_dot<0>(w3 + 128, h, x2)) + w3[194]);
+            if (live) {
+                a.rgb[ic * 3 + 0] = cr;
+                a.rgb[ic * 3 + 1] = cg;
+                a.rgb[ic * 3 + 2] = cb;
+            }
+        }
+        // ---- thermal branch: geo -> 64 -> 64 sigmoid -> 1 --------------------------------------------------------------
+        {
+            f32x16 x1[2][2], x2[2][2];
+            layer_geo(A, A_T1, lds + OFF_B_T1, lane, h, g, x1);
+            tape_store<1>(a.t1, row0, a.N, lane, h, x1);
+            layer64(A, A_T2, lds + OFF_B_T2, lane, h, x1, x2);
+            tape_store<2>(a.t2, row0, a.N, lane, h, x2);
+            // x2 now holds sigmoid(t2): the head is a plain dot product on it
+            const float *wt = lds + OFF_WTH;
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *reinterpret_cast<const float4 *>(wt + 32 * mt + 8 * q + 4 * h);
+                    const float ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p0 = fmaf(ww[e], x2[mt][0][4 * q + e], p0);
+                        p1 = fmaf(ww[e], x2[mt][1][4 * q + e], p1);
+                    }
+                }
+            }
+            const float th = combine_halves(make_float2(p0, p1)) + wt[64];
+            if (live) a.thermal[ic] = th;
+        }
+    }
+}
+
 inline bool mfma_supported(const tn_thermal_field *f) {
     return f && f->geo_feat_dim == GF && f->app_dim == APP && f->grid.num_levels == L16;
 }
@@ -719,6 +930,37 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
 }  // namespace tn
 
 extern "C" {
+
+int tn_field_fwd_taped(const tn_thermal_field *f, const float *positions, const float *directions,
+                       const int32_t *camera_indices, int64_t num_rays, int32_t n, float *enc, float *selector, float *h1,
+                       float *bo, float *density, float *c1, float *c2, float *rgb, float *t1, float *t2, float *thermal,
+                       void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!f || !positions || !directions || !camera_indices) return TN_ERR_NULL;
+    if (!enc || !selector || !h1 || !bo || !density || !c1 || !c2 || !rgb || !t1 || !t2 || !thermal) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    TN_TRY(tn_check_thermal_field(f));
+    if (!mfma_supported(f) || !f->prepared) return TN_ERR_UNSUPPORTED;
+    TapedArgs a;
+    a.g = tn_make_grid(f->grid);
+    a.space = f->space;
+    a.blob = f->prepared;
+    a.appearance = f->appearance;
+    a.avg = f->average_init_density;
+    a.sh_shifted = f->sh_shifted;
+    a.positions = positions; a.dirs = directions; a.cam = camera_indices;
+    a.N = (long long)num_rays * n; a.n = n;
+    a.enc = enc; a.sel = selector; a.h1 = h1; a.bo = bo; a.density = density; a.c1 = c1; a.c2 = c2; a.rgb = rgb;
+    a.t1 = t1; a.t2 = t2; a.thermal = thermal;
+    const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
+    if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel>(smem)) return TN_ERR_LAUNCH;
+    const long long passes = (a.N + 63) / 64;
+    const long long need = (passes + kWaves - 1) / kWaves;
+    const unsigned grid = (unsigned)(need < 512 ? (need < 1 ? 1 : need) : 512);
+    hipLaunchKernelGGL(field_fwd_taped_kernel, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
 
 size_t tn_field_prepare_bytes(const tn_thermal_field *field) {
     if (!mfma_supported(field) || tn_check_thermal_field(field) != TN_OK) return 0;

@@ -223,15 +223,29 @@ __global__ void depth_kernel(const float *__restrict__ weights, const float *__r
     }
     }  // ray loop
     if (expected) {
-        // ONE atomic pair per wave: a returned atomic per ray on a single address serialises in L2 (~12 ns each)
+        // ONE atomic pair per BLOCK: atomics on a single address serialise in L2 (~12 ns each) — one pair per ray, or per
+        // wave with a ray per wave (a 4096-ray training batch), is 50 us of serialisation in a 10 us kernel
+        __shared__ float red[2][kWavesPerBlock];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             smin = fminf(smin, __shfl_xor(smin, o, 64));
             smax = fmaxf(smax, __shfl_xor(smax, o, 64));
         }
-        if (lane == 0 && smin <= smax) {
-            atomicMin(&mm[0], f2key(smin));
-            atomicMax(&mm[1], f2key(smax));
+        if (lane == 0) {
+            red[0][threadIdx.x >> 6] = smin;
+            red[1][threadIdx.x >> 6] = smax;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int wv = 1; wv < kWavesPerBlock; ++wv) {
+                smin = fminf(smin, red[0][wv]);
+                smax = fmaxf(smax, red[1][wv]);
+            }
+            if (smin <= smax) {
+                atomicMin(&mm[0], f2key(smin));
+                atomicMax(&mm[1], f2key(smax));
+            }
         }
     }
 }
@@ -438,7 +452,7 @@ int tn_depth_fwd(const float *weights, const float *starts, const float *ends, i
     unsigned *mm = reinterpret_cast<unsigned *>(minmax_scratch);
     if (expected) hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
     const unsigned depth_blocks = blocks_for(num_rays, kWavesPerBlock);
-    hipLaunchKernelGGL(depth_kernel, dim3(depth_blocks < 2048u ? depth_blocks : 2048u), dim3(kBlock), 0, s, weights, starts,
+    hipLaunchKernelGGL(depth_kernel, dim3(depth_blocks < 512u ? depth_blocks : 512u), dim3(kBlock), 0, s, weights, starts,
                        ends, (long long)num_rays, n, accumulation, median, expected, mm);
     if (expected)
         hipLaunchKernelGGL(depth_clip_kernel, dim3(blocks_for(num_rays, kBlock)), dim3(kBlock), 0, s, expected,

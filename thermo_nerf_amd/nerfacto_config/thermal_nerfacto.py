@@ -82,6 +82,9 @@ class NerfactoModelConfig:
     """eval only; > 0: a wave of 64 rays stops marching once every ray's transmittance is below this value
     (outputs move by <= eps; 0 = off = the reference's behaviour).  Only the lane = ray kernels (calls of ~60 k rays and
     more) implement it; smaller calls run one ray per wave and render exactly."""
+    fused_train_forward: bool = True
+    """Training: the final level's field forward (encode + mlp_base + heads, with its tape) as ONE MFMA kernel
+    (tn_field_fwd_taped); False: the stage-by-stage entry points (one launch per nerfstudio module)."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""

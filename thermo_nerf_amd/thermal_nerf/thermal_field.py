@@ -124,14 +124,15 @@ class ThermalNerfactoTField(nn.Module):
                     self._prepared = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
                     _hip.check(lib.tn_field_prepare(f, self._prepared.data_ptr(), nbytes, _hip.current_stream()),
                                "tn_field_prepare")
-                nbytes = lib.tn_field_prepare_f16x3_bytes(f)
-                if nbytes > 0:
-                    self._prepared_h3 = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
-                    _hip.check(lib.tn_field_prepare_f16x3(f, self._prepared_h3.data_ptr(), nbytes, _hip.current_stream()),
-                               "tn_field_prepare_f16x3")
                 self._prepared_key = key
             f.prepared = None if self._prepared is None else self._prepared.data_ptr()
             if precision == "f16x3":
+                if self._prepared_h3 is None:  # built on first use for the current weights (the training path never needs it)
+                    nbytes = lib.tn_field_prepare_f16x3_bytes(f)
+                    if nbytes > 0:
+                        self._prepared_h3 = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
+                        _hip.check(lib.tn_field_prepare_f16x3(f, self._prepared_h3.data_ptr(), nbytes, _hip.current_stream()),
+                                   "tn_field_prepare_f16x3")
                 f.prepared_f16x3 = None if self._prepared_h3 is None else self._prepared_h3.data_ptr()
         return f
 

@@ -101,13 +101,41 @@ def weights_bwd(deltas: Tensor, density: Tensor, g_w: Tensor) -> Tensor:
 class _LevelTape:
     """What one sampling level keeps for its backward."""
 
-    __slots__ = ("pos", "enc", "sel", "hid", "raw", "density", "deltas", "weights", "spacing", "eucl")
+    __slots__ = ("pos", "enc", "sel", "hid", "raw", "density", "deltas", "weights", "spacing", "eucl", "starts", "ends")
 
 
-def _frustum_positions(o: Tensor, d: Tensor, eucl: Tensor) -> Tuple[Tensor, Tensor]:
-    R, n1 = eucl.shape
+def _starts_ends(t: "_LevelTape") -> Tuple[Tensor, Tensor]:
+    """contiguous [R,n] copies of the two edge columns of eucl [R,n+1], made once per level and step"""
+    if getattr(t, "starts", None) is None:
+        t.starts, t.ends = t.eucl[:, :-1].contiguous(), t.eucl[:, 1:].contiguous()
+    return t.starts, t.ends
+
+
+class _GradArena:
+    """Zero-initialised gradient buffers of one backward pass as views of ONE flat allocation cleared by ONE fill (the
+    adjoint kernels accumulate with += / atomics, so every parameter gradient starts at zero; a torch.zeros_like per
+    parameter was ~50 fill launches per step).  A fresh arena per backward: the views become the parameters' .grad and must
+    not alias the next step's."""
+
+    def __init__(self, like: Dict[str, Tensor], dev) -> None:
+        self.like, self.dev = like, dev
+        self.offsets: Dict[str, int] = {}
+        total = 0
+        for name, p in like.items():
+            self.offsets[name] = total
+            total += (p.numel() + 63) // 64 * 64  # 256-byte aligned views
+        self.flat = torch.zeros((total,), dtype=torch.float32, device=dev)
+
+    def get(self, name: str) -> Tensor:
+        p = self.like[name]
+        off = self.offsets[name]
+        return self.flat[off:off + p.numel()].view(p.shape)
+
+
+def _frustum_positions(o: Tensor, d: Tensor, t: "_LevelTape") -> Tuple[Tensor, Tensor]:
+    R, n1 = t.eucl.shape
     n = n1 - 1
-    starts, ends = eucl[:, :-1].contiguous(), eucl[:, 1:].contiguous()
+    starts, ends = _starts_ends(t)
     pos = _f32((R * n, 3), o.device)
     _hip.check(_hip.load().tn_frustum_positions(o.data_ptr(), d.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, n,
                                                 pos.data_ptr(), _stream()), "tn_frustum_positions")
@@ -118,7 +146,7 @@ def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl:
     lib = _hip.load()
     t = _LevelTape()
     t.spacing, t.eucl = spacing, eucl
-    t.pos, t.deltas = _frustum_positions(o, d, eucl)
+    t.pos, t.deltas = _frustum_positions(o, d, t)
     n = t.pos.shape[0]
     t.enc, t.sel = hash_encode_fwd(net_struct.grid, net_struct.space, t.pos)
     t.hid = linear_fwd(t.enc, 0, t.enc.shape[1], net_struct.l0, ACT_RELU, n)
@@ -138,7 +166,7 @@ def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, 
     g_pos = _f32((n, 3), g_enc.device)
     _hip.check(lib.tn_hash_encode_bwd_input(grid, space, t.pos.data_ptr(), g_enc.data_ptr(), n, g_pos.data_ptr(), _stream()),
                "tn_hash_encode_bwd_input")
-    starts, ends = t.eucl[:, :-1].contiguous(), t.eucl[:, 1:].contiguous()
+    starts, ends = _starts_ends(t)
     _hip.check(lib.tn_frustum_positions_bwd(g_pos.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, per, g_o.data_ptr(),
                                             g_d.data_ptr(), _stream()), "tn_frustum_positions_bwd")
 
@@ -156,7 +184,7 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
              f"{prefix}.mlp_base.mlp.layers.1.bias"]
     for k in names:
         if k not in grads:
-            grads[k] = torch.zeros_like(like[k])
+            grads[k] = like.get(k)  # `like` is the step's _GradArena: zero-filled views
     H = t.hid.shape[1]
     g_hid = _f32((n, H), g_w.device)
     linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
@@ -244,26 +272,45 @@ class RenderTrain(torch.autograd.Function):
         # ---- final level: taped field ----------------------------------------------------------------------
         f = _LevelTape()
         f.spacing, f.eucl = spacing, eucl
-        f.pos, f.deltas = _frustum_positions(o, d, eucl)
+        f.pos, f.deltas = _frustum_positions(o, d, f)
         N = R * S
-        f.enc, f.sel = hash_encode_fwd(fld.grid, fld.space, f.pos)
-        E = f.enc.shape[1]
-        h1 = linear_fwd(f.enc, 0, E, fld.base0, ACT_RELU, N)
-        bo = linear_fwd(h1, 0, h1.shape[1], fld.base1, ACT_NONE, N)  # [N, 1 + geo]: raw density | geo features
-        G = fld.geo_feat_dim
-        ldb = bo.shape[1]
-        f.density = _f32((N,), dev)
-        _hip.check(lib.tn_density_act_fwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density, N,
-                                          f.density.data_ptr(), _stream()), "tn_density_act_fwd")
-        cin = _f32((N, 64), dev)
-        _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), bo.data_ptr() + 4, ldb, cam.data_ptr(), 1, R, S,
-                                          cin.data_ptr(), _stream()), "tn_color_input_fwd")
-        c1 = linear_fwd(cin, 0, 64, fld.head0, ACT_RELU, N)
-        c2 = linear_fwd(c1, 0, c1.shape[1], fld.head1, ACT_RELU, N)
-        rgb_s = linear_fwd(c2, 0, c2.shape[1], fld.head2, ACT_SIGMOID, N)
-        t1 = linear_fwd(bo, 1, ldb, fld.th0, ACT_RELU, N)
-        t2 = linear_fwd(t1, 0, t1.shape[1], fld.th1, ACT_SIGMOID, N)
-        th_s = linear_fwd(t2, 0, t2.shape[1], fld.thead, ACT_NONE, N)
+        fused = None
+        if cfg.fused_train_forward:
+            fused = model.field.c_struct(prepare=True, dense=False)  # MFMA fragments of the CURRENT weights (rebuilt per step)
+            if not fused.prepared:
+                fused = None  # geometry the MFMA chain does not cover: stage-by-stage entry points below
+        if fused is not None:
+            # the whole field forward of the level in one launch; every tensor of the tape in the layout the adjoints read
+            f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
+            h1, bo = _f32((N, 64), dev), _f32((N, 16), dev)
+            c1, c2, rgb_s = _f32((N, 64), dev), _f32((N, 64), dev), _f32((N, 3), dev)
+            t1, t2, th_s = _f32((N, 64), dev), _f32((N, 64), dev), _f32((N, 1), dev)
+            _hip.check(lib.tn_field_fwd_taped(fused, f.pos.data_ptr(), d.data_ptr(), cam.data_ptr(), R, S, f.enc.data_ptr(),
+                                              f.sel.data_ptr(), h1.data_ptr(), bo.data_ptr(), f.density.data_ptr(),
+                                              c1.data_ptr(), c2.data_ptr(), rgb_s.data_ptr(), t1.data_ptr(), t2.data_ptr(),
+                                              th_s.data_ptr(), _stream()), "tn_field_fwd_taped")
+            ldb = bo.shape[1]
+            cin = _f32((N, 64), dev)  # the colour layer's input rows, which its weight gradient multiplies
+            _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), bo.data_ptr() + 4, ldb, cam.data_ptr(), 1, R, S,
+                                              cin.data_ptr(), _stream()), "tn_color_input_fwd")
+        else:
+            f.enc, f.sel = hash_encode_fwd(fld.grid, fld.space, f.pos)
+            E = f.enc.shape[1]
+            h1 = linear_fwd(f.enc, 0, E, fld.base0, ACT_RELU, N)
+            bo = linear_fwd(h1, 0, h1.shape[1], fld.base1, ACT_NONE, N)  # [N, 1 + geo]: raw density | geo features
+            ldb = bo.shape[1]
+            f.density = _f32((N,), dev)
+            _hip.check(lib.tn_density_act_fwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density, N,
+                                              f.density.data_ptr(), _stream()), "tn_density_act_fwd")
+            cin = _f32((N, 64), dev)
+            _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), bo.data_ptr() + 4, ldb, cam.data_ptr(), 1, R, S,
+                                              cin.data_ptr(), _stream()), "tn_color_input_fwd")
+            c1 = linear_fwd(cin, 0, 64, fld.head0, ACT_RELU, N)
+            c2 = linear_fwd(c1, 0, c1.shape[1], fld.head1, ACT_RELU, N)
+            rgb_s = linear_fwd(c2, 0, c2.shape[1], fld.head2, ACT_SIGMOID, N)
+            t1 = linear_fwd(bo, 1, ldb, fld.th0, ACT_RELU, N)
+            t2 = linear_fwd(t1, 0, t1.shape[1], fld.th1, ACT_SIGMOID, N)
+            th_s = linear_fwd(t2, 0, t2.shape[1], fld.thead, ACT_NONE, N)
         f.weights = weights_fwd(f.deltas, f.density.view(R, S))
 
         rgb, thermal = _f32((R, 3), dev), _f32((R, 1), dev)
@@ -273,12 +320,12 @@ class RenderTrain(torch.autograd.Function):
                    "tn_composite_fwd")
         acc, depth, expected = _f32((R, 1), dev), _f32((R, 1), dev), _f32((R, 1), dev)
         scratch = _f32((2,), dev)
-        starts, ends = eucl[:, :-1].contiguous(), eucl[:, 1:].contiguous()
+        starts, ends = _starts_ends(f)
         _hip.check(lib.tn_depth_fwd(f.weights.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S, acc.data_ptr(),
                                     depth.data_ptr(), expected.data_ptr(), scratch.data_ptr(), _stream()), "tn_depth_fwd")
         for t in (tapes if not prop_depths else []):
             pd = _f32((R, 1), dev)
-            st, en = t.eucl[:, :-1].contiguous(), t.eucl[:, 1:].contiguous()
+            st, en = _starts_ends(t)
             _hip.check(lib.tn_depth_fwd(t.weights.data_ptr(), st.data_ptr(), en.data_ptr(), R, t.weights.shape[1], None,
                                         pd.data_ptr(), None, None, _stream()), "tn_depth_fwd")
             prop_depths.append(pd)
@@ -319,8 +366,10 @@ class RenderTrain(torch.autograd.Function):
         # directions; config.sh_direction_gradient=True adds that term (a differentiable SH encoding)
         sh_grads = ray_grads is not None and bool(cfg.sh_direction_gradient)
 
+        arena = _GradArena(like, dev)  # every parameter gradient of this step: one allocation, one fill
+
         def zeros(name: str) -> Tensor:
-            grads[name] = torch.zeros_like(like[name])
+            grads[name] = arena.get(name)
             return grads[name]
 
         # ---- final level ------------------------------------------------------------------------------------
@@ -340,7 +389,7 @@ class RenderTrain(torch.autograd.Function):
                                             _stream()), "tn_composite_bwd")
         g_density = weights_bwd(f.deltas, f.density.view(R, S), g_w)
         if cfg.use_gradient_scaling:  # REF :228-231: field_outputs = scale_gradients_by_distance_squared(field_outputs, ray_samples)
-            starts, ends = f.eucl[:, :-1].contiguous(), f.eucl[:, 1:].contiguous()
+            starts, ends = _starts_ends(f)
             _hip.check(lib.tn_gradient_scale_bwd(starts.data_ptr(), ends.data_ptr(), N, g_density.data_ptr(), _hip.ptr(g_rgb_s),
                                                  _hip.ptr(g_th_s), _stream()), "tn_gradient_scale_bwd")
         ldb = bo.shape[1]
@@ -390,7 +439,7 @@ class RenderTrain(torch.autograd.Function):
                 t = ctx.tapes[lvl]
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
                 net = model.proposal_networks[which].c_struct(dense=False)
-                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", like,
+                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
                                     ray_grads)
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
