@@ -314,6 +314,25 @@ int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, 
 int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
                    float *d_densities, void *stream);
 
+/* Backward of up to three CONSECUTIVE Linear(+activation) layers in one launch (an MLP's chain: mlp_head, mlp_thermal + head,
+ * mlp_base).  layers[0] is the layer nearest the loss; layers[j].x = that layer's input rows (the ACTIVATED output of the
+ * layer below, produced by activation act_x), so layers[j].lin.out_dim == layers[j-1].lin.in_dim.  dy [n, out_0] (rows lddy
+ * apart) is the gradient w.r.t. layer 0's ACTIVATED output y_top (needed when act_top != none).  d_weight / d_bias (+=) per
+ * layer, may be NULL; dx [n, in_last] (= or += when accumulate_dx) may be NULL.  Same arithmetic as num_layers calls of
+ * tn_linear_bwd, with one [n, width] read per layer instead of three reads and a write. */
+typedef struct tn_chain_layer {
+    tn_linear lin;
+    const float *x;
+    int32_t ldx;
+    int32_t act_x;   /* TN_ACT_* of the layer that produced x (unused for the last layer) */
+    float *d_weight;
+    float *d_bias;
+} tn_chain_layer;
+size_t tn_linear_chain_bwd_workspace_bytes(void);
+int tn_linear_chain_bwd(const tn_chain_layer *layers, int32_t num_layers, const float *y_top, int32_t act_top, const float *dy,
+                        int32_t lddy, int64_t n, float *dx, int32_t lddx, int32_t accumulate_dx, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* The final level's field forward of a training step in ONE launch [REF thermal_field.py:183-201 in train mode]: what the
  * chain tn_hash_encode_fwd -> tn_linear_fwd (mlp_base x2) -> tn_density_act_fwd -> tn_color_input_fwd -> tn_linear_fwd
  * (mlp_head x3, mlp_thermal x2, head) computes, with every activation the backward differentiates written to its tape

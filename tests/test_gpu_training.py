@@ -62,6 +62,67 @@ def test_linear_fwd_bwd(IN, OUT, ldx, off, act, n):
     assert rel(dx[:, off:off + IN], 2 * x.grad) <= 1e-5 and rel(dw, 2 * w.grad) <= 1e-5
 
 
+# (in, out, activation) bottom-up, x row stride / column offset of the bottom input, top dy width
+CHAINS = {
+    "mlp_head": ([(63, 64, 1), (64, 64, 1), (64, 3, 2)], 64, 0),           # REF thermal_field.py:160-168 (cin is 64 wide, 63 used)
+    "mlp_thermal+head": ([(15, 64, 1), (64, 64, 2), (64, 1, 0)], 16, 1),   # REF :90-102,170-179 (input = columns 1..15 of bo)
+    "mlp_base": ([(32, 64, 1), (64, 16, 0)], 32, 0),
+    "proposal": ([(10, 16, 1), (16, 1, 0)], 10, 0),
+    "single": ([(64, 64, 1)], 64, 0),
+}
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+@pytest.mark.parametrize("n", [1000, 64, 1, 4097])
+def test_linear_chain_bwd(name, n):
+    """tn_linear_chain_bwd (each MLP's backward in one launch) against torch autograd over the same layers."""
+    spec, ldx, off = CHAINS[name]
+    g = torch.Generator().manual_seed(n + len(name))
+    act_fn = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid}
+    xfull = torch.randn(n, ldx, generator=g)
+    x0 = xfull[:, off:off + spec[0][0]].clone().requires_grad_(True)
+    ws, bs, acts = [], [], []
+    h = x0
+    for IN, OUT, act in spec:
+        w = (torch.randn(OUT, IN, generator=g) / IN**0.5).requires_grad_(True)
+        b = torch.randn(OUT, generator=g).requires_grad_(True)
+        h = act_fn[act](torch.nn.functional.linear(h, w, b))
+        ws.append(w); bs.append(b); acts.append(h)
+    dy = torch.randn(n, spec[-1][1], generator=g)
+    h.backward(dy)
+    # device side: the tape = activated outputs; layers listed top first, each with ITS input and the activation that made it
+    xd = xfull.to(DEV)
+    tape = [a.detach().to(DEV).contiguous() for a in acts]
+    dws = [torch.zeros_like(w.detach()).to(DEV) for w in ws]
+    dbs = [torch.zeros_like(b.detach()).to(DEV) for b in bs]
+    lins = [lin_struct(w.detach().to(DEV), b.detach().to(DEV)) for w, b in zip(ws, bs)]
+    keep = [l for l in lins]  # (the structs hold raw pointers of tensors created above: keep them alive)
+    wkeep = [(w.detach().to(DEV), b.detach().to(DEV)) for w, b in zip(ws, bs)]
+    lins = [lin_struct(w, b) for w, b in wkeep]
+    layers = []
+    for k in range(len(spec) - 1, -1, -1):
+        if k == 0:
+            layers.append((lins[0], xd, off, ldx, 0, dws[0], dbs[0]))
+        else:
+            layers.append((lins[k], tape[k - 1], 0, spec[k][0], spec[k - 1][2], dws[k], dbs[k]))
+    top_act = spec[-1][2]
+    dx = torch.full((n, ldx), 7.0, device=DEV)
+    TR.linear_chain_bwd(layers, tape[-1] if top_act else None, top_act, dy.to(DEV), spec[-1][1], n, dx, off, ldx, False)
+    IN0 = spec[0][0]
+    assert rel(dx[:, off:off + IN0], x0.grad) <= 2e-5, rel(dx[:, off:off + IN0], x0.grad)
+    if off:
+        assert torch.all(dx[:, :off] == 7.0), "columns outside the chain's input were touched"
+    for k in range(len(spec)):
+        assert rel(dws[k], ws[k].grad) <= 2e-5, (k, rel(dws[k], ws[k].grad))
+        assert rel(dbs[k], bs[k].grad) <= 2e-5, (k, rel(dbs[k], bs[k].grad))
+    # accumulate_dx adds on top; weight/bias gradients accumulate (+=); dx may be NULL
+    TR.linear_chain_bwd(layers, tape[-1] if top_act else None, top_act, dy.to(DEV), spec[-1][1], n, dx, off, ldx, True)
+    assert rel(dx[:, off:off + IN0], 2 * x0.grad) <= 2e-5 and rel(dws[0], 2 * ws[0].grad) <= 2e-5
+    TR.linear_chain_bwd(layers, tape[-1] if top_act else None, top_act, dy.to(DEV), spec[-1][1], n, None, 0, ldx, False)
+    assert rel(dws[-1], 3 * ws[-1].grad) <= 2e-5
+    del keep
+
+
 @pytest.mark.parametrize("contraction", [True, False])
 def test_hash_encode_fwd_bwd(contraction):
     L, log2T = 16, 15
@@ -219,9 +280,10 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
     use_same_proposal_network [REF :122-139] — next to the default configuration."""
     if variant not in ("default", "stage_forward") and S != 48:
         pytest.skip("config variants are checked at the reference's default sample count")
-    # default = the final level's forward as one fused MFMA kernel (tn_field_fwd_taped); stage_forward = one launch per module
+    # default = the final level's forward as one fused MFMA kernel (tn_field_fwd_taped) and each MLP's backward as one launch
+    # (tn_linear_chain_bwd); stage_forward = one launch per nerfstudio module / layer in both directions
     over = {"gradient_scaling": {"use_gradient_scaling": True}, "same_proposal_network": ONE_NET,
-            "stage_forward": {"fused_train_forward": False}}.get(variant, {})
+            "stage_forward": {"fused_train_forward": False, "fused_train_backward": False}}.get(variant, {})
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, **over)
     if variant == "same_proposal_network":
         assert len(gm.proposal_networks) == 1

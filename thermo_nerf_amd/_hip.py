@@ -49,6 +49,11 @@ class tn_linear(C.Structure):
     _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
 
 
+class tn_chain_layer(C.Structure):
+    _fields_ = [("lin", tn_linear), ("x", C.c_void_p), ("ldx", C.c_int32), ("act_x", C.c_int32), ("d_weight", C.c_void_p),
+                ("d_bias", C.c_void_p)]
+
+
 class tn_space(C.Structure):
     _fields_ = [
         ("contraction", C.c_int32),
@@ -180,6 +185,8 @@ SIGNATURES = {
     "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _vp, _i64, _vp, _i32, _vp]),
     "tn_weights_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tn_gradient_scale_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tn_linear_chain_bwd_workspace_bytes": (_sz, []),
+    "tn_linear_chain_bwd": (C.c_int, [C.POINTER(tn_chain_layer), _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
     "tn_field_fwd_taped": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32] + [_vp] * 12),
     "tn_composite_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "tn_color_input_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),

@@ -495,6 +495,227 @@ linear_bwd_mfma_kernel(const float *__restrict__ x, int ldx, const float *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// linear_chain_bwd_kernel — the backward of up to three CONSECUTIVE Linear(+activation) layers of an MLP in one launch
+// (mlp_head: 3 layers, mlp_thermal + head: 3, mlp_base: 2).  Layer by layer the single-layer kernel above streams x, y, dy in
+// and dx out of HBM: four [N, 64] matrices per layer.  In a chain the input x_j of layer j IS the activated output of the
+// layer below, so  g_{j+1} = dx_j . act'(x_j)  is formed in LDS from the tile that was loaded for dW_j anyway: per layer ONE
+// [64-row, width] tile is read, and only the chain's last dx is written.  Per 64-row tile and layer the 4 waves own the 4
+// 32x32 tiles of dW (g^T x, K = the 64 rows) and of dx^T (W^T g^T, K = OUT), as in linear_bwd_mfma_kernel; dW of every layer
+// accumulates in registers across the block's tiles and leaves as one slab per layer and block (linear_bwd_reduce_kernel).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kChainMax = 3;
+constexpr int kChainBlocks = 512;  // persistent; LDS = the layers' weights (OUT rows of 64) + 2 row tiles: <= 80 KB -> 2 blocks per CU
+
+struct ChainLayerDev {
+    const float *W;   // [OUT][IN]
+    const float *x;   // input rows of the layer (= activated output of the layer below), ldx floats apart
+    int IN, OUT, ldx, act_x, vec_x;
+};
+struct ChainArgs {
+    ChainLayerDev L[kChainMax];  // L[0] = the layer nearest the loss
+    int nl;
+    const float *dy;     // [n, OUT_0] rows lddy apart
+    const float *y_top;  // activated output of layer 0 (its activation's derivative), or nullptr when act_top == none
+    int lddy, act_top, vec_top;
+    long long n;
+    float *dx;           // [n, IN_last]
+    int lddx, accumulate_dx, vec_dx;
+    float *partials;     // [nl][blocks][65][64]
+};
+
+// a [64-row, <= 64 column] tile of a row-major matrix in 16 registers per thread (thread t: row (t + 256 q) >> 4, columns
+// 4 ((t + 256 q) & 15) .. +3, q = 0..3); vec: 16-byte loads, else element loads; out-of-range entries are zero
+struct TileRegs {
+    float4 v[4];
+};
+__device__ __forceinline__ void tile_fetch(TileRegs &t, const float *__restrict__ p, int ld, int cols, long long base, long long n,
+                                           int vec) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + q * kBlock, r = e >> 4, c = (e & 15) * 4;
+        float4 x4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (base + r < n && c < cols) {
+            const float *src = p + (size_t)(base + r) * ld + c;
+            if (vec) {
+                x4 = *reinterpret_cast<const float4 *>(src);
+            } else {
+                x4.x = src[0];
+                if (c + 1 < cols) x4.y = src[1];
+                if (c + 2 < cols) x4.z = src[2];
+                if (c + 3 < cols) x4.w = src[3];
+            }
+        }
+        t.v[q] = x4;
+    }
+}
+__device__ __forceinline__ void tile_to_lds(const TileRegs &t, float *dst) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + q * kBlock, r = e >> 4, c = (e & 15) * 4;
+        float *d = dst + r * LDP + c;
+        d[0] = t.v[q].x; d[1] = t.v[q].y; d[2] = t.v[q].z; d[3] = t.v[q].w;
+    }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(kBlock, 2) linear_chain_bwd_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // W_j as [o][i]: even(OUT_j) rows of 64 (read along rows only: no padding needed), zero padded
+    float *Ws = smem;
+    int woff[NL + 1];
+    woff[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) woff[j + 1] = woff[j] + ((a.L[j].OUT + 1) & ~1) * 64;
+    float *gs = Ws + woff[NL];              // [TILE * LDP]    g rows [row][o]
+    float *xs = gs + TILE * LDP;            // [TILE * LDP]    x rows [row][i]; staging of the final dx
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int IN = a.L[j].IN, OUT = a.L[j].OUT;
+        for (int e = threadIdx.x; e < ((OUT + 1) & ~1) * 64; e += kBlock) {
+            const int o = e >> 6, i = e & 63;
+            Ws[woff[j] + e] = (o < OUT && i < IN) ? a.L[j].W[o * IN + i] : 0.0f;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    f32x16 accw[NL];
+    float accb[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[j][r] = 0.0f;
+        accb[j] = 0.0f;
+    }
+    const long long tiles = (a.n + TILE - 1) / TILE;
+    // Every tile of the chain (dy, y_top, x_0 .. x_{NL-1}) is fetched into registers ONE TILE AHEAD: a register set is
+    // re-issued for the next tile right after it was copied to LDS, so the loads fly during the MFMAs of the current tile and
+    // the block never waits for HBM in steady state (one block per CU: there is no other block to hide the latency).
+    TileRegs rdy, ry, rx[NL];
+    const int OUT0 = a.L[0].OUT;
+    auto fetch_top = [&](long long tile) {
+        const long long base = tile * TILE;
+        tile_fetch(rdy, a.dy, a.lddy, OUT0, base, a.n, a.vec_top);
+        if (a.act_top != TN_ACT_NONE) tile_fetch(ry, a.y_top, a.lddy, OUT0, base, a.n, a.vec_top);
+    };
+    if ((long long)blockIdx.x < tiles) {
+        fetch_top(blockIdx.x);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) tile_fetch(rx[j], a.L[j].x, a.L[j].ldx, a.L[j].IN, (long long)blockIdx.x * TILE, a.n, a.L[j].vec_x);
+    }
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        const long long next = tile + gridDim.x;
+        __syncthreads();  // the previous tile's readers of gs / xs are done
+        {   // g of the top layer: dy . act'(y)
+            TileRegs g0 = rdy;
+            if (a.act_top != TN_ACT_NONE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    g0.v[q].x *= act_bwd(ry.v[q].x, a.act_top);
+                    g0.v[q].y *= act_bwd(ry.v[q].y, a.act_top);
+                    g0.v[q].z *= act_bwd(ry.v[q].z, a.act_top);
+                    g0.v[q].w *= act_bwd(ry.v[q].w, a.act_top);
+                }
+            }
+            tile_to_lds(g0, gs);
+            if (next < tiles) fetch_top(next);
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const ChainLayerDev &L = a.L[j];
+            const int IN = L.IN, OUT = L.OUT;
+            const int n_it = (IN + 31) >> 5, n_ot = (OUT + 31) >> 5, ksteps_o = (OUT + 1) >> 1;
+            const float *Wj = Ws + woff[j];
+            tile_to_lds(rx[j], xs);
+            if (next < tiles) tile_fetch(rx[j], L.x, L.ldx, IN, next * TILE, a.n, L.vec_x);
+            __syncthreads();  // gs (g_j) and xs (x_j) complete
+            const int ot = wave % n_ot, it2 = wave / n_ot;
+            if (wave < n_ot * n_it) {  // dW_j tile (ot, it2)
+#pragma unroll 8
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    const float av = gs[(2 * s2 + h) * LDP + ot * 32 + l31];
+                    const float bv = xs[(2 * s2 + h) * LDP + it2 * 32 + l31];
+                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
+                }
+            }
+            if (threadIdx.x < 64) {  // bias_j: column sums of g_j
+                float sb = 0.0f;
+                for (int r = 0; r < TILE; ++r) sb += gs[r * LDP + threadIdx.x];
+                accb[j] += sb;
+            }
+            const bool last = j == NL - 1;
+            const bool has_dx = (!last || a.dx != nullptr) && wave < n_it * 2;
+            const int it = wave % n_it, nt = wave / n_it;
+            f32x16 accd;
+            if (has_dx) {  // dx_j^T tile (it, nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+                for (int s2 = 0; s2 < ksteps_o; ++s2) {
+                    const float av = Wj[(2 * s2 + h) * 64 + it * 32 + l31];
+                    const float bv = gs[(nt * 32 + l31) * LDP + 2 * s2 + h];
+                    accd = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd, 0, 0, 0);
+                }
+            }
+            __syncthreads();  // every MFMA operand read of gs / xs is done
+            if (!last) {
+                // g_{j+1}[row][i] = dx_j[row][i] . act'(x_j[row][i]) -> gs
+                if (has_dx) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = nt * 32 + l31, col = it * 32 + crow(r, h);
+                        gs[row * LDP + col] = accd[r] * act_bwd(xs[row * LDP + col], L.act_x);
+                    }
+                }
+                if (n_it == 1) {  // the upper 32 columns are not covered by a dx tile: clear them (the next layer's K range)
+                    for (int e = threadIdx.x; e < TILE * 32; e += kBlock) gs[(e >> 5) * LDP + 32 + (e & 31)] = 0.0f;
+                }
+                __syncthreads();  // the next layer's x tile overwrites xs: all act' reads above are done
+            } else if (a.dx) {
+                if (has_dx) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xs[(nt * 32 + l31) * LDP + it * 32 + crow(r, h)] = accd[r];
+                }
+                __syncthreads();
+                if (a.vec_dx) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int e = threadIdx.x + q * kBlock, r = e >> 4, c = (e & 15) * 4;
+                        if (base + r < a.n && c < IN) {
+                            const float *sp = xs + r * LDP + c;
+                            *reinterpret_cast<float4 *>(a.dx + (size_t)(base + r) * a.lddx + c) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                        }
+                    }
+                } else {
+                    for (int e = threadIdx.x; e < TILE * 64; e += kBlock) {
+                        const int r = e >> 6, i = e & 63;
+                        if (base + r < a.n && i < IN) {
+                            float *p = a.dx + (size_t)(base + r) * a.lddx + i;
+                            const float v = xs[r * LDP + i];
+                            *p = a.accumulate_dx ? *p + v : v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // one slab [i (64 rows) | bias row][o (64)] per layer and block
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int n_it = (a.L[j].IN + 31) >> 5, n_ot = (a.L[j].OUT + 31) >> 5;
+        float *pb = a.partials + ((size_t)j * gridDim.x + blockIdx.x) * 65 * 64;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 65 * 64; e += kBlock) pb[e] = 0.0f;
+        __syncthreads();
+        const int ot = wave % n_ot, it2 = wave / n_ot;
+        if (wave < n_ot * n_it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pb[(it2 * 32 + l31) * 64 + ot * 32 + crow(r, h)] = accw[j][r];
+        }
+        if (threadIdx.x < 64) pb[64 * 64 + threadIdx.x] = accb[j];
+    }
+}
+
 // dW[o][i] += sum_b partials[b][i][o];  db[o] += sum_b partials[b][INP][o].  grid (INP + 1 rows, kRedSplit slices of
 // the block range); 256 threads = 64 outputs x 4 interleaved block streams; one atomic per (entry, slice).
 constexpr int kRedSplit = 8;
@@ -1082,6 +1303,63 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
     if (partials) {
         hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(INP + 1, kRedSplit), dim3(kBlock), 0, st, partials, blocks, INP, IN, OUT,
                            d_weight, d_bias);
+        TN_LAUNCH_CHECK();
+    }
+    return TN_OK;
+}
+
+size_t tn_linear_chain_bwd_workspace_bytes(void) { return (size_t)kChainMax * kChainBlocks * 65 * 64 * sizeof(float); }
+
+int tn_linear_chain_bwd(const tn_chain_layer *layers, int32_t num_layers, const float *y_top, int32_t act_top, const float *dy,
+                        int32_t lddy, int64_t n, float *dx, int32_t lddx, int32_t accumulate_dx, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+    if (!layers || !dy) return TN_ERR_NULL;
+    if (num_layers < 1 || num_layers > kChainMax || n < 0) return TN_ERR_SHAPE;
+    if (act_top < TN_ACT_NONE || act_top > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
+    if (act_top != TN_ACT_NONE && !y_top) return TN_ERR_NULL;
+    if (n == 0) return TN_OK;
+    if (!workspace || workspace_bytes < tn_linear_chain_bwd_workspace_bytes()) return TN_ERR_WORKSPACE;
+    auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    ChainArgs a;
+    a.nl = num_layers;
+    for (int j = 0; j < num_layers; ++j) {
+        const tn_chain_layer &l = layers[j];
+        if (!l.lin.weight || !l.x) return TN_ERR_NULL;
+        const int IN = l.lin.in_dim, OUT = l.lin.out_dim;
+        if (IN < 1 || IN > 64 || OUT < 1 || OUT > 64 || l.ldx < IN) return TN_ERR_SHAPE;
+        if (j > 0 && layers[j - 1].lin.in_dim != OUT) return TN_ERR_SHAPE;  // x_{j-1} is this layer's output
+        if (l.act_x < TN_ACT_NONE || l.act_x > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
+        a.L[j].W = l.lin.weight; a.L[j].x = l.x; a.L[j].IN = IN; a.L[j].OUT = OUT; a.L[j].ldx = l.ldx; a.L[j].act_x = l.act_x;
+        a.L[j].vec_x = (l.ldx % 4 == 0) && (IN % 4 == 0) && al16(l.x);
+    }
+    const int OUT0 = layers[0].lin.out_dim, INL = layers[num_layers - 1].lin.in_dim;
+    if (lddy < OUT0 || (dx && lddx < INL)) return TN_ERR_SHAPE;
+    a.dy = dy; a.y_top = y_top; a.lddy = lddy; a.act_top = act_top;
+    a.vec_top = (lddy % 4 == 0) && (OUT0 % 4 == 0) && al16(dy) && (act_top == TN_ACT_NONE || al16(y_top));
+    a.n = n; a.dx = dx; a.lddx = lddx; a.accumulate_dx = accumulate_dx;
+    a.vec_dx = dx && !accumulate_dx && (lddx % 4 == 0) && (INL % 4 == 0) && al16(dx);
+    a.partials = reinterpret_cast<float *>(workspace);
+    const int blocks = grid_for((n + TILE - 1) / TILE, 1, kChainBlocks);
+    hipStream_t st = (hipStream_t)stream;
+    size_t wrows = 0;
+    for (int j = 0; j < num_layers; ++j) wrows += (size_t)((layers[j].lin.out_dim + 1) & ~1);
+    const size_t smem = (wrows * 64 + 2 * TILE * LDP) * sizeof(float);
+    if (num_layers == 1) {
+        if (!tn_ensure_dynamic_lds<linear_chain_bwd_kernel<1>>(smem)) return TN_ERR_LAUNCH;
+        hipLaunchKernelGGL(linear_chain_bwd_kernel<1>, dim3(blocks), dim3(kBlock), smem, st, a);
+    } else if (num_layers == 2) {
+        if (!tn_ensure_dynamic_lds<linear_chain_bwd_kernel<2>>(smem)) return TN_ERR_LAUNCH;
+        hipLaunchKernelGGL(linear_chain_bwd_kernel<2>, dim3(blocks), dim3(kBlock), smem, st, a);
+    } else {
+        if (!tn_ensure_dynamic_lds<linear_chain_bwd_kernel<3>>(smem)) return TN_ERR_LAUNCH;
+        hipLaunchKernelGGL(linear_chain_bwd_kernel<3>, dim3(blocks), dim3(kBlock), smem, st, a);
+    }
+    TN_LAUNCH_CHECK();
+    for (int j = 0; j < num_layers; ++j) {
+        if (!layers[j].d_weight && !layers[j].d_bias) continue;
+        hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(65, kRedSplit), dim3(kBlock), 0, st,
+                           a.partials + (size_t)j * blocks * 65 * 64, blocks, 64, layers[j].lin.in_dim, layers[j].lin.out_dim,
+                           layers[j].d_weight, layers[j].d_bias);
         TN_LAUNCH_CHECK();
     }
     return TN_OK;

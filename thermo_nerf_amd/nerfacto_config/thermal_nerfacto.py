@@ -85,6 +85,9 @@ class NerfactoModelConfig:
     fused_train_forward: bool = True
     """Training: the final level's field forward (encode + mlp_base + heads, with its tape) as ONE MFMA kernel
     (tn_field_fwd_taped); False: the stage-by-stage entry points (one launch per nerfstudio module)."""
+    fused_train_backward: bool = True
+    """Training: the backward of each MLP (mlp_head, mlp_thermal + head, mlp_base, the proposal MLPs) as ONE launch per MLP
+    (tn_linear_chain_bwd: one tile read per layer); False: one tn_linear_bwd launch per layer."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""

@@ -82,6 +82,30 @@ def linear_bwd(x: Tensor, x_off: int, ldx: int, y: Optional[Tensor], dy: Tensor,
         _stream()), "tn_linear_bwd")
 
 
+_CHAIN_WS: Dict = {}
+
+
+def linear_chain_bwd(layers, y_top: Optional[Tensor], act_top: int, dy: Tensor, lddy: int, n: int, dx: Optional[Tensor],
+                     dx_off: int, lddx: int, accumulate: bool) -> None:
+    """Backward of consecutive Linear(+activation) layers in one launch.  ``layers``: top (nearest the loss) first, each
+    (tn_linear, x tensor, x column offset, ldx, activation that produced x, d_weight, d_bias)."""
+    lib = _hip.load()
+    dev = dy.device
+    ws = _CHAIN_WS.get(dev)
+    if ws is None:
+        ws = _CHAIN_WS[dev] = torch.empty(lib.tn_linear_chain_bwd_workspace_bytes(), dtype=torch.uint8, device=dev)
+    arr = (_hip.tn_chain_layer * len(layers))()
+    for k, (lin, x, x_off, ldx, act_x, d_w, d_b) in enumerate(layers):
+        arr[k].lin = lin
+        arr[k].x = x.data_ptr() + 4 * x_off
+        arr[k].ldx, arr[k].act_x = ldx, act_x
+        arr[k].d_weight = None if d_w is None else d_w.data_ptr()
+        arr[k].d_bias = None if d_b is None else d_b.data_ptr()
+    _hip.check(lib.tn_linear_chain_bwd(arr, len(layers), None if y_top is None else y_top.data_ptr(), act_top, dy.data_ptr(), lddy,
+                                       n, None if dx is None else dx.data_ptr() + 4 * dx_off, lddx, 1 if accumulate else 0,
+                                       ws.data_ptr(), ws.numel(), _stream()), "tn_linear_chain_bwd")
+
+
 def weights_fwd(deltas: Tensor, density: Tensor) -> Tensor:
     R, n = deltas.shape
     w = _f32((R, n), deltas.device)
@@ -172,7 +196,7 @@ def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, 
 
 
 def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict,
-                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None) -> None:
+                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True) -> None:
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
@@ -186,11 +210,16 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
         if k not in grads:
             grads[k] = like.get(k)  # `like` is the step's _GradArena: zero-filled views
     H = t.hid.shape[1]
-    g_hid = _f32((n, H), g_w.device)
-    linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
     E = t.enc.shape[1]
     g_enc = _f32((n, E), g_w.device)
-    linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
+    if chained:
+        linear_chain_bwd([(net_struct.l1, t.hid, 0, H, ACT_RELU, grads[names[3]], grads[names[4]]),
+                          (net_struct.l0, t.enc, 0, E, ACT_NONE, grads[names[1]], grads[names[2]])],
+                         None, ACT_NONE, g_raw, 1, n, g_enc, 0, E, False)
+    else:
+        g_hid = _f32((n, H), g_w.device)
+        linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
+        linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
     hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]])
     if ray_grads is not None:
         _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads)
@@ -397,36 +426,47 @@ class RenderTrain(torch.autograd.Function):
         _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density,
                                           g_density.data_ptr(), N, g_bo.data_ptr(), ldb, _stream()), "tn_density_act_bwd")
         W = 64
+        chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
         if g_th_s is not None:  # thermal branch [REF thermal_field.py:170-179]
-            g_t2, g_t1 = _f32((N, W), dev), _f32((N, W), dev)
-            linear_bwd(t2, 0, W, None, g_th_s, 1, fld.thead, ACT_NONE, N, g_t2, 0, W, False,
-                       zeros("field.field_head_thermal.net.weight"), zeros("field.field_head_thermal.net.bias"))
-            linear_bwd(t1, 0, W, t2, g_t2, W, fld.th1, ACT_SIGMOID, N, g_t1, 0, W, False,
-                       zeros("field.mlp_thermal.layers.1.weight"), zeros("field.mlp_thermal.layers.1.bias"))
             into_geo = g_bo if model.field.pass_thermal_gradients else None  # REF :171-172 (.detach())
-            linear_bwd(bo, 1, ldb, t1, g_t1, W, fld.th0, ACT_RELU, N, into_geo, 1, ldb, True,
-                       zeros("field.mlp_thermal.layers.0.weight"), zeros("field.mlp_thermal.layers.0.bias"))
+            th = [(fld.thead, t2, 0, W, ACT_SIGMOID, zeros("field.field_head_thermal.net.weight"),
+                   zeros("field.field_head_thermal.net.bias")),
+                  (fld.th1, t1, 0, W, ACT_RELU, zeros("field.mlp_thermal.layers.1.weight"), zeros("field.mlp_thermal.layers.1.bias")),
+                  (fld.th0, bo, 1, ldb, ACT_NONE, zeros("field.mlp_thermal.layers.0.weight"), zeros("field.mlp_thermal.layers.0.bias"))]
+            if chained:
+                linear_chain_bwd(th, None, ACT_NONE, g_th_s, 1, N, into_geo, 1, ldb, True)
+            else:
+                g_t2, g_t1 = _f32((N, W), dev), _f32((N, W), dev)
+                linear_bwd(t2, 0, W, None, g_th_s, 1, fld.thead, ACT_NONE, N, g_t2, 0, W, False, th[0][5], th[0][6])
+                linear_bwd(t1, 0, W, t2, g_t2, W, fld.th1, ACT_SIGMOID, N, g_t1, 0, W, False, th[1][5], th[1][6])
+                linear_bwd(bo, 1, ldb, t1, g_t1, W, fld.th0, ACT_RELU, N, into_geo, 1, ldb, True, th[2][5], th[2][6])
         if g_rgb_s is not None:  # colour branch [REF :160-168]
-            g_c2, g_c1 = _f32((N, W), dev), _f32((N, W), dev)
             g_cin = _f32((N, 64), dev)
-            linear_bwd(c2, 0, W, rgb_s, g_rgb_s, 3, fld.head2, ACT_SIGMOID, N, g_c2, 0, W, False,
-                       zeros("field.mlp_head.layers.2.weight"), zeros("field.mlp_head.layers.2.bias"))
-            linear_bwd(c1, 0, W, c2, g_c2, W, fld.head1, ACT_RELU, N, g_c1, 0, W, False,
-                       zeros("field.mlp_head.layers.1.weight"), zeros("field.mlp_head.layers.1.bias"))
-            linear_bwd(cin, 0, 64, c1, g_c1, W, fld.head0, ACT_RELU, N, g_cin, 0, 64, False,
-                       zeros("field.mlp_head.layers.0.weight"), zeros("field.mlp_head.layers.0.bias"))
+            hd = [(fld.head2, c2, 0, W, ACT_RELU, zeros("field.mlp_head.layers.2.weight"), zeros("field.mlp_head.layers.2.bias")),
+                  (fld.head1, c1, 0, W, ACT_RELU, zeros("field.mlp_head.layers.1.weight"), zeros("field.mlp_head.layers.1.bias")),
+                  (fld.head0, cin, 0, 64, ACT_NONE, zeros("field.mlp_head.layers.0.weight"), zeros("field.mlp_head.layers.0.bias"))]
+            if chained:
+                linear_chain_bwd(hd, rgb_s, ACT_SIGMOID, g_rgb_s, 3, N, g_cin, 0, 64, False)
+            else:
+                g_c2, g_c1 = _f32((N, W), dev), _f32((N, W), dev)
+                linear_bwd(c2, 0, W, rgb_s, g_rgb_s, 3, fld.head2, ACT_SIGMOID, N, g_c2, 0, W, False, hd[0][5], hd[0][6])
+                linear_bwd(c1, 0, W, c2, g_c2, W, fld.head1, ACT_RELU, N, g_c1, 0, W, False, hd[1][5], hd[1][6])
+                linear_bwd(cin, 0, 64, c1, g_c1, W, fld.head0, ACT_RELU, N, g_cin, 0, 64, False, hd[2][5], hd[2][6])
             _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, S, g_bo.data_ptr() + 4, ldb,
                                               zeros("field.embedding_appearance.embedding.weight").data_ptr(),
                                               ctx.d.data_ptr() if sh_grads else None,
                                               ray_grads[1].data_ptr() if sh_grads else None, _stream()),
                        "tn_color_input_bwd")
-        g_h1 = _f32((N, W), dev)
-        linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False,
-                   zeros("field.mlp_base.mlp.layers.1.weight"), zeros("field.mlp_base.mlp.layers.1.bias"))
         E = f.enc.shape[1]
         g_enc = _f32((N, E), dev)
-        linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False,
-                   zeros("field.mlp_base.mlp.layers.0.weight"), zeros("field.mlp_base.mlp.layers.0.bias"))
+        bs = [(fld.base1, h1, 0, W, ACT_RELU, zeros("field.mlp_base.mlp.layers.1.weight"), zeros("field.mlp_base.mlp.layers.1.bias")),
+              (fld.base0, f.enc, 0, E, ACT_NONE, zeros("field.mlp_base.mlp.layers.0.weight"), zeros("field.mlp_base.mlp.layers.0.bias"))]
+        if chained:
+            linear_chain_bwd(bs, None, ACT_NONE, g_bo, ldb, N, g_enc, 0, E, False)
+        else:
+            g_h1 = _f32((N, W), dev)
+            linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
+            linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
         hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"))
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
@@ -440,7 +480,7 @@ class RenderTrain(torch.autograd.Function):
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
                 net = model.proposal_networks[which].c_struct(dense=False)
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
-                                    ray_grads)
+                                    ray_grads, chained)
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
         result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)
