@@ -128,18 +128,26 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
         const unsigned m = g.mask;
         const unsigned idx[8] = {(cx ^ hcy ^ hcz) & m, (cx ^ hfy ^ hcz) & m, (fx ^ hfy ^ hcz) & m, (fx ^ hcy ^ hcz) & m,
                                  (cx ^ hcy ^ hfz) & m, (cx ^ hfy ^ hfz) & m, (fx ^ hfy ^ hfz) & m, (fx ^ hcy ^ hfz) & m};
-        // issue with the two features of an entry on NEIGHBOURING lanes (one 8-byte segment per lane pair): lane L adds
-        // feature (L & 1) of sample (L >> 1) of each half-wave, so an instruction touches 32 segments instead of 64 lines
-        const int feat = lane & 1, tl = tail ? 1 : 0;
+        // The memory side retires ~21 G atomic transactions/s on this part, one per 64-byte line an instruction touches,
+        // whatever the line carries (tools/micro/atomics.hip: 4, 8, 16 ... 64 contiguous bytes of adds cost the same).  So an
+        // instruction should put as much of a line as possible on its lanes: the hash's first prime is 1, hence the two
+        // x-neighbours (ceil-x and floor-x corner at the same y, z) sit in the same aligned group of 8 entries = the same line
+        // 7 times out of 8.  Lane L adds feature (L & 1) of x-corner ((L >> 1) & 1) of sample (L >> 2) of each quarter-wave,
+        // one (y, z) combination per instruction: 16 lines per instruction instead of 32 eight-byte segments on 32 lines.
+        const int feat = lane & 1, xc = (lane >> 1) & 1, tl = tail ? 1 : 0;
+        constexpr int kPairs[4][2] = {{0, 3}, {1, 2}, {4, 7}, {5, 6}};  // (ceil-x, floor-x) corners sharing (y, z)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int src = half * 32 + (lane >> 1);
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            const int src = quarter * 16 + (lane >> 2);
             const int st = __shfl(tl, src, 64);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float v0 = __shfl(v[2 * c], src, 64), v1 = __shfl(v[2 * c + 1], src, 64);
-                const unsigned id = (unsigned)__shfl((int)idx[c], src, 64);
-                const float val = feat ? v1 : v0;
+            for (int p = 0; p < 4; ++p) {
+                const int ca = kPairs[p][0], cb = kPairs[p][1];
+                const float a0 = __shfl(v[2 * ca], src, 64), a1 = __shfl(v[2 * ca + 1], src, 64);
+                const float b0 = __shfl(v[2 * cb], src, 64), b1 = __shfl(v[2 * cb + 1], src, 64);
+                const unsigned ia = (unsigned)__shfl((int)idx[ca], src, 64), ib = (unsigned)__shfl((int)idx[cb], src, 64);
+                const float val = xc ? (feat ? b1 : b0) : (feat ? a1 : a0);
+                const unsigned id = xc ? ib : ia;
                 if (st && val != 0.0f) atomic_add_f32(tb + (size_t)id * 2 + feat, val);
             }
         }

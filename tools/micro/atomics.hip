@@ -63,6 +63,35 @@ void run(const char *name, float *table, unsigned log2e, unsigned *census) {
     printf("%-34s %8.3f ms  %7.2f G float-adds/s  sum/adds = %.6f  xcc mask 0x%x\n", name, ms, adds / ms / 1e6, sum / adds, c);
 }
 
+// GROUP consecutive lanes add to GROUP consecutive floats (GROUP * 4 contiguous bytes): does the rate follow lanes or segments?
+template <int GROUP>
+__global__ void __launch_bounds__(256) kg(float *table, unsigned floats_log2, long long per_thread) {
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned mask = (1u << floats_log2) - 1u;
+    for (long long i = 0; i < per_thread; ++i) {
+        unsigned f = (hash32((tid / GROUP) * 7919u + (unsigned)i * 104729u) * GROUP) & mask;
+        unsafeAtomicAdd(table + f + (tid % GROUP), 1.0f);
+    }
+}
+template <int GROUP>
+void rung(float *table, unsigned log2e) {
+    const int blocks = 2048, threads = 256;
+    const long long per_thread = 96;
+    CK(hipMemset(table, 0, (size_t)8 << log2e));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((kg<GROUP>), dim3(blocks), dim3(threads), 0, 0, table, log2e + 1, per_thread);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((kg<GROUP>), dim3(blocks), dim3(threads), 0, 0, table, log2e + 1, per_thread);
+    CK(hipEventRecord(b));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    const double adds = (double)blocks * threads * per_thread;
+    printf("contiguous group of %2d lanes (%3d B)   %8.3f ms  %7.2f G float-adds/s  %7.2f G segments/s\n", GROUP, GROUP * 4, ms,
+           adds / ms / 1e6, adds / GROUP / ms / 1e6);
+}
+
 int main() {
     const unsigned log2e = 23;  // 8 M entries x 8 B = 64 MB (16 levels x 2^19)
     float *table; unsigned *census;
@@ -75,5 +104,7 @@ int main() {
     run<1, true>("agent scope, XCD-partitioned", table, log2e, census);
     run<2, true>("workgroup scope, XCD-partitioned", table, log2e, census);
     run<3, true>("wavefront scope, XCD-partitioned", table, log2e, census);
+    rung<1>(table, log2e); rung<2>(table, log2e); rung<4>(table, log2e); rung<8>(table, log2e); rung<16>(table, log2e);
+    rung<32>(table, log2e); rung<64>(table, log2e);
     return 0;
 }
