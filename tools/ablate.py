@@ -11,9 +11,10 @@ FLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unus
 
 
 def variant(name: str, src: str) -> str:
-    if name == "nohash":
-        return src.replace("f[q] = encode_level<false, true>(a.g, l0 + q, px, py, pz);",
-                           "f[q] = make_float2(px * (float)(l0 + q), py + pz);")
+    if name == "nohash":  # lane = ray kernel: features from arithmetic, no index math, no gathers
+        old = "hash_encode_pipelined<L16, LG>(a.g, px, py, pz, [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });"
+        assert src.count(old) == 1
+        return src.replace(old, "for (int l = 0; l < L16; ++l) swap32(px * (float)l, py + pz, bt0[l], bt1[l]);")
     if name == "coherent":
         return src.replace("            // ---- hash grid: 32 features",
                            "            px = __shfl(px, 0, 64); py = __shfl(py, 0, 64); pz = __shfl(pz, 0, 64);\n"
@@ -60,7 +61,7 @@ def variant(name: str, src: str) -> str:
                       "    float smin = INFINITY, smax = -INFINITY;\n    unsigned long long ts[8] = {0,0,0,0,0,0,0,0};\n", 1)
         k = k.replace("            const float st = en;\n", "            long long t0 = clock64();\n            const float st = en;\n", 1)
         k = k.replace("            f32x16 h1[2][2];\n", "            long long t1 = clock64(); ts[0] += t1 - t0;\n            f32x16 h1[2][2];\n", 1)
-        k = k.replace("            f32x16 g[2];\n", "            long long t2 = clock64(); ts[1] += t2 - t1;\n            f32x16 g[2];\n", 1)
+        k = k.replace("            float g[2][8];\n", "            long long t2 = clock64(); ts[1] += t2 - t1;\n            float g[2][8];\n", 1)
         k = k.replace("            float raw, unused;\n", "            long long t3 = clock64(); ts[2] += t3 - t2;\n            float raw, unused;\n", 1)
         k = k.replace("            {   // thermal: geo", "            long long t4 = clock64(); ts[3] += t4 - t3;\n            {   // thermal: geo", 1)
         k = k.replace("            cr = nan_to_num(cr); cg = nan_to_num(cg);", "            long long t5 = clock64(); ts[4] += t5 - t4;\n            cr = nan_to_num(cr); cg = nan_to_num(cg);", 1)
