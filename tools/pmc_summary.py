@@ -36,7 +36,12 @@ def head_stamp():
                                capture_output=True, text=True, check=True).stdout.strip()
         return head + (" (+ uncommitted changes under thermo_nerf_amd/ or bench.py)" if dirty else "")
     except Exception:
-        return "unknown"
+        # on the GPU box there is no .git: the build container writes `git rev-parse HEAD` into tools/.head_stamp before the
+        # gpurun call (tools/gpu_profile.sh header)
+        try:
+            return open(os.path.join(root, "tools", ".head_stamp")).read().strip()
+        except OSError:
+            return "unknown"
 
 
 def main():

@@ -1,12 +1,14 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the training step; run ON the GPU box:  gpurun -- 'bash tools/train_profile.sh <tag> [samples]'
+# rocprofv3 kernel trace of the training step, summarised on the GPU box:
+#   git rev-parse HEAD > tools/.head_stamp && gpurun -- 'bash tools/train_profile.sh <tag> [samples]'
 tag=${1:-train}
 S=${2:-48}
 repo=$(pwd)
 export TMPDIR=/tmp
-out=$repo/gpurun_out/${tag}_S${S}
-mkdir -p $out
+out=/tmp/prof_${tag}_S${S}
+rm -rf $out; mkdir -p $out $repo/gpurun_out
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python $repo/tools/train_bench.py --steps 36 --warmup 6 --samples $S > $out/trace.log 2>&1)
-tail -2 $out/trace.log
-find $out -name "*.json" -size +2M -delete 2>/dev/null
-ls $out/trace | head
+cd $repo
+python tools/prof_summary.py $out/trace gpurun_out/${tag}_kernel_trace_train_S${S}.txt \
+  "rocprofv3 --kernel-trace --stats -- python tools/train_bench.py --steps 36 --warmup 6 --samples $S (42 steps in the trace)" > /dev/null
+grep "ms/step" $out/trace.log
