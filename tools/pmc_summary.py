@@ -21,7 +21,7 @@ KEY = {"main_mfma_rays_kernel": "field_render", "main_h3_rays_kernel": "field_re
 
 def short(name):
     for k in KEEP:
-        if k + "(" in name:
+        if k + "(" in name or k + "<" in name:  # templated kernels print as name<args>(
             return k
     return None
 
