@@ -41,6 +41,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense, f32 i
 FIELD_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 63 * 64 + 64 * 64 + 64 * 3 + 15 * 64 + 64 * 64 + 64 * 1)  # 33 024
 PROP_FLOPS_PER_SAMPLE = 2 * (10 * 16 + 16)  # 352
 P0, P1 = 256, 96
+ATOMIC_PEAK_GTPS = 21.0  # measured on MI355X: scattered fp32 atomic adds, transactions (64-byte lines) per second (tools/micro/atomics.hip)
 REF_CHUNK = 1 << 16  # REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:30
 
 
@@ -213,6 +214,14 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
                         "mfma_view": {"achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tfl / MFMA_F32_PEAK_TFLOPS},
                         "kernel": "whole step (all launches between two optimizer steps)"}}
+    # what actually binds the step: the hash-table gradient scatter.  The memory side retires ~21 G atomic transactions per
+    # second, one per 64-byte line an instruction touches (tools/micro/atomics.hip).  Algorithmic transactions = samples x
+    # levels x 4 lines (the two x-neighbour corners of a (y, z) pair share a line); the proposal levels take gradient on one
+    # step in six after warm-up.
+    atom = (R * samples * 16 * 4 + R * (P0 + P1) * 5 * 4 / 6.0) / dt / 1e9
+    res["roofline"]["atomic_view"] = {"achieved": atom, "peak": ATOMIC_PEAK_GTPS, "unit": "G line-transactions/s",
+                                      "frac": atom / ATOMIC_PEAK_GTPS,
+                                      "note": "whole step time; the scatter kernel alone is priced in dominant_kernel"}
     prof = load_profile_json("train_kernels.json").get("S%d" % samples)
     if prof:
         res["roofline"]["dominant_kernel"] = prof
