@@ -147,11 +147,13 @@ int tn_field_heads_fwd(const tn_thermal_field *field, const float *directions, c
  * REF thermal_nerf_model.py:172-179,222-224,233)
  * ---------------------------------------------------------------------------------------------------- */
 
-/* UniformLinDispPiecewiseSampler: spacing bins [n+1] (= torch.linspace(0,1,n+1), host-computed, device
- * resident) (+ optional per-ray stratified jitter t_rand [R], NULL in eval) -> spacing_bins [R,n+1],
- * euclidean bins [R,n+1]. nears/fars [R]. */
+/* The proposal sampler's initial sampler [REF thermal_nerf_model.py:164-170]: UniformLinDispPiecewiseSampler
+ * (uniform_spacing == 0, the reference default) or UniformSampler (uniform_spacing == 1; spacing_fn and its inverse are the
+ * identity).  spacing bins [n+1] (= torch.linspace(0,1,n+1), host-computed, device resident) (+ optional per-ray
+ * stratified jitter t_rand [R], NULL in eval) -> spacing_bins [R,n+1], euclidean bins [R,n+1]. nears/fars [R]. */
 int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *nears, const float *fars,
-                      int64_t num_rays, int32_t n, float *spacing_bins, float *eucl_bins, void *stream);
+                      int64_t num_rays, int32_t n, int32_t uniform_spacing, float *spacing_bins, float *eucl_bins,
+                      void *stream);
 
 /* RaySamples.get_weights: deltas [R,n], densities [R,n] -> weights [R,n]. */
 int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays, int32_t n, float *weights,
@@ -159,10 +161,11 @@ int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays
 
 /* PDFSampler.generate_ray_samples (histogram_padding 0.01, eps 1e-5): weights [R,n_in] (already annealed),
  * existing spacing bins [R,n_in+1], u [n_out+1] (host-computed eval positions) or u_rand [R] jitter (training;
- * NULL in eval), nears/fars [R] -> spacing_bins [R,n_out+1], eucl_bins [R,n_out+1]. */
+ * NULL in eval), nears/fars [R] -> spacing_bins [R,n_out+1], eucl_bins [R,n_out+1].  uniform_spacing = the initial
+ * sampler's spacing function, which PDFSampler reuses for the new bins (see tn_sample_initial). */
 int tn_sample_pdf(const float *weights, const float *existing_bins, const float *u, const float *u_rand,
                   const float *nears, const float *fars, int64_t num_rays, int32_t n_in, int32_t n_out,
-                  float *spacing_bins, float *eucl_bins, void *stream);
+                  int32_t uniform_spacing, float *spacing_bins, float *eucl_bins, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Renderers
@@ -199,6 +202,9 @@ typedef struct tn_render_config {
      * to fill the chip; one ray per wave below), 1 = lane = ray (a caller that overlaps several calls on different
      * streams, like RayRenderEngine, fills the chip with fewer rays per call), 2 = one ray per wave. */
     int32_t kernel_family;
+    /* ProposalNetworkSampler's initial sampler [REF thermal_nerf_model.py:164-170]: 0 = UniformLinDispPiecewiseSampler
+     * ("piecewise", the default), 1 = UniformSampler ("uniform").  Every level's spacing -> euclidean map follows it. */
+    int32_t initial_sampler;
 } tn_render_config;
 
 typedef struct tn_render_inputs {

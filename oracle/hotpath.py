@@ -67,6 +67,7 @@ class OracleConfig:
     sh_grad: bool = False
     use_same_proposal_network: bool = False  # [REF thermal_nerf_model.py:127-139]: one network for every proposal level
     use_gradient_scaling: bool = False  # [REF :228-231]: NS scale_gradients_by_distance_squared on the field outputs
+    proposal_initial_sampler: str = "piecewise"  # [REF :164-170]: "uniform" -> NS UniformSampler
 
 
 # ----------------------------------------------------------------------------------------------
@@ -322,24 +323,31 @@ class Samples:
     spacing_ends: Tensor
     s_near: Tensor
     s_far: Tensor
+    uniform: bool = False  # NS UniformSampler: spacing_fn = spacing_fn_inv = identity
 
     @property
     def deltas(self) -> Tensor:
         return self.ends - self.starts
 
     def to_euclidean(self, x: Tensor) -> Tensor:
-        return spacing_fn_inv(x * self.s_far + (1 - x) * self.s_near)
+        u = x * self.s_far + (1 - x) * self.s_near
+        return u if self.uniform else spacing_fn_inv(u)
 
 
-def _samples_from_bins(bins: Tensor, s_near: Tensor, s_far: Tensor) -> Samples:
-    eucl = spacing_fn_inv(bins * s_far + (1 - bins) * s_near)
+def _samples_from_bins(bins: Tensor, s_near: Tensor, s_far: Tensor, uniform: bool = False) -> Samples:
+    eucl = bins * s_far + (1 - bins) * s_near
+    if not uniform:
+        eucl = spacing_fn_inv(eucl)
     n_rays = eucl.shape[0]
     sb = bins.expand(n_rays, -1)
-    return Samples(eucl[..., :-1, None], eucl[..., 1:, None], sb[..., :-1, None], sb[..., 1:, None], s_near, s_far)
+    return Samples(eucl[..., :-1, None], eucl[..., 1:, None], sb[..., :-1, None], sb[..., 1:, None], s_near, s_far,
+                   uniform)
 
 
-def sample_initial(nears: Tensor, fars: Tensor, num_samples: int, t_rand: Optional[Tensor]) -> Samples:
-    """NS UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (a4).
+def sample_initial(nears: Tensor, fars: Tensor, num_samples: int, t_rand: Optional[Tensor],
+                   uniform: bool = False) -> Samples:
+    """NS UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (a4); ``uniform`` = NS UniformSampler
+    (proposal_initial_sampler="uniform", REF thermal_nerf_model.py:164-170: identity spacing functions).
     ``t_rand`` [R,1] = the single-jitter random draw in training, None in eval."""
     bins = torch.linspace(0.0, 1.0, num_samples + 1)[None, ...]
     if t_rand is not None:
@@ -347,8 +355,8 @@ def sample_initial(nears: Tensor, fars: Tensor, num_samples: int, t_rand: Option
         upper = torch.cat([centers, bins[..., -1:]], -1)
         lower = torch.cat([bins[..., :1], centers], -1)
         bins = lower + (upper - lower) * t_rand
-    s_near, s_far = spacing_fn(nears), spacing_fn(fars)
-    return _samples_from_bins(bins, s_near, s_far)
+    s_near, s_far = (nears, fars) if uniform else (spacing_fn(nears), spacing_fn(fars))
+    return _samples_from_bins(bins, s_near, s_far, uniform)
 
 
 def pdf_u(num_bins: int) -> Tensor:
@@ -386,7 +394,7 @@ def sample_pdf(prev: Samples, weights: Tensor, num_samples: int, rand: Optional[
     t = torch.clip(torch.nan_to_num((u - cdf_g0) / (cdf_g1 - cdf_g0), 0), 0, 1)
     bins = bins_g0 + t * (bins_g1 - bins_g0)
     bins = bins.detach()  # NS PDFSampler: "Stop gradients" — sample positions never carry gradient
-    return _samples_from_bins(bins, prev.s_near, prev.s_far)
+    return _samples_from_bins(bins, prev.s_near, prev.s_far, prev.uniform)
 
 
 def get_weights(deltas: Tensor, densities: Tensor) -> Tensor:
@@ -486,7 +494,7 @@ def proposal_sampler(
         num = cfg.num_proposal_samples_per_ray[lvl] if is_prop else cfg.num_nerf_samples_per_ray
         jit = None if jitter is None else jitter[lvl]
         if lvl == 0:
-            s = sample_initial(nears, fars, num, jit)
+            s = sample_initial(nears, fars, num, jit, uniform=cfg.proposal_initial_sampler == "uniform")
         else:
             s = sample_pdf(s, torch.pow(weights, anneal), num, jit)
         if is_prop:

@@ -27,7 +27,7 @@ def oracle_config(cfg: ThermalNerfModelConfig) -> H.OracleConfig:
         use_average_appearance_embedding=cfg.use_average_appearance_embedding,
         disable_scene_contraction=cfg.disable_scene_contraction, sh_input=cfg.sh_input,
         sh_grad=cfg.sh_direction_gradient, use_same_proposal_network=cfg.use_same_proposal_network,
-        use_gradient_scaling=cfg.use_gradient_scaling,
+        use_gradient_scaling=cfg.use_gradient_scaling, proposal_initial_sampler=cfg.proposal_initial_sampler,
     )
 
 

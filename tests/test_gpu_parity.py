@@ -14,7 +14,7 @@ from tests import helpers
 from thermo_nerf_amd import (FieldHeadNames, FieldHeadNamesT, Frustums, RayBundle, RaySamples, ThermalRenderer,
                              synthetic)
 from thermo_nerf_amd.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
-from thermo_nerf_amd.samplers import PDFSampler, UniformLinDispPiecewiseSampler
+from thermo_nerf_amd.samplers import PDFSampler, UniformLinDispPiecewiseSampler, UniformSampler
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +75,46 @@ def test_sample_initial(near, n):
     rs = s(rb, num_samples=n, t_rand=t.to(DEV))
     assert_close(rs.frustums.ends, want.ends, 0, 5e-7, "ends(train)")
     assert_close(rs.spacing_ends, want.spacing_ends, 1e-7, 0, "spacing(train)")
+
+
+@pytest.mark.parametrize("near,far", [(0.0, 1000.0), (0.05, 6.0)])
+@pytest.mark.parametrize("n", [256, 7])
+def test_uniform_sampler_and_its_pdf_resampling(near, far, n):
+    """NS UniformSampler (proposal_initial_sampler="uniform", REF thermal_nerf_model.py:164-170): identity spacing functions,
+    which the PDFSampler that follows inherits for its own bins."""
+    R = 37
+    o, d = helpers.rays(8, 8)
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
+    rb = bundle(o[:R], d[:R])
+    rb.nears, rb.fars = nears.to(DEV), fars.to(DEV)
+    s = UniformSampler(single_jitter=True).eval()
+    want = H.sample_initial(nears, fars, n, None, uniform=True)
+    rs = s(rb, num_samples=n)
+    assert rs.uniform_spacing
+    assert_close(rs.frustums.starts, want.starts, 0, 2e-7, "starts")
+    assert_close(rs.frustums.ends, want.ends, 0, 2e-7, "ends")
+    assert_close(rs.spacing_starts, want.spacing_starts, 0, 0, "spacing")
+    # bins are linear in distance: equal widths
+    widths = (rs.frustums.ends - rs.frustums.starts)[..., 0]
+    assert (widths - (far - near) / n).abs().max().item() <= 2e-6 * far
+    t = torch.rand(R, 1, generator=torch.Generator().manual_seed(5))
+    want_t = H.sample_initial(nears, fars, n, t, uniform=True)
+    rs_t = s.train()(rb, num_samples=n, t_rand=t.to(DEV))
+    assert_close(rs_t.frustums.ends, want_t.ends, 0, 5e-7, "ends(train)")
+    # PDF resampling on top of it
+    g = torch.Generator().manual_seed(n)
+    w = torch.rand(R, n, 1, generator=g) ** 6
+    w[0] = 0.0
+    n_out = 96
+    want_p = H.sample_pdf(want, w, n_out, None)
+    rs_p = PDFSampler(single_jitter=True).eval()(rb, rs, w.to(DEV), num_samples=n_out)
+    assert rs_p.uniform_spacing
+    assert_close(rs_p.spacing_starts, want_p.spacing_starts, 5e-6, 0, "pdf spacing")
+    assert_close(rs_p.frustums.ends, want_p.ends, 1e-6 + 5e-6 * (far - near), 0, "pdf ends")  # distance = linear in spacing
+    u = torch.rand(R, 1, generator=g)
+    want_p = H.sample_pdf(want, w, n_out, u)
+    rs_p = PDFSampler(single_jitter=True).train()(rb, rs, w.to(DEV), num_samples=n_out, u_rand=u.to(DEV))
+    assert_close(rs_p.frustums.ends, want_p.ends, 1e-6 + 5e-6 * (far - near), 0, "pdf ends(train)")
 
 
 @pytest.mark.parametrize("n", [48, 64, 192, 256, 5])
@@ -584,6 +624,33 @@ def test_same_proposal_network(form):
     with torch.no_grad():
         got = gm(bundle(o, d))
     check_outputs(got, want, f"same proposal network, {form}")
+
+
+@pytest.mark.parametrize("far", [1000.0, 6.0])
+@pytest.mark.parametrize("form", ["fused", "fused_scalar", "modular", "fused_ray_per_wave", "fused_f16x3"])
+def test_uniform_initial_sampler(form, far):
+    """proposal_initial_sampler="uniform" [REF thermal_nerf_model.py:164-170]: every level's spacing -> distance map is
+    linear.  far=6: a far plane a scene sampled uniformly would actually use; far=1000: the reference default plane."""
+    gm, sd, ocfg = gpu_model("scene", 48, family="ray_per_wave" if form == "fused_ray_per_wave" else "lane_ray",
+                             proposal_initial_sampler="uniform", far_plane=far)
+    assert isinstance(gm.proposal_sampler.initial_sampler, UniformSampler)
+    gm.config.fused = form != "modular"
+    gm.config.use_mfma = form != "fused_scalar"
+    gm.config.mlp_precision = "f16x3" if form == "fused_f16x3" else "f32"
+    o, d = helpers.rays(13, 11, view=5)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    if form == "fused_f16x3":
+        for k in ("rgb", "thermal"):
+            assert (got[k].cpu() - want[k]).abs().max().item() <= 2e-4, k
+    else:
+        check_outputs(got, want, f"uniform initial sampler, {form}, far {far}")
+    # and it is a different sampling from the piecewise default
+    gp, sdp, ocfgp = gpu_model("scene", 48, far_plane=far)
+    with torch.no_grad():
+        other = gp(bundle(o, d))
+    assert (other["depth"] - got["depth"]).abs().max().item() > 1e-3
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])

@@ -272,18 +272,21 @@ def _gpu_step(gm, o, d, jit, cam, batch):
 ONE_NET = {"one_proposal_network": True}  # helpers.build: use_same_proposal_network + a one-entry proposal_net_args_list
 
 
-@pytest.mark.parametrize("variant", ["default", "stage_forward", "gradient_scaling", "same_proposal_network"])
+@pytest.mark.parametrize("variant", ["default", "stage_forward", "gradient_scaling", "same_proposal_network",
+                                     "uniform_initial_sampler"])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 @pytest.mark.parametrize("S", [48, 64, 192])  # 192 = BASELINE config 3 (multi-chunk scans in every per-ray kernel)
 def test_training_step_matches_autograd_oracle(kind, S, variant):
-    """variant: the reference's config switches on this path — use_gradient_scaling [REF thermal_nerf_model.py:228-231] and
-    use_same_proposal_network [REF :122-139] — next to the default configuration."""
+    """variant: the reference's config switches on this path — use_gradient_scaling [REF thermal_nerf_model.py:228-231],
+    use_same_proposal_network [REF :122-139] and proposal_initial_sampler="uniform" [REF :164-170] — next to the default
+    configuration."""
     if variant not in ("default", "stage_forward") and S != 48:
         pytest.skip("config variants are checked at the reference's default sample count")
     # default = the final level's forward as one fused MFMA kernel (tn_field_fwd_taped) and each MLP's backward as one launch
     # (tn_linear_chain_bwd); stage_forward = one launch per nerfstudio module / layer in both directions
     over = {"gradient_scaling": {"use_gradient_scaling": True}, "same_proposal_network": ONE_NET,
-            "stage_forward": {"fused_train_forward": False, "fused_train_backward": False}}.get(variant, {})
+            "stage_forward": {"fused_train_forward": False, "fused_train_backward": False},
+            "uniform_initial_sampler": {"proposal_initial_sampler": "uniform", "far_plane": 6.0}}.get(variant, {})
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, **over)
     if variant == "same_proposal_network":
         assert len(gm.proposal_networks) == 1

@@ -106,3 +106,23 @@ def test_anneal_schedule():
     assert abs(model.proposal_sampler._anneal - 10 * 0.5 / (9 * 0.5 + 1)) < 1e-12
     model.set_step(5000)
     assert model.proposal_sampler._anneal == 1.0
+
+
+def test_oracle_uniform_initial_sampler_is_linear_in_distance():
+    """NS UniformSampler [REF thermal_nerf_model.py:164-170 -> proposal_initial_sampler="uniform"]: identity spacing
+    functions, so bin edges are a linspace between near and far, and PDF resampling keeps that map."""
+    import torch
+
+    from oracle import hotpath as H
+
+    nears, fars = torch.full((3, 1), 0.05), torch.full((3, 1), 6.0)
+    s = H.sample_initial(nears, fars, 8, None, uniform=True)
+    edges = torch.cat([s.starts[..., 0], s.ends[:, -1:, 0]], -1)
+    assert torch.allclose(edges, torch.linspace(0.05, 6.0, 9).expand(3, -1), atol=1e-6)
+    p = H.sample_pdf(s, torch.zeros(3, 8, 1), 4, None)  # zero weights -> the histogram padding resamples uniformly
+    assert p.uniform
+    mids = (p.starts + p.ends)[..., 0] / 2
+    assert torch.all(mids[:, 1:] > mids[:, :-1]) and float(p.ends.max()) <= 6.0 + 1e-5
+    # the piecewise default is NOT linear: half of the spacing range covers [0, 1]
+    q = H.sample_initial(torch.zeros(1, 1), torch.full((1, 1), 1000.0), 8, None)
+    assert abs(float(q.ends[0, 3, 0]) - 1.0) < 2e-3

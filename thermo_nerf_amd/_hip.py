@@ -106,6 +106,7 @@ class tn_render_config(C.Structure):
         ("pdf_anneal", C.c_float),
         ("early_stop_transmittance", C.c_float),
         ("kernel_family", C.c_int32),
+        ("initial_sampler", C.c_int32),
     ]
 
 
@@ -147,9 +148,9 @@ SIGNATURES = {
     "tn_density_fwd": (C.c_int, [C.POINTER(tn_density_field), _vp, _i64, _vp, _vp]),
     "tn_field_density_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _i64, _vp, _vp, _vp]),
     "tn_field_heads_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
-    "tn_sample_initial": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_sample_initial": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "tn_weights_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
-    "tn_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "tn_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "tn_composite_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "tn_depth_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tn_render_workspace_bytes": (_sz, [C.POINTER(tn_render_config), _i64]),

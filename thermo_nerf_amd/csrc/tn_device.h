@@ -52,16 +52,23 @@ __device__ __forceinline__ float t_exp(float x) {
     return expf(x);
 }
 
-// ---- NS UniformLinDispPiecewiseSampler spacing functions ---------------------------------
-__device__ __forceinline__ float spacing_fn(float x) { return x < 1.0f ? x / 2.0f : sub_rn(1.0f, 1.0f / mul_rn(2.0f, x)); }
+// ---- NS SpacedSampler spacing functions ---------------------------------------------------
+// lin == false: UniformLinDispPiecewiseSampler (the "piecewise" proposal_initial_sampler, the reference default);
+// lin == true:  UniformSampler (proposal_initial_sampler="uniform", REF thermal_nerf_model.py:164-170): both functions are
+//               the identity, so edges map linearly between near and far.  The choice is made once per call and carried by
+//               every level (PDFSampler reuses the initial sampler's spacing_to_euclidean_fn).
+__device__ __forceinline__ float spacing_fn(float x, bool lin = false) {
+    return lin ? x : (x < 1.0f ? x / 2.0f : sub_rn(1.0f, 1.0f / mul_rn(2.0f, x)));
+}
 template <bool FAST = false>
 __device__ __forceinline__ float spacing_fn_inv(float x) {
     return x < 0.5f ? mul_rn(2.0f, x) : t_rcp<FAST>(sub_rn(2.0f, mul_rn(2.0f, x)));
 }
 // spacing_to_euclidean_fn(x) = s_inv(x * s_far + (1 - x) * s_near)
 template <bool FAST = false>
-__device__ __forceinline__ float spacing_to_eucl(float x, float s_near, float s_far) {
-    return spacing_fn_inv<FAST>(add_rn(mul_rn(x, s_far), mul_rn(sub_rn(1.0f, x), s_near)));
+__device__ __forceinline__ float spacing_to_eucl(float x, float s_near, float s_far, bool lin = false) {
+    const float u = add_rn(mul_rn(x, s_far), mul_rn(sub_rn(1.0f, x), s_near));
+    return lin ? u : spacing_fn_inv<FAST>(u);
 }
 
 // ---- NS Frustums.get_positions: o + d * (s + e) / 2 ---------------------------------------------------

@@ -48,6 +48,7 @@ struct PropArgs {
     const float *wk;  // [2][kPropWFloats] k-major copies of the two proposal MLPs (workspace), scalar-operand evaluation
     long long R;
     int P0, P1, S, training;
+    int lin;                 // initial sampler: 0 piecewise (UniformLinDispPiecewise), 1 UniformSampler
     float anneal;
     float *ws_spacing;       // final spacing bins, ray-tiled (tn_ws_bin), always written
     float *out_spacing[3];   // optional
@@ -58,14 +59,14 @@ struct PropArgs {
 
 // one proposal level for one ray (one wave): density -> weights (left in wts[]) -> median depth
 __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLds &w, float ox, float oy, float oz,
-                                            float dx, float dy, float dz, float s_near, float s_far, const float *bins,
-                                            int n, float *wts, int lane) {
+                                            float dx, float dy, float dz, float s_near, float s_far, bool lin,
+                                            const float *bins, int n, float *wts, int lane) {
     const Space sp = make_space(net.space);
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         if (i < n) {
-            const float st = spacing_to_eucl<true>(bins[i], s_near, s_far);
-            const float en = spacing_to_eucl<true>(bins[i + 1], s_near, s_far);
+            const float st = spacing_to_eucl<true>(bins[i], s_near, s_far, lin);
+            const float en = spacing_to_eucl<true>(bins[i + 1], s_near, s_far, lin);
             float px, py, pz;
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
@@ -94,8 +95,8 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
         if (ok) wts[i] = wi;
     }
     const int idx = min(med_idx, n - 1);
-    const float st = spacing_to_eucl<true>(bins[idx], s_near, s_far);
-    const float en = spacing_to_eucl<true>(bins[idx + 1], s_near, s_far);
+    const float st = spacing_to_eucl<true>(bins[idx], s_near, s_far, lin);
+    const float en = spacing_to_eucl<true>(bins[idx + 1], s_near, s_far, lin);
     return add_rn(st, en) / 2.0f;
 }
 
@@ -150,12 +151,12 @@ __device__ __forceinline__ void pdf_resample(const float *wts, const float *bins
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void store_bins(const float *bins, int nb, float s_near, float s_far, float *spacing,
+__device__ __forceinline__ void store_bins(const float *bins, int nb, float s_near, float s_far, bool lin, float *spacing,
                                            float *eucl, long long r, int lane) {
     if (spacing)
         for (int j = lane; j < nb; j += 64) spacing[r * nb + j] = bins[j];
     if (eucl)
-        for (int j = lane; j < nb; j += 64) eucl[r * nb + j] = spacing_to_eucl<true>(bins[j], s_near, s_far);
+        for (int j = lane; j < nb; j += 64) eucl[r * nb + j] = spacing_to_eucl<true>(bins[j], s_near, s_far, lin);
 }
 
 __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, int nbmax) {
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
     const TwoLayerLds w1 = stage_two_layer<PH>(wbase1, a.net[1].w0, a.net[1].b0, a.net[1].w1, a.net[1].b1, in1, 1);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool lin = a.lin != 0;
     float *binsA = per_wave + (size_t)wave * (3 * nbmax + nmax);
     float *binsB = binsA + nbmax;
     float *cdf = binsB + nbmax;
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
     for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
-        const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
+        const float s_near = spacing_fn(a.nears[r], lin), s_far = spacing_fn(a.fars[r], lin);
         // level 0 bins: linspace (+ single stratified jitter in training), SURVEY A.7
         const int P0 = a.P0, P1 = a.P1, S = a.S;
         for (int j = lane; j <= P0; j += 64) {
@@ -192,18 +194,18 @@ __global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        store_bins(binsA, P0 + 1, s_near, s_far, a.out_spacing[0], a.out_eucl[0], r, lane);
-        const float med0 = prop_level(a.net[0], w0, ox, oy, oz, dx, dy, dz, s_near, s_far, binsA, P0, wts, lane);
+        store_bins(binsA, P0 + 1, s_near, s_far, lin, a.out_spacing[0], a.out_eucl[0], r, lane);
+        const float med0 = prop_level(a.net[0], w0, ox, oy, oz, dx, dy, dz, s_near, s_far, lin, binsA, P0, wts, lane);
         if (a.out_w[0]) for (int i = lane; i < P0; i += 64) a.out_w[0][r * P0 + i] = wts[i];
         pdf_resample(wts, binsA, P0, cdf, a.u1, a.jitter != nullptr, a.jitter ? a.jitter[a.R + r] : 0.0f, a.anneal, P1,
                      binsB, lane);
-        store_bins(binsB, P1 + 1, s_near, s_far, a.out_spacing[1], a.out_eucl[1], r, lane);
-        const float med1 = prop_level(a.net[1], w1, ox, oy, oz, dx, dy, dz, s_near, s_far, binsB, P1, wts, lane);
+        store_bins(binsB, P1 + 1, s_near, s_far, lin, a.out_spacing[1], a.out_eucl[1], r, lane);
+        const float med1 = prop_level(a.net[1], w1, ox, oy, oz, dx, dy, dz, s_near, s_far, lin, binsB, P1, wts, lane);
         if (a.out_w[1]) for (int i = lane; i < P1; i += 64) a.out_w[1][r * P1 + i] = wts[i];
         pdf_resample(wts, binsB, P1, cdf, a.u2, a.jitter != nullptr, a.jitter ? a.jitter[2 * a.R + r] : 0.0f, a.anneal,
                      S, binsA, lane);
         for (int j = lane; j <= S; j += 64) a.ws_spacing[tn_ws_bin(r, j, S)] = binsA[j];
-        store_bins(binsA, S + 1, s_near, s_far, nullptr, a.out_eucl[2], r, lane);
+        store_bins(binsA, S + 1, s_near, s_far, lin, nullptr, a.out_eucl[2], r, lane);
         if (a.out_spacing[2]) for (int j = lane; j <= S; j += 64) a.out_spacing[2][r * (S + 1) + j] = binsA[j];
         if (lane == 0) {
             if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
@@ -349,6 +351,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
     const Space sp0 = make_space(a.net[0].space), sp1 = make_space(a.net[1].space);
     const bool fast0 = a.net[0].g.num_levels == 5, fast1 = a.net[1].g.num_levels == 5;
     const bool jittered = a.jitter != nullptr;
+    const bool lin = a.lin != 0;
     const long long tiles = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
     for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += stride) {
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
         const long long rc = live ? r : a.R - 1;
         const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
         const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
-        const float s_near = spacing_fn(a.nears[rc]), s_far = spacing_fn(a.fars[rc]);
+        const float s_near = spacing_fn(a.nears[rc], lin), s_far = spacing_fn(a.fars[rc], lin);
         float *wsc = ra.w_scratch + (size_t)tile * ra.nmax * 64 + lane;       // w[i] at wsc[i*64]
         float *b1sc = ra.b1_scratch + (size_t)tile * (P1 + 1) * 64 + lane;   // edge j at b1sc[j*64]
         float *fin = a.ws_spacing + tn_ws_bin(tile * 64, 0, S) + lane;       // final edge j at fin[j*64]
@@ -378,13 +381,13 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
             float accum = 0.0f, cum_w = 0.0f, step = 0.0f;
             bool found = false;
             float sb = edge0(0);
-            float en = spacing_to_eucl<true>(sb, s_near, s_far);
+            float en = spacing_to_eucl<true>(sb, s_near, s_far, lin);
             if (live && a.out_spacing[0]) a.out_spacing[0][r * (P0 + 1)] = sb;
             if (live && a.out_eucl[0]) a.out_eucl[0][r * (P0 + 1)] = en;
             for (int i = 0; i < P0; ++i) {
                 const float st = en;
                 sb = edge0(i + 1);
-                en = spacing_to_eucl<true>(sb, s_near, s_far);
+                en = spacing_to_eucl<true>(sb, s_near, s_far, lin);
                 step = add_rn(st, en) / 2.0f;
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp0, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
@@ -417,13 +420,13 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
             float accum = 0.0f, cum_w = 0.0f, step = 0.0f;
             bool found = false;
             float sb = b1sc[0];
-            float en = spacing_to_eucl<true>(sb, s_near, s_far);
+            float en = spacing_to_eucl<true>(sb, s_near, s_far, lin);
             if (live && a.out_spacing[1]) a.out_spacing[1][r * (P1 + 1)] = sb;
             if (live && a.out_eucl[1]) a.out_eucl[1][r * (P1 + 1)] = en;
             for (int i = 0; i < P1; ++i) {
                 const float st = en;
                 sb = b1sc[(size_t)(i + 1) * 64];
-                en = spacing_to_eucl<true>(sb, s_near, s_far);
+                en = spacing_to_eucl<true>(sb, s_near, s_far, lin);
                 step = add_rn(st, en) / 2.0f;
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp1, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
@@ -453,7 +456,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                  [&](int j, float v) {
                      fin[(size_t)j * 64] = v;
                      if (live && a.out_spacing[2]) a.out_spacing[2][r * (S + 1) + j] = v;
-                     if (live && a.out_eucl[2]) a.out_eucl[2][r * (S + 1) + j] = spacing_to_eucl<true>(v, s_near, s_far);
+                     if (live && a.out_eucl[2]) a.out_eucl[2][r * (S + 1) + j] = spacing_to_eucl<true>(v, s_near, s_far, lin);
                  });
         if (live) {
             if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
@@ -475,7 +478,7 @@ struct MainArgs {
     const int *cam;
     const float *spacing;  // [R,S+1]
     long long R;
-    int S, training;
+    int S, training, lin;
     float *rgb, *acc, *depth, *expected, *thermal;
     float *out_w;  // optional [R,S]
     unsigned *minmax;
@@ -499,13 +502,14 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
     __syncthreads();
     const Space sp = make_space(a.space);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool lin = a.lin != 0;
     const int S = a.S, A = a.heads.app_dim;
     const long long stride = (long long)gridDim.x * kWaves;
     float smin = INFINITY, smax = -INFINITY;  // running over every ray this wave renders
     for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
-        const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
+        const float s_near = spacing_fn(a.nears[r], lin), s_far = spacing_fn(a.fars[r], lin);
         const float *app = a.training ? (a.heads.appearance + (long long)a.cam[r] * A) : wh.APP;
         const WsBins sb{a.spacing + tn_ws_bin(r, 0, S)};  // ray-tiled workspace layout
         float carry = 0.0f, carry_w = 0.0f;
@@ -517,8 +521,8 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
             const bool ok = i < S;
             float dd = 0.0f, step = 0.0f, c[3] = {0.0f, 0.0f, 0.0f}, th = 0.0f;
             if (ok) {
-                const float st = spacing_to_eucl(sb[i], s_near, s_far);
-                const float en = spacing_to_eucl(sb[i + 1], s_near, s_far);
+                const float st = spacing_to_eucl(sb[i], s_near, s_far, lin);
+                const float en = spacing_to_eucl(sb[i + 1], s_near, s_far, lin);
                 step = add_rn(st, en) / 2.0f;
                 float px, py, pz;
                 const float sel = normalize_position(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
             a.rgb[r * 3 + 0] = cr; a.rgb[r * 3 + 1] = cg; a.rgb[r * 3 + 2] = cb;
             a.thermal[r] = ct;
             a.acc[r] = wsum;
-            const float st = spacing_to_eucl(sb[idx], s_near, s_far), en = spacing_to_eucl(sb[idx + 1], s_near, s_far);
+            const float st = spacing_to_eucl(sb[idx], s_near, s_far, lin), en = spacing_to_eucl(sb[idx + 1], s_near, s_far, lin);
             a.depth[r] = add_rn(st, en) / 2.0f;
             a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
         }
@@ -641,6 +645,7 @@ static int check_render_common(const tn_render_config *cfg, int64_t num_rays, vo
     if (!cfg || !workspace) return TN_ERR_NULL;
     const int P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1], S = cfg->num_nerf_samples;
     if (P0 < 1 || P1 < 1 || S < 1 || P0 > 1024 || P1 > 1024 || S > 1024 || num_rays < 0) return TN_ERR_SHAPE;
+    if (cfg->initial_sampler != 0 && cfg->initial_sampler != 1) return TN_ERR_UNSUPPORTED;
     if (workspace_bytes < tn_render_workspace_bytes(cfg, num_rays)) return TN_ERR_WORKSPACE;
     return TN_OK;
 }
@@ -670,6 +675,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
     pa.lin0 = in->lin_bins0; pa.u1 = in->u1; pa.u2 = in->u2;
     pa.jitter = cfg->training ? in->jitter : nullptr;
     pa.R = num_rays; pa.P0 = P0; pa.P1 = P1; pa.S = S; pa.training = cfg->training; pa.anneal = cfg->pdf_anneal;
+    pa.lin = cfg->initial_sampler == 1;
     pa.ws_spacing = reinterpret_cast<float *>(workspace);
     for (int i = 0; i < 3; ++i) { pa.out_spacing[i] = out->spacing_bins[i]; pa.out_eucl[i] = out->eucl_bins[i]; }
     pa.out_w[0] = out->weights[0]; pa.out_w[1] = out->weights[1];
@@ -748,7 +754,7 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
         ma.origins = in->origins; ma.dirs = in->directions; ma.nears = in->nears; ma.fars = in->fars;
         ma.cam = in->camera_indices;
         ma.spacing = ws_spacing;
-        ma.R = num_rays; ma.S = S; ma.training = cfg->training;
+        ma.R = num_rays; ma.S = S; ma.training = cfg->training; ma.lin = cfg->initial_sampler == 1;
         ma.rgb = out->rgb; ma.acc = out->accumulation; ma.depth = out->depth; ma.expected = out->expected_depth;
         ma.thermal = out->thermal; ma.out_w = out->weights[2]; ma.minmax = minmax;
         const size_t main_smem = (size_t)(two_layer_floats(2 * field->grid.num_levels, HW, 1 + GF) +

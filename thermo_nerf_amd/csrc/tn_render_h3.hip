@@ -260,7 +260,7 @@ struct H3Args {
     const float *origins, *dirs, *nears, *fars;
     const float *spacing;
     long long R;
-    int S;
+    int S, lin;
     float *rgb, *acc, *depth, *expected, *thermal;
     unsigned *minmax;
     float early_eps;  // 0 = never stop early
@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
     __syncthreads();
     const Space sp = make_space(a.space);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const bool lin = a.lin != 0;
     const int S = a.S;
     const long long groups = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
         const long long rc = live ? r : a.R - 1;
         const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
         const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
-        const float s_near = spacing_fn(a.nears[rc]), s_far = spacing_fn(a.fars[rc]);
+        const float s_near = spacing_fn(a.nears[rc], lin), s_far = spacing_fn(a.fars[rc], lin);
         const float *tb = a.spacing + tn_ws_bin(grp * 64, 0, S) + (rc - grp * 64);
         HL sh0, sh1;  // SH(dir) of this lane's ray as the K=16 step of the colour layer (constant over samples)
         {
@@ -298,14 +299,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             sh16(sx, sy, sz, c);
             pack_step(c, sh0, sh1);
         }
-        float en = spacing_to_eucl<true>(tb[0], s_near, s_far);
+        float en = spacing_to_eucl<true>(tb[0], s_near, s_far, lin);
         float accum = 0.0f, cum_w = 0.0f;
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
         bool med_found = false;
         for (int i = 0; i < S; ++i) {
             const float st = en;
-            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far);
+            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far, lin);
             step = add_rn(st, en) / 2.0f;
             float px, py, pz;
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
@@ -425,8 +426,8 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             // early ray termination (eval, opt-in): wave-wide vote on the transmittance left after this sample
             if (a.early_eps > 0.0f && i + 1 < S && __all(__expf(-accum) < a.early_eps)) {
                 // keep the call-global depth bounds exact: they only miss the last mid-point
-                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far);
-                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far);
+                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far, lin);
+                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far, lin);
                 smax = fmaxf(smax, add_rn(e0, e1) / 2.0f);
                 break;
             }
@@ -475,7 +476,7 @@ int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, c
     a.sh_shifted = field->sh_shifted;
     a.origins = in->origins; a.dirs = in->directions; a.nears = in->nears; a.fars = in->fars;
     a.spacing = spacing_ws;
-    a.R = num_rays; a.S = cfg->num_nerf_samples;
+    a.R = num_rays; a.S = cfg->num_nerf_samples; a.lin = cfg->initial_sampler == 1;
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.minmax = minmax;
     a.early_eps = fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);

@@ -147,7 +147,7 @@ struct MfmaArgs {
     const int *cam;
     const float *spacing;  // [R,S+1]
     long long R;
-    int S, training;
+    int S, training, lin;
     float *rgb, *acc, *depth, *expected, *thermal;
     float *out_w;
     unsigned *minmax;
@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
     const float *A = lds + OFF_A;
     const Space sp = make_space(a.space);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const bool lin = a.lin != 0;
     float *scratch = lds + OFF_SCRATCH + wave * 64;
     const int S = a.S;
     const long long stride = (long long)gridDim.x * kWaves;
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
     for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
-        const float s_near = spacing_fn(a.nears[r]), s_far = spacing_fn(a.fars[r]);
+        const float s_near = spacing_fn(a.nears[r], lin), s_far = spacing_fn(a.fars[r], lin);
         const WsBins sb{a.spacing + tn_ws_bin(r, 0, S)};  // ray-tiled workspace layout
         {   // per-ray colour-layer bias: b + W_sh . SH(dir) (+ W_app . embedding[cam] in training); lane = feature
             float sx = dx, sy = dy, sz = dz;
@@ -346,8 +347,8 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             const int i = base + lane;
             const bool ok = i < S;
             const int ic = ok ? i : S - 1;  // idle lanes re-evaluate the last sample (masked out below)
-            const float st = spacing_to_eucl<true>(sb[ic], s_near, s_far);
-            const float en = spacing_to_eucl<true>(sb[ic + 1], s_near, s_far);
+            const float st = spacing_to_eucl<true>(sb[ic], s_near, s_far, lin);
+            const float en = spacing_to_eucl<true>(sb[ic + 1], s_near, s_far, lin);
             const float step = add_rn(st, en) / 2.0f;
             float px, py, pz;
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             a.rgb[r * 3 + 0] = c0; a.rgb[r * 3 + 1] = c1; a.rgb[r * 3 + 2] = c2;
             a.thermal[r] = ct;
             a.acc[r] = wsum;
-            const float st = spacing_to_eucl<true>(sb[idx], s_near, s_far), en = spacing_to_eucl<true>(sb[idx + 1], s_near, s_far);
+            const float st = spacing_to_eucl<true>(sb[idx], s_near, s_far, lin), en = spacing_to_eucl<true>(sb[idx + 1], s_near, s_far, lin);
             a.depth[r] = add_rn(st, en) / 2.0f;
             a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
         }
@@ -524,6 +525,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
     const float *A = lds + OFF_A;
     const Space sp = make_space(a.space);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const bool lin = a.lin != 0;
     const int S = a.S;
     const long long groups = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
@@ -534,7 +536,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
         const long long rc = live ? r : a.R - 1;  // idle lanes shadow the last ray (stores masked)
         const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
         const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
-        const float s_near = spacing_fn(a.nears[rc]), s_far = spacing_fn(a.fars[rc]);
+        const float s_near = spacing_fn(a.nears[rc], lin), s_far = spacing_fn(a.fars[rc], lin);
         const float *tb = a.spacing + tn_ws_bin(grp * 64, 0, S) + (rc - grp * 64);  // edge j at tb[j*64]
         // SH(dir) of this lane's ray -> B operands of the 8 SH k-steps (constant over the sample loop)
         float bs0[8], bs1[8];
@@ -548,14 +550,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) swap32(c[2 * s], c[2 * s + 1], bs0[s], bs1[s]);
         }
-        float en = spacing_to_eucl<true>(tb[0], s_near, s_far);
+        float en = spacing_to_eucl<true>(tb[0], s_near, s_far, lin);
         float accum = 0.0f, cum_w = 0.0f;  // sum of delta*sigma before this sample; running sum of weights
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
         bool med_found = false;
         for (int i = 0; i < S; ++i) {
             const float st = en;
-            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far);
+            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far, lin);
             step = add_rn(st, en) / 2.0f;
             float px, py, pz;
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
@@ -642,8 +644,8 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             // early ray termination (eval, opt-in): wave-wide vote on the transmittance left after this sample
             if (a.early_eps > 0.0f && i + 1 < S && __all(__expf(-accum) < a.early_eps)) {
                 // keep the call-global depth bounds exact: they only miss the last mid-point
-                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far);
-                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far);
+                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far, lin);
+                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far, lin);
                 smax = fmaxf(smax, add_rn(e0, e1) / 2.0f);
                 break;
             }
@@ -896,7 +898,7 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     a.origins = in->origins; a.dirs = in->directions; a.nears = in->nears; a.fars = in->fars;
     a.cam = in->camera_indices;
     a.spacing = spacing_ws;
-    a.R = num_rays; a.S = cfg->num_nerf_samples; a.training = cfg->training;
+    a.R = num_rays; a.S = cfg->num_nerf_samples; a.training = cfg->training; a.lin = cfg->initial_sampler == 1;
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.out_w = out->weights[2]; a.minmax = minmax;
     a.early_eps = cfg->training ? 0.0f : fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);

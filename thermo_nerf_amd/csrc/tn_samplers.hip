@@ -1,7 +1,7 @@
 // Samplers, weights and renderers of the plugin surface (one wave64 per ray; rays are independent).
 //
 //   tn_frustum_positions  NS Frustums.get_positions
-//   tn_sample_initial     NS UniformLinDispPiecewiseSampler           
+//   tn_sample_initial     NS UniformLinDispPiecewiseSampler | UniformSampler
 //   tn_weights_fwd        NS RaySamples.get_weights                   (a6)  [REF thermal_nerf_model.py:233]
 //   tn_sample_pdf         NS PDFSampler.generate_ray_samples          (a11)
 //   tn_composite_fwd      ThermalRenderer / RGBRenderer(last_sample)  (a12,a13) [REF thermal_renderer.py:27-80,113-149]
@@ -32,7 +32,7 @@ __global__ void frustum_positions_kernel(const float *__restrict__ o, const floa
 
 __global__ void sample_initial_kernel(const float *__restrict__ lin_bins, const float *__restrict__ t_rand,
                                       const float *__restrict__ nears, const float *__restrict__ fars,
-                                      long long num_rays, int n, float *__restrict__ spacing,
+                                      long long num_rays, int n, bool lin, float *__restrict__ spacing,
                                       float *__restrict__ eucl) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = n + 1;
@@ -46,9 +46,9 @@ __global__ void sample_initial_kernel(const float *__restrict__ lin_bins, const 
         const float hi = (j == n) ? lin_bins[n] : add_rn(lin_bins[j + 1], lin_bins[j]) / 2.0f;
         b = add_rn(lo, mul_rn(sub_rn(hi, lo), t_rand[r]));
     }
-    const float sn = spacing_fn(nears[r]), sf = spacing_fn(fars[r]);
+    const float sn = spacing_fn(nears[r], lin), sf = spacing_fn(fars[r], lin);
     spacing[i] = b;
-    eucl[i] = spacing_to_eucl(b, sn, sf);
+    eucl[i] = spacing_to_eucl(b, sn, sf, lin);
 }
 
 // weights = nan_to_num((1 - exp(-d*sigma)) * exp(-exclusive_cumsum(d*sigma)))
@@ -77,7 +77,7 @@ __global__ void weights_kernel(const float *__restrict__ deltas, const float *__
 __global__ void sample_pdf_kernel(const float *__restrict__ weights, const float *__restrict__ existing,
                                   const float *__restrict__ u, const float *__restrict__ u_rand,
                                   const float *__restrict__ nears, const float *__restrict__ fars,
-                                  long long num_rays, int n_in, int n_out, float *__restrict__ spacing,
+                                  long long num_rays, int n_in, int n_out, bool lin, float *__restrict__ spacing,
                                   float *__restrict__ eucl) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -109,7 +109,7 @@ __global__ void sample_pdf_kernel(const float *__restrict__ weights, const float
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     const int nb = n_out + 1;
-    const float sn = spacing_fn(nears[r]), sf = spacing_fn(fars[r]);
+    const float sn = spacing_fn(nears[r], lin), sf = spacing_fn(fars[r], lin);
     const float jit = u_rand ? u_rand[r] / (float)nb : 0.0f;
     for (int j = lane; j < nb; j += 64) {
         const float uu = u_rand ? add_rn(u[j], jit) : u[j];
@@ -128,7 +128,7 @@ __global__ void sample_pdf_kernel(const float *__restrict__ weights, const float
         t = fminf(fmaxf(t, 0.0f), 1.0f);
         const float b = add_rn(b0, mul_rn(t, sub_rn(b1, b0)));
         spacing[r * nb + j] = b;
-        eucl[r * nb + j] = spacing_to_eucl(b, sn, sf);
+        eucl[r * nb + j] = spacing_to_eucl(b, sn, sf, lin);
     }
 }
 
@@ -383,14 +383,16 @@ int tn_frustum_positions(const float *origins, const float *directions, const fl
 }
 
 int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *nears, const float *fars,
-                      int64_t num_rays, int32_t n, float *spacing_bins, float *eucl_bins, void *stream) {
+                      int64_t num_rays, int32_t n, int32_t uniform_spacing, float *spacing_bins, float *eucl_bins,
+                      void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!lin_bins || !nears || !fars || !spacing_bins || !eucl_bins) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     if (num_rays == 0) return TN_OK;
     const long long total = (long long)num_rays * (n + 1);
     hipLaunchKernelGGL(sample_initial_kernel, dim3(blocks_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                       lin_bins, t_rand, nears, fars, (long long)num_rays, n, spacing_bins, eucl_bins);
+                       lin_bins, t_rand, nears, fars, (long long)num_rays, n, uniform_spacing != 0, spacing_bins,
+                       eucl_bins);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -409,7 +411,7 @@ int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays
 
 int tn_sample_pdf(const float *weights, const float *existing_bins, const float *u, const float *u_rand,
                   const float *nears, const float *fars, int64_t num_rays, int32_t n_in, int32_t n_out,
-                  float *spacing_bins, float *eucl_bins, void *stream) {
+                  int32_t uniform_spacing, float *spacing_bins, float *eucl_bins, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!weights || !existing_bins || !u || !nears || !fars || !spacing_bins || !eucl_bins) return TN_ERR_NULL;
     if (num_rays < 0 || n_in < 1 || n_in > kMaxPdfIn || n_out < 1) return TN_ERR_SHAPE;
@@ -417,7 +419,7 @@ int tn_sample_pdf(const float *weights, const float *existing_bins, const float 
     const size_t smem = (size_t)kWavesPerBlock * 2 * (n_in + 1) * sizeof(float);
     hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(num_rays, kWavesPerBlock)), dim3(kBlock), smem,
                        (hipStream_t)stream, weights, existing_bins, u, u_rand, nears, fars, (long long)num_rays, n_in,
-                       n_out, spacing_bins, eucl_bins);
+                       n_out, uniform_spacing != 0, spacing_bins, eucl_bins);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -38,6 +38,7 @@ class RayRenderEngine:
         self.rc.pdf_anneal = float(model.proposal_sampler._anneal)
         self.rc.early_stop_transmittance = float(cfg.early_termination_eps)
         self.rc.kernel_family = 0
+        self.rc.initial_sampler = int(model.proposal_sampler.initial_sampler.uniform_spacing)
         # a chunk of 65 536 rays is 1024 waves — one per SIMD, half of what the field kernel needs to hide its gathers —
         # so consecutive chunks go to alternating HIP streams (own workspace each) and overlap on the device
         # (default: 2 streams; 4 — the number of hardware queues HIP streams map onto — for small chunks)

@@ -63,6 +63,8 @@ class RaySamples:
     eucl_bins: Optional[Tensor] = None
     nears: Optional[Tensor] = None
     fars: Optional[Tensor] = None
+    # which SpacedSampler made the bins: False = UniformLinDispPiecewiseSampler, True = UniformSampler
+    uniform_spacing: bool = False
 
     @property
     def shape(self):

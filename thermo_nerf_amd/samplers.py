@@ -1,7 +1,8 @@
 """Ray samplers with nerfstudio's names (NS model_components.ray_samplers), built at
 [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:164-179] and run at :222-224 — on MI355X.
 
-  UniformLinDispPiecewiseSampler  -> tn_sample_initial     
+  UniformLinDispPiecewiseSampler  -> tn_sample_initial     (proposal_initial_sampler="piecewise")
+  UniformSampler                  -> tn_sample_initial     (uniform_spacing=1; proposal_initial_sampler="uniform")
   PDFSampler                      -> tn_sample_pdf         (a11)
   ProposalNetworkSampler          -> the level loop of SURVEY A.7, same update/anneal bookkeeping
 """
@@ -37,18 +38,23 @@ def pdf_positions(num_bins: int, device, training: bool) -> Tensor:
     return _const_cache[key]
 
 
-def _samples_from_bins(ray_bundle: RayBundle, spacing: Tensor, eucl: Tensor) -> RaySamples:
+def _samples_from_bins(ray_bundle: RayBundle, spacing: Tensor, eucl: Tensor, uniform_spacing: bool = False) -> RaySamples:
     rs = ray_bundle.get_ray_samples(
         bin_starts=eucl[..., :-1, None], bin_ends=eucl[..., 1:, None],
         spacing_starts=spacing[..., :-1, None], spacing_ends=spacing[..., 1:, None],
         spacing_to_euclidean_fn=None,
     )
     rs.spacing_bins, rs.eucl_bins = spacing, eucl
+    # stands in for nerfstudio's spacing_to_euclidean_fn closure: which spacing function the bins were made with, so that
+    # PDFSampler maps its new bins the same way
+    rs.uniform_spacing = uniform_spacing
     return rs
 
 
 class UniformLinDispPiecewiseSampler(nn.Module):
     """NS UniformLinDispPiecewiseSampler (the "piecewise" proposal_initial_sampler default)."""
+
+    uniform_spacing = False
 
     def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False):
         super().__init__()
@@ -77,11 +83,18 @@ class UniformLinDispPiecewiseSampler(nn.Module):
         _hip.check(
             lib.tn_sample_initial(linspace_bins(n, o.device).data_ptr(),
                                   None if t_rand is None else _hip.require_device_tensor(t_rand.reshape(-1), "t_rand").data_ptr(),
-                                  nears.data_ptr(), fars.data_ptr(), R, n, spacing.data_ptr(), eucl.data_ptr(),
-                                  _hip.current_stream()),
+                                  nears.data_ptr(), fars.data_ptr(), R, n, int(self.uniform_spacing), spacing.data_ptr(),
+                                  eucl.data_ptr(), _hip.current_stream()),
             "tn_sample_initial",
         )
-        return _samples_from_bins(ray_bundle, spacing, eucl)
+        return _samples_from_bins(ray_bundle, spacing, eucl, self.uniform_spacing)
+
+
+class UniformSampler(UniformLinDispPiecewiseSampler):
+    """NS UniformSampler (proposal_initial_sampler="uniform", REF thermal_nerf_model.py:164-170): the same SpacedSampler
+    with spacing_fn = spacing_fn_inv = identity, i.e. bins spread linearly in distance between near and far."""
+
+    uniform_spacing = True
 
 
 class PDFSampler(nn.Module):
@@ -112,6 +125,7 @@ class PDFSampler(nn.Module):
         else:
             u_rand = None
         existing = _hip.require_device_tensor(ray_samples.spacing_bins, "spacing_bins")
+        uniform = bool(getattr(ray_samples, "uniform_spacing", False))
         nears = _hip.require_device_tensor(ray_bundle.nears.reshape(-1), "nears")
         fars = _hip.require_device_tensor(ray_bundle.fars.reshape(-1), "fars")
         spacing = torch.empty((R, n_out + 1), dtype=torch.float32, device=w.device)
@@ -120,15 +134,15 @@ class PDFSampler(nn.Module):
         _hip.check(
             lib.tn_sample_pdf(w.data_ptr(), existing.data_ptr(), pdf_positions(n_out + 1, w.device, jitter).data_ptr(),
                               None if u_rand is None else _hip.require_device_tensor(u_rand.reshape(-1), "u_rand").data_ptr(),
-                              nears.data_ptr(), fars.data_ptr(), R, n_in, n_out, spacing.data_ptr(), eucl.data_ptr(),
-                              _hip.current_stream()),
+                              nears.data_ptr(), fars.data_ptr(), R, n_in, n_out, int(uniform), spacing.data_ptr(),
+                              eucl.data_ptr(), _hip.current_stream()),
             "tn_sample_pdf",
         )
-        return _samples_from_bins(ray_bundle, spacing, eucl)
+        return _samples_from_bins(ray_bundle, spacing, eucl, uniform)
 
 
 class ProposalNetworkSampler(nn.Module):
-    """NS ProposalNetworkSampler: piecewise initial sampler, then PDF resampling per level."""
+    """NS ProposalNetworkSampler: initial sampler (piecewise by default), then PDF resampling per level."""
 
     def __init__(self, num_proposal_samples_per_ray: Tuple[int, ...] = (64,), num_nerf_samples_per_ray: int = 32,
                  num_proposal_network_iterations: int = 2, single_jitter: bool = False,

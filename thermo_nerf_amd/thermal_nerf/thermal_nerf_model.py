@@ -26,7 +26,7 @@ from ..nerfacto_config.thermal_nerfacto import KERNEL_FAMILY, ThermalNerfactoMod
 from ..rays import RayBundle, RaySamples
 from ..rendered_image_modalities import RenderedImageModality
 from ..renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
-from ..samplers import ProposalNetworkSampler, linspace_bins, pdf_positions, _samples_from_bins
+from ..samplers import ProposalNetworkSampler, UniformSampler, linspace_bins, pdf_positions, _samples_from_bins
 from ..scene import NearFarCollider, SceneBox, SceneContraction
 from .thermal_field import ThermalNerfactoTField
 from .thermal_field_head import FieldHeadNamesT
@@ -107,14 +107,15 @@ class ThermalNerfModel(ThermalNerfactoModel):
             return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1,
                            cfg.proposal_update_every)
 
+        # REF :164-170: "uniform" -> UniformSampler, anything else -> UniformLinDispPiecewiseSampler
+        initial_sampler = None
         if cfg.proposal_initial_sampler == "uniform":
-            raise NotImplementedError('proposal_initial_sampler="uniform" is not implemented; the reference default '
-                                      'is "piecewise" (REF :164-170)')
+            initial_sampler = UniformSampler(single_jitter=cfg.use_single_jitter)
         self.proposal_sampler = ProposalNetworkSampler(
             num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray,
             num_proposal_samples_per_ray=cfg.num_proposal_samples_per_ray,
             num_proposal_network_iterations=cfg.num_proposal_iterations, single_jitter=cfg.use_single_jitter,
-            update_sched=update_schedule, initial_sampler=None,
+            update_sched=update_schedule, initial_sampler=initial_sampler,
         )
         self.collider = NearFarCollider(near_plane=cfg.near_plane, far_plane=cfg.far_plane)
         self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
@@ -311,6 +312,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         rc.pdf_anneal = float(self.proposal_sampler._anneal)
         rc.early_stop_transmittance = 0.0 if training else float(cfg.early_termination_eps)
         rc.kernel_family = KERNEL_FAMILY[cfg.kernel_family]
+        rc.initial_sampler = int(self.proposal_sampler.initial_sampler.uniform_spacing)
 
         ins = _hip.tn_render_inputs()
         ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
@@ -363,7 +365,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
         }
         if want_samples:
             outputs["weights_list"] = [w[..., None] for w in extra["w"]]
-            outputs["ray_samples_list"] = [_samples_from_bins(ray_bundle, sp, eu) for sp, eu in zip(extra["sp"], extra["eu"])]
+            outputs["ray_samples_list"] = [_samples_from_bins(ray_bundle, sp, eu, bool(rc.initial_sampler))
+                                           for sp, eu in zip(extra["sp"], extra["eu"])]
         outputs["prop_depth_0"] = buf[3][:, None]
         outputs["prop_depth_1"] = buf[4][:, None]
         outputs[RenderedImageModality.THERMAL.value] = buf[5][:, None]

@@ -245,6 +245,7 @@ class RenderTrain(torch.autograd.Function):
         prop_structs = [model.proposal_networks[min(i, nets - 1)].c_struct(dense=False) for i in range(2)]
         fld = model.field.c_struct(prepare=False, dense=False)
         anneal = float(model.proposal_sampler._anneal)
+        uniform = int(model.proposal_sampler.initial_sampler.uniform_spacing)  # REF thermal_nerf_model.py:164-170
 
         # ---- proposal levels ---------------------------------------------------------------------------------
         tapes: List[_LevelTape] = []
@@ -254,7 +255,8 @@ class RenderTrain(torch.autograd.Function):
             spacing = _f32((R, P[0] + 1), dev)
             eucl = _f32((R, P[0] + 1), dev)
             _hip.check(lib.tn_sample_initial(linspace_bins(P[0], dev).data_ptr(), jitter[0].data_ptr(), nears.data_ptr(),
-                                             fars.data_ptr(), R, P[0], spacing.data_ptr(), eucl.data_ptr(), _stream()),
+                                             fars.data_ptr(), R, P[0], uniform, spacing.data_ptr(), eucl.data_ptr(),
+                                             _stream()),
                        "tn_sample_initial")
             counts = (P[1], S)
             for lvl in range(2):
@@ -265,13 +267,14 @@ class RenderTrain(torch.autograd.Function):
                 spacing, eucl = _f32((R, n_out + 1), dev), _f32((R, n_out + 1), dev)
                 _hip.check(lib.tn_sample_pdf(w_in.data_ptr(), t.spacing.data_ptr(), pdf_positions(n_out + 1, dev, True).data_ptr(),
                                              jitter[lvl + 1].data_ptr(), nears.data_ptr(), fars.data_ptr(), R, P[lvl], n_out,
-                                             spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
+                                             uniform, spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
         else:
             # nerfstudio evaluates the proposal densities under no_grad on these steps (5 of 6 after warm-up): no tape is
             # needed, so both levels run as ONE fused kernel (tn_proposal_sample_fwd, train-mode semantics)
             rc = _hip.tn_render_config()
             rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = P[0], P[1], S
             rc.training, rc.pdf_anneal, rc.early_stop_transmittance, rc.kernel_family = 1, anneal, 0.0, 0
+            rc.initial_sampler = uniform
             ins = _hip.tn_render_inputs()
             ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
             ins.camera_indices, ins.jitter = cam.data_ptr(), jitter.data_ptr()
@@ -575,6 +578,7 @@ def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = N
     return {
         "rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": expected,
         "weights_list": [w0, w1, w2],
-        "ray_samples_list": [_samples_from_bins(ray_bundle, sp, eu) for sp, eu in ((sp0, eu0), (sp1, eu1), (sp2, eu2))],
+        "ray_samples_list": [_samples_from_bins(ray_bundle, sp, eu, sampler.initial_sampler.uniform_spacing)
+                             for sp, eu in ((sp0, eu0), (sp1, eu1), (sp2, eu2))],
         "prop_depth_0": pd0, "prop_depth_1": pd1, "thermal": thermal,
     }
