@@ -357,6 +357,22 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
 int tn_gradient_scale_bwd(const float *starts, const float *ends, int64_t n, float *d_density, float *d_rgb,
                           float *d_thermal, void *stream);
 
+/* NS CameraOptimizer(mode="SO3xR3").apply_to_raybundle — the first statement of the training forward
+ * [REF thermal_nerf_model.py:218-219]: with M_c = exp_map_SO3xR3(pose_adjustment[c]) ([t | w] -> [R(w) | t], Rodrigues with
+ * theta = sqrt(max(|w|^2, 1e-4))), out_origins = origins + t_c, out_directions = R(w_c) directions, c = camera_indices[ray]
+ * (int64, as nerfstudio's ray bundles carry them; 0 <= c < num_cameras is the caller's contract).  pose_adjustment
+ * [num_cameras, 6], origins / directions / outputs [R,3]; outputs may alias the inputs. */
+int tn_camera_opt_fwd(const float *pose_adjustment, const int64_t *camera_indices, const float *origins,
+                      const float *directions, int64_t num_rays, int32_t num_cameras, float *out_origins,
+                      float *out_directions, void *stream);
+
+/* its backward: d_out_origins / d_out_directions [R,3] (either may be NULL = zero), directions = the INPUT directions of the
+ * forward -> d_pose_adjustment [num_cameras, 6] (+=, caller clears it; torch.clamp's sub-gradient: theta is a constant where
+ * |w|^2 < 1e-4), optional d_directions [R,3] (=) = R^T d_out_directions.  d origins = d_out_origins (identity, not written). */
+int tn_camera_opt_bwd(const float *pose_adjustment, const int64_t *camera_indices, const float *directions,
+                      const float *d_out_origins, const float *d_out_directions, int64_t num_rays, int32_t num_cameras,
+                      float *d_pose_adjustment, float *d_directions, void *stream);
+
 /* backward of tn_composite_fwd in training mode (no nan_to_num / clamp): d_out [R,C], accumulation [R] ->
  * d_values [R,n,C] (=), d_weights [R,n] (+=). */
 int tn_composite_bwd(const float *values, const float *weights, const float *accumulation, const float *d_out,

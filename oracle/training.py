@@ -8,6 +8,8 @@ Restates, in differentiable plain torch, what one optimisation step of the refer
 * ``interlevel_loss`` / ``distortion_loss`` / ``lossfun_outer`` / ``outer`` / ``ray_samples_to_sdist``
                                           NS model_components/losses.py (nerfstudio 1.1.5, pinned by uv.lock)
 * proposal-weight anneal + update schedule NS NerfactoModel.get_training_callbacks, built at [REF :152-161]
+* ``exp_map_SO3xR3`` / ``apply_pose_adjustment``  NS cameras/lie_groups.py + CameraOptimizer.apply_to_raybundle (mode "SO3xR3",
+                                          [REF nerfacto_config/thermal_nerfacto.py:38-40]), the call at [REF :218-219]
 
 Gradients come from torch autograd over these functions; the HIP backward kernels are compared against them.
 **Parity unpinned**: nerfstudio is not importable here and the reference holds no numeric vector for its losses.
@@ -107,6 +109,35 @@ def proposal_anneal(step: int, max_num_iters: int = 1000, slope: float = 10.0) -
 def update_schedule(step: int, proposal_warmup: int = 5000, proposal_update_every: int = 5) -> float:
     """[REF thermal_nerf_model.py:152-161]."""
     return float(np.clip(np.interp(step, [0, proposal_warmup], [0, proposal_update_every]), 1, proposal_update_every))
+
+
+def exp_map_SO3xR3(tangent_vector: Tensor) -> Tensor:
+    """NS cameras/lie_groups.exp_map_SO3xR3: [N,6] = (translation, log-rotation) -> [N,3,4] = [R | t], Rodrigues with the
+    squared angle clamped at 1e-4."""
+    log_rot = tangent_vector[:, 3:]
+    nrms = (log_rot * log_rot).sum(1)
+    rot_angles = torch.clamp(nrms, 1e-4).sqrt()
+    rot_angles_inv = 1.0 / rot_angles
+    fac1 = rot_angles_inv * rot_angles.sin()
+    fac2 = rot_angles_inv * rot_angles_inv * (1.0 - rot_angles.cos())
+    skews = torch.zeros((log_rot.shape[0], 3, 3), dtype=log_rot.dtype)
+    skews[:, 0, 1] = -log_rot[:, 2]
+    skews[:, 0, 2] = log_rot[:, 1]
+    skews[:, 1, 0] = log_rot[:, 2]
+    skews[:, 1, 2] = -log_rot[:, 0]
+    skews[:, 2, 0] = -log_rot[:, 1]
+    skews[:, 2, 1] = log_rot[:, 0]
+    skews_square = torch.bmm(skews, skews)
+    ret = torch.zeros(tangent_vector.shape[0], 3, 4, dtype=tangent_vector.dtype)
+    ret[:, :3, :3] = fac1[:, None, None] * skews + fac2[:, None, None] * skews_square + torch.eye(3, dtype=log_rot.dtype)[None]
+    ret[:, :3, 3] = tangent_vector[:, :3]
+    return ret
+
+
+def apply_pose_adjustment(pose_adjustment: Tensor, camera_indices: Tensor, origins: Tensor, directions: Tensor):
+    """NS CameraOptimizer.forward (mode "SO3xR3": gather the rays' rows, exponentiate) + apply_to_raybundle."""
+    m = exp_map_SO3xR3(pose_adjustment[camera_indices.reshape(-1).long(), :])
+    return origins + m[:, :3, 3], torch.bmm(m[:, :3, :3], directions[..., None]).squeeze(-1)
 
 
 def loss_and_grads(sd: Dict[str, Tensor], origins: Tensor, directions: Tensor, camera_indices: Tensor, batch: Dict,

@@ -442,11 +442,43 @@ def test_ray_gradients_match_autograd_oracle(kind, contraction, sh_grad):
     assert rel(gm.field.mlp_head.layers[0].weight.grad, want["field.mlp_head.layers.0.weight"]) <= 2e-3
 
 
+@pytest.mark.parametrize("scale", [0.0, 0.004, 0.02, 0.5])  # |w|^2 below / around / above the 1e-4 clamp; large angles
+@pytest.mark.parametrize("n,cams", [(1000, 8), (64, 1), (4097, 200), (1, 3)])
+def test_camera_opt_apply_and_its_adjoint(n, cams, scale):
+    """tn_camera_opt_fwd / tn_camera_opt_bwd against torch autograd over the oracle's restatement of NS exp_map_SO3xR3 +
+    CameraOptimizer.apply_to_raybundle [REF thermal_nerf_model.py:218-219]."""
+    from thermo_nerf_amd.camera_optimizer import CameraOptimizer, CameraOptimizerConfig
+
+    g = torch.Generator().manual_seed(n + cams)
+    pose = scale * torch.randn(cams, 6, generator=g)
+    pose[0, 3:] = 0.0  # an untouched camera: theta sits on the clamp
+    o = torch.randn(n, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    cam = torch.randint(0, cams, (n, 1), generator=g)
+    go, gd = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+    pose_cpu, d_cpu = pose.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    wo, wd = T.apply_pose_adjustment(pose_cpu, cam, o, d_cpu)
+    ((wo * go).sum() + (wd * gd).sum()).backward()
+
+    copt = CameraOptimizer(CameraOptimizerConfig(mode="SO3xR3"), cams, device=DEV)
+    with torch.no_grad():
+        copt.pose_adjustment.copy_(pose.to(DEV))
+    d_dev = d.to(DEV).requires_grad_(True)
+    rb = RayBundle(origins=o.to(DEV), directions=d_dev, camera_indices=cam.to(DEV))
+    copt.apply_to_raybundle(rb)
+    assert (rb.origins.detach().cpu() - wo.detach()).abs().max().item() <= 1e-6
+    assert (rb.directions.detach().cpu() - wd.detach()).abs().max().item() <= 2e-6
+    ((rb.origins * go.to(DEV)).sum() + (rb.directions * gd.to(DEV)).sum()).backward()
+    assert rel(copt.pose_adjustment.grad, pose_cpu.grad) <= 2e-5, rel(copt.pose_adjustment.grad, pose_cpu.grad)
+    assert rel(d_dev.grad, d_cpu.grad) <= 2e-6
+    # the [N,3,4] matrices of forward(indices) are the same map
+    m = copt(cam.reshape(-1).to(DEV)).detach().cpu()
+    assert (m - T.exp_map_SO3xR3(pose[cam.reshape(-1)])).abs().max().item() <= 1e-6
+
+
 def test_camera_optimizer_receives_the_pose_gradient():
     """Reference default camera_optimizer_mode="SO3xR3" [REF nerfacto_config/thermal_nerfacto.py:24]: pose_adjustment gets
     its gradient through apply_to_raybundle (torch) from the HIP ray gradients."""
-    from thermo_nerf_amd.camera_optimizer import CameraOptimizer, CameraOptimizerConfig
-
     cm, sd, ocfg = helpers.build("stress", 48)
     assert cm.config.camera_optimizer.mode == "SO3xR3"
     gm = copy.deepcopy(cm).to(DEV).train()
@@ -470,16 +502,14 @@ def test_camera_optimizer_receives_the_pose_gradient():
     got = gm.camera_optimizer.pose_adjustment.grad
     assert got is not None and torch.isfinite(got).all() and got.abs().max().item() > 0
 
-    # expected: the same chain on the CPU — camera optimizer (torch) in front of the autograd oracle
-    copt = CameraOptimizer(CameraOptimizerConfig(mode="SO3xR3"), 8)
-    with torch.no_grad():
-        copt.pose_adjustment.copy_(pose)
-    rb_cpu = RayBundle(origins=o.clone(), directions=d.clone(), camera_indices=cam)
-    copt.apply_to_raybundle(rb_cpu)
-    _, _, want = T.loss_and_grads(sd, rb_cpu.origins.detach(), rb_cpu.directions.detach(), cam, batch, ocfg, jit)
-    (rb_cpu.origins * want["__origins__"]).sum().backward(retain_graph=True)
-    (rb_cpu.directions * want["__directions__"]).sum().backward()
-    assert rel(got, copt.pose_adjustment.grad) <= 2e-2, rel(got, copt.pose_adjustment.grad)
+    # expected: the same chain on the CPU — the oracle's camera optimizer in front of the autograd oracle
+    pose_cpu = pose.clone().requires_grad_(True)
+    o_adj, d_adj = T.apply_pose_adjustment(pose_cpu, cam, o, d)
+    assert (rb.origins.detach().cpu() - o_adj.detach()).abs().max().item() <= 1e-6
+    assert (rb.directions.detach().cpu() - d_adj.detach()).abs().max().item() <= 1e-6
+    _, _, want = T.loss_and_grads(sd, o_adj.detach(), d_adj.detach(), cam, batch, ocfg, jit)
+    ((o_adj * want["__origins__"]).sum() + (d_adj * want["__directions__"]).sum()).backward()
+    assert rel(got, pose_cpu.grad) <= 2e-2, rel(got, pose_cpu.grad)
     # used cameras only
     used = torch.zeros(8, dtype=torch.bool)
     used[cam.reshape(-1)] = True

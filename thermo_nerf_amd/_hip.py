@@ -148,6 +148,8 @@ SIGNATURES = {
     "tn_density_fwd": (C.c_int, [C.POINTER(tn_density_field), _vp, _i64, _vp, _vp]),
     "tn_field_density_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _i64, _vp, _vp, _vp]),
     "tn_field_heads_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_camera_opt_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_camera_opt_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "tn_sample_initial": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "tn_weights_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "tn_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),

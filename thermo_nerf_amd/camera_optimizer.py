@@ -1,7 +1,8 @@
 """Per-camera pose refinement holder with nerfstudio's parameter name ``pose_adjustment`` [N,6]
 (NS CameraOptimizer; configured at [REF thermo_nerf/nerfacto_config/thermal_nerfacto.py:38-40], applied in
-training at [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:218-219]).  Training-side glue: a few tiny
-torch ops per batch on [R,3] tensors, outside the rendering hot path."""
+training at [REF thermo_nerf/thermal_nerf/thermal_nerf_model.py:218-219]).  ``apply_to_raybundle`` — the first statement
+of the training forward — is one HIP kernel each way (tn_camera_opt_fwd / tn_camera_opt_bwd); ``forward(indices)`` (the
+[N,3,4] correction matrices, which nothing on the rendering path asks for) stays a handful of torch ops."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -10,6 +11,7 @@ from typing import Literal
 import torch
 from torch import Tensor, nn
 
+from . import _hip
 from .rays import RayBundle
 
 
@@ -35,6 +37,37 @@ def _so3xr3_exp(tangent: Tensor) -> Tensor:
     return torch.cat([rot, t[:, :, None]], dim=2)
 
 
+class _ApplyPoseAdjustment(torch.autograd.Function):
+    """origins + t_c, R(w_c) directions with c = the ray's camera (NS exp_map_SO3xR3 + apply_to_raybundle) on the device."""
+
+    @staticmethod
+    def forward(ctx, pose: Tensor, cam: Tensor, origins: Tensor, directions: Tensor):
+        pose = _hip.require_device_tensor(pose.detach(), "pose_adjustment")
+        cam = _hip.require_device_tensor(cam, "camera_indices", dtype=torch.int64)
+        o = _hip.require_device_tensor(origins.detach(), "origins")
+        d = _hip.require_device_tensor(directions.detach(), "directions")
+        out_o, out_d = torch.empty_like(o), torch.empty_like(d)
+        _hip.check(_hip.load().tn_camera_opt_fwd(pose.data_ptr(), cam.data_ptr(), o.data_ptr(), d.data_ptr(), o.shape[0],
+                                                 pose.shape[0], out_o.data_ptr(), out_d.data_ptr(), _hip.current_stream()),
+                   "tn_camera_opt_fwd")
+        ctx.save_for_backward(pose, cam, d)
+        return out_o, out_d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        pose, cam, d = ctx.saved_tensors
+        g_o = None if g_o is None else _hip.require_device_tensor(g_o, "d origins")
+        g_d = None if g_d is None else _hip.require_device_tensor(g_d, "d directions")
+        d_pose = torch.zeros_like(pose)
+        d_dirs = torch.empty_like(d) if ctx.needs_input_grad[3] else None
+        _hip.check(_hip.load().tn_camera_opt_bwd(pose.data_ptr(), cam.data_ptr(), d.data_ptr(), _hip.ptr(g_o), _hip.ptr(g_d),
+                                                 d.shape[0], pose.shape[0], d_pose.data_ptr(), _hip.ptr(d_dirs),
+                                                 _hip.current_stream()), "tn_camera_opt_bwd")
+        if d_dirs is not None and g_d is None:
+            d_dirs.zero_()
+        return d_pose, None, (g_o if ctx.needs_input_grad[2] else None), d_dirs
+
+
 class CameraOptimizer(nn.Module):
     def __init__(self, config: CameraOptimizerConfig, num_cameras: int, device="cpu") -> None:
         super().__init__()
@@ -56,6 +89,8 @@ class CameraOptimizer(nn.Module):
     def apply_to_raybundle(self, raybundle: RayBundle) -> None:
         if self.config.mode == "off":
             return
-        m = self(raybundle.camera_indices.squeeze(-1).long())
-        raybundle.origins = raybundle.origins + m[:, :3, 3]
-        raybundle.directions = torch.bmm(m[:, :3, :3], raybundle.directions[..., None]).squeeze(-1)
+        cam = raybundle.camera_indices.reshape(-1)
+        if cam.dtype != torch.int64:
+            cam = cam.long()
+        raybundle.origins, raybundle.directions = _ApplyPoseAdjustment.apply(self.pose_adjustment, cam, raybundle.origins,
+                                                                             raybundle.directions)

@@ -862,6 +862,133 @@ gradient_scale_kernel(const float *__restrict__ starts, const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// NS CameraOptimizer (mode "SO3xR3").apply_to_raybundle, the first statement of the training forward
+// [REF thermal_nerf_model.py:218-219]:  M_c = exp_map_SO3xR3(pose_adjustment[c]);  o' = o + M_c[:, 3];  d' = M_c[:, :3] d.
+//   theta = sqrt(max(|w|^2, 1e-4)),  a = sin(theta)/theta,  b = (1 - cos(theta))/theta^2,  R = I + a K(w) + b K(w)^2
+// applied to a vector without forming R:  R d = d + a (w x d) + b (w x (w x d)).  As ~60 tiny torch launches (slice assignments,
+// two bmm's over [R,3,3], their autograd twins) this cost more device time than the whole proposal pass of a step.
+// ------------------------------------------------------------------------------------------------------
+struct Pose {
+    float t[3], w[3], a, b, theta;
+    bool clamped;
+};
+__device__ __forceinline__ Pose pose_load(const float *__restrict__ pose, long long c) {
+    Pose p;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p.t[k] = pose[c * 6 + k];
+        p.w[k] = pose[c * 6 + 3 + k];
+    }
+    const float n2 = p.w[0] * p.w[0] + p.w[1] * p.w[1] + p.w[2] * p.w[2];
+    p.clamped = !(n2 >= 1e-4f);  // torch.clamp passes the gradient where the input is >= min
+    p.theta = sqrtf(fmaxf(n2, 1e-4f));
+    const float inv = 1.0f / p.theta;
+    p.a = inv * sinf(p.theta);
+    p.b = inv * inv * (1.0f - cosf(p.theta));
+    return p;
+}
+__device__ __forceinline__ void cross3(const float *u, const float *v, float *o) {
+    o[0] = u[1] * v[2] - u[2] * v[1];
+    o[1] = u[2] * v[0] - u[0] * v[2];
+    o[2] = u[0] * v[1] - u[1] * v[0];
+}
+
+__global__ void __launch_bounds__(kBlock)
+camera_opt_fwd_kernel(const float *__restrict__ pose, const long long *__restrict__ cam, const float *__restrict__ origins,
+                      const float *__restrict__ dirs, long long n, float *__restrict__ out_o, float *__restrict__ out_d) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const Pose p = pose_load(pose, cam[i]);
+        const float d[3] = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
+        float u[3], v[3];
+        cross3(p.w, d, u);
+        cross3(p.w, u, v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out_o[i * 3 + k] = origins[i * 3 + k] + p.t[k];
+            out_d[i * 3 + k] = d[k] + p.a * u[k] + p.b * v[k];
+        }
+    }
+}
+
+// backward: per ray the 6 components of d loss / d pose_adjustment[c]; lanes of a wave that share a camera are summed first
+// (a loop over the distinct cameras of the wave), so one atomic per (wave, camera, component) reaches the [C, 6] gradient.
+//   d/dt = g_o;   d/dw = a (d x g) + b (g (w.d) + d (g.w) - 2 (g.d) w) + (a'(theta) g.(w x d) + b'(theta) g.(w x (w x d))) w / theta
+// with the last term only where |w|^2 >= 1e-4 (inside the clamp theta is a constant).  Optional d_dirs_in = R^T g.
+__global__ void __launch_bounds__(kBlock)
+camera_opt_bwd_kernel(const float *__restrict__ pose, const long long *__restrict__ cam, const float *__restrict__ dirs,
+                      const float *__restrict__ g_o, const float *__restrict__ g_d, long long n, float *__restrict__ d_pose,
+                      float *__restrict__ d_dirs_in) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    const long long rounds = (n + stride - 1) / stride;
+    for (long long rd = 0; rd < rounds; ++rd) {
+        const long long i = rd * stride + (long long)blockIdx.x * kBlock + threadIdx.x;
+        const bool live = i < n;
+        long long c = -1;
+        float q[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) {
+            c = cam[i];
+            const Pose p = pose_load(pose, c);
+            const float d[3] = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
+            float g[3] = {0.0f, 0.0f, 0.0f};
+            if (g_d) {
+                g[0] = g_d[i * 3]; g[1] = g_d[i * 3 + 1]; g[2] = g_d[i * 3 + 2];
+            }
+            if (g_o) {
+                q[0] = g_o[i * 3]; q[1] = g_o[i * 3 + 1]; q[2] = g_o[i * 3 + 2];
+            }
+            float u[3], v[3], dxg[3];
+            cross3(p.w, d, u);
+            cross3(p.w, u, v);
+            cross3(d, g, dxg);
+            const float wd = p.w[0] * d[0] + p.w[1] * d[1] + p.w[2] * d[2];
+            const float gw = g[0] * p.w[0] + g[1] * p.w[1] + g[2] * p.w[2];
+            const float gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+            float radial = 0.0f;
+            if (!p.clamped) {
+                const float th = p.theta, gu = g[0] * u[0] + g[1] * u[1] + g[2] * u[2], gv = g[0] * v[0] + g[1] * v[1] + g[2] * v[2];
+                float da, db;
+                if (th < 0.1f) {  // series: the closed forms cancel catastrophically in fp32 for small angles
+                    const float t2 = th * th;
+                    da = th * (-1.0f / 3.0f + t2 * (1.0f / 30.0f - t2 / 840.0f));
+                    db = th * (-1.0f / 12.0f + t2 * (1.0f / 180.0f - t2 / 6720.0f));
+                } else {
+                    const float sn = sinf(th), cs = cosf(th);
+                    da = (th * cs - sn) / (th * th);
+                    db = (th * sn - 2.0f * (1.0f - cs)) / (th * th * th);
+                }
+                radial = (da * gu + db * gv) / th;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                q[3 + k] = p.a * dxg[k] + p.b * (g[k] * wd + d[k] * gw - 2.0f * gd * p.w[k]) + radial * p.w[k];
+            if (d_dirs_in) {  // R^T g = g - a (w x g) + b (w x (w x g))
+                float wg[3], wwg[3];
+                cross3(p.w, g, wg);
+                cross3(p.w, wg, wwg);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d_dirs_in[i * 3 + k] = g[k] - p.a * wg[k] + p.b * wwg[k];
+            }
+        }
+        // distinct cameras of this wave, one at a time (a training batch draws its rays from all images: up to 64 rounds)
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const long long cc = __shfl(c, leader, 64);
+            const bool mine = live && c == cc;
+            float r[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r[k] = wave_sum(mine ? q[k] : 0.0f);
+            if (lane == leader) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) atomic_add_f32(d_pose + cc * 6 + k, r[k]);
+            }
+            todo &= ~__ballot(mine);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // get_weights backward: one wave per ray, chunks of 64 samples walked back to front.
 //   a_i = delta_i sigma_i,  T_i = exp(-sum_{j<i} a_j),  w_i = (1 - e^{-a_i}) T_i
 //   dL/da_k = g_k e^{-a_k} T_k - sum_{i>k} g_i w_i
@@ -1402,6 +1529,32 @@ int tn_gradient_scale_bwd(const float *starts, const float *ends, int64_t n, flo
     if (n < 0) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(gradient_scale_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, starts,
                        ends, (long long)n, d_density, d_rgb, d_thermal);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_camera_opt_fwd(const float *pose_adjustment, const int64_t *camera_indices, const float *origins,
+                      const float *directions, int64_t num_rays, int32_t num_cameras, float *out_origins,
+                      float *out_directions, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!pose_adjustment || !camera_indices || !origins || !directions || !out_origins || !out_directions) return TN_ERR_NULL;
+    if (num_rays < 0 || num_cameras < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(camera_opt_fwd_kernel, dim3(grid_for(num_rays, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
+                       pose_adjustment, reinterpret_cast<const long long *>(camera_indices), origins, directions,
+                       (long long)num_rays, out_origins, out_directions);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_camera_opt_bwd(const float *pose_adjustment, const int64_t *camera_indices, const float *directions,
+                      const float *d_out_origins, const float *d_out_directions, int64_t num_rays, int32_t num_cameras,
+                      float *d_pose_adjustment, float *d_directions, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!pose_adjustment || !camera_indices || !directions || !d_pose_adjustment) return TN_ERR_NULL;
+    if (num_rays < 0 || num_cameras < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(camera_opt_bwd_kernel, dim3(grid_for(num_rays, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
+                       pose_adjustment, reinterpret_cast<const long long *>(camera_indices), directions, d_out_origins,
+                       d_out_directions, (long long)num_rays, d_pose_adjustment, d_directions);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
