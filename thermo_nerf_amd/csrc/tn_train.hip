@@ -647,9 +647,10 @@ __global__ void __launch_bounds__(kBlock, 2) linear_chain_bwd_kernel(ChainArgs a
                     accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);
                 }
             }
-            if (threadIdx.x < 64) {  // bias_j: column sums of g_j
+            {   // bias_j: column sums of g_j, a quarter of the rows per wave (summed over the waves when the slab is written)
                 float sb = 0.0f;
-                for (int r = 0; r < TILE; ++r) sb += gs[r * LDP + threadIdx.x];
+#pragma unroll
+                for (int r = 0; r < TILE / 4; ++r) sb += gs[(wave * (TILE / 4) + r) * LDP + lane];
                 accb[j] += sb;
             }
             const bool last = j == NL - 1;
@@ -659,6 +660,7 @@ __global__ void __launch_bounds__(kBlock, 2) linear_chain_bwd_kernel(ChainArgs a
             if (has_dx) {  // dx_j^T tile (it, nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accd[r] = 0.0f;
+#pragma unroll 8
                 for (int s2 = 0; s2 < ksteps_o; ++s2) {
                     const float av = Wj[(2 * s2 + h) * 64 + it * 32 + l31];
                     const float bv = gs[(nt * 32 + l31) * LDP + 2 * s2 + h];
@@ -720,7 +722,10 @@ __global__ void __launch_bounds__(kBlock, 2) linear_chain_bwd_kernel(ChainArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) pb[(it2 * 32 + l31) * 64 + ot * 32 + crow(r, h)] = accw[j][r];
         }
-        if (threadIdx.x < 64) pb[64 * 64 + threadIdx.x] = accb[j];
+        __syncthreads();  // the four waves' bias partials meet in LDS (the row tiles are no longer needed)
+        gs[wave * 64 + lane] = accb[j];
+        __syncthreads();
+        if (wave == 0) pb[64 * 64 + lane] = (gs[lane] + gs[64 + lane]) + (gs[128 + lane] + gs[192 + lane]);
     }
 }
 

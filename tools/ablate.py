@@ -80,7 +80,49 @@ def variant(name: str, src: str) -> str:
         k = k.replace("th = combine_halves(out_dot_fast<1>(wt, h, x2)) + wt[64];", "th = x2[0][0][5] + x2[1][1][7] + x2[0][1][9] + x2[1][0][11];")
         assert k.count("x2[1][1][7]") == 1
         return v[:a] + k + v[b:]
-    if name == "base":
+    if name == "train_nomfma":  # chain backward without its MFMAs: loads, LDS staging, barriers, epilogues only
+        assert src.count("accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);") == 1
+        src = src.replace("accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[j], 0, 0, 0);", "accw[j][s2 & 15] += av * bv;")
+        assert src.count("accd = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd, 0, 0, 0);") == 1
+        return src.replace("accd = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd, 0, 0, 0);", "accd[s2 & 15] += av * bv;")
+    if name == "train_noload":  # chain backward without HBM reads of the row tiles (first tile's registers reused)
+        old = "            if (next < tiles) tile_fetch(rx[j], L.x, L.ldx, IN, next * TILE, a.n, L.vec_x);\n"
+        assert src.count(old) == 1
+        src = src.replace(old, "")
+        old = "            if (next < tiles) fetch_top(next);\n"
+        assert src.count(old) == 1
+        return src.replace(old, "")
+    if name == "train_nobias":  # without wave 0's serial column sums
+        old = "                for (int r = 0; r < TILE; ++r) sb += gs[r * LDP + threadIdx.x];\n"
+        assert src.count(old) == 1
+        return src.replace(old, "                sb += gs[threadIdx.x];\n")
+    if name == "train_timing":  # per-phase wave-cycle sums of linear_chain_bwd_kernel (wave 0) -> 8 uint64 after the slabs
+        a = src.index("template <int NL>\n__global__ void __launch_bounds__(kBlock, 2) linear_chain_bwd_kernel")
+        b = src.index("// dW[o][i] += sum_b partials[b][i][o]")
+        k = src[a:b]
+        def rep(old, new):
+            nonlocal k
+            assert k.count(old) == 1, old
+            k = k.replace(old, new)
+        rep("    const long long tiles = (a.n + TILE - 1) / TILE;\n",
+            "    const long long tiles = (a.n + TILE - 1) / TILE;\n    unsigned long long ts[8] = {0,0,0,0,0,0,0,0}; long long tq;\n")
+        rep("        __syncthreads();  // the previous tile's readers of gs / xs are done\n",
+            "        tq = clock64();\n        __syncthreads();  // the previous tile's readers of gs / xs are done\n")
+        rep("            tile_to_lds(rx[j], xs);\n", "            { long long t = clock64(); ts[0] += t - tq; tq = t; }\n            tile_to_lds(rx[j], xs);\n")
+        rep("            const int ot = wave % n_ot, it2 = wave / n_ot;\n            if (wave < n_ot * n_it) {  // dW_j tile (ot, it2)\n",
+            "            { long long t = clock64(); ts[1] += t - tq; tq = t; }\n            const int ot = wave % n_ot, it2 = wave / n_ot;\n            if (wave < n_ot * n_it) {  // dW_j tile (ot, it2)\n")
+        rep("            {   // bias_j: column sums", "            { long long t = clock64(); ts[2] += t - tq; tq = t; }\n            {   // bias_j: column sums")
+        rep("            const bool last = j == NL - 1;\n", "            { long long t = clock64(); ts[3] += t - tq; tq = t; }\n            const bool last = j == NL - 1;\n")
+        rep("            __syncthreads();  // every MFMA operand read of gs / xs is done\n",
+            "            { long long t = clock64(); ts[4] += t - tq; tq = t; }\n            __syncthreads();  // every MFMA operand read of gs / xs is done\n            { long long t = clock64(); ts[5] += t - tq; tq = t; }\n")
+        rep("    // one slab [i (64 rows) | bias row][o (64)] per layer and block\n",
+            "    if (threadIdx.x == 0) { for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<unsigned long long *>(a.partials + (size_t)kChainMax * kChainBlocks * 65 * 64) + q, ts[q]); }\n    // one slab [i (64 rows) | bias row][o (64)] per layer and block\n")
+        # the epilogue (after the barrier) up to the loop end is charged to ts[0] of the next layer / tile
+        src = src[:a] + k + src[b:]
+        old = "size_t tn_linear_chain_bwd_workspace_bytes(void) { return (size_t)kChainMax * kChainBlocks * 65 * 64 * sizeof(float); }"
+        assert src.count(old) == 1
+        return src.replace(old, "size_t tn_linear_chain_bwd_workspace_bytes(void) { return (size_t)kChainMax * kChainBlocks * 65 * 64 * sizeof(float) + 64; }")
+    if name == "base" or name == "train_base":
         return src
     raise SystemExit(f"unknown variant {name}")
 
@@ -119,7 +161,7 @@ def main():
     """names: a tn_render_mfma.hip source variant, a header variant (applied to the field kernels), or `prop_<header variant>`
     (the same header patch applied to tn_render.hip = the proposal kernels only)."""
     for name in sys.argv[1:]:
-        target = "tn_render.hip" if name.startswith("prop_") else "tn_render_mfma.hip"
+        target = "tn_render.hip" if name.startswith("prop_") else "tn_train.hip" if name.startswith("train_") else "tn_render_mfma.hip"
         hname = name[5:] if name.startswith("prop_") else name
         inc = CSRC
         if hname in HEADER_VARIANTS:
@@ -132,8 +174,13 @@ def main():
         src = open(os.path.join(CSRC, target)).read().replace('#include "tn_field_eval.h"', f'#include "{inc}/tn_field_eval.h"')
         tmp = f"/tmp/abl_{name}.hip"
         open(tmp, "w").write(src if hname in HEADER_VARIANTS else variant(name, src))
-        others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_mfma.hip",
-                                                  "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip") if f != target]
+        # the untouched translation units come from the regular build's objects (make in csrc/ first)
+        others = [os.path.join(CSRC, "build", f.replace(".hip", ".o")) for f in
+                  ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_mfma.hip", "tn_render_h3.hip", "tn_train.hip",
+                   "tn_prepare.hip") if f != target and hname not in HEADER_VARIANTS]
+        if hname in HEADER_VARIANTS:
+            others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_mfma.hip",
+                                                      "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip") if f != target]
         out = os.path.join(ROOT, f"ab_{name}.so")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)
         print("built", out)
