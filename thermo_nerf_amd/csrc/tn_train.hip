@@ -1202,11 +1202,14 @@ color_input_bwd_dir_kernel(int sh_shifted, const float *__restrict__ d_cin, cons
 __global__ void __launch_bounds__(kBlock)
 distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weights, long long R, int n,
                   float *__restrict__ loss_sum, float *__restrict__ gw) {
+    // a wave walks several rays and a block adds ONE value to loss_sum: atomics on a single address retire one at a time in
+    // L2 (~12 ns each), so one per ray made this kernel 50 us of waiting for 4096 rays
+    __shared__ float red[kBlock / 64];
     const int lane = threadIdx.x & 63;
-    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (ray >= R) return;
-    const float *t = bins + ray * (n + 1), *w = weights + ray * n;
     const int chunks = (n + 63) / 64;
+    float loss_acc = 0.0f;
+    for (long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); ray < R; ray += (long long)gridDim.x * (kBlock / 64)) {
+    const float *t = bins + ray * (n + 1), *w = weights + ray * n;
     float W = 0.0f, WU = 0.0f;
     for (int c = 0; c < chunks; ++c) {
         const int i = c * 64 + lane;
@@ -1233,8 +1236,12 @@ distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weig
         cW += __shfl(iw, 63, 64);
         cWU += __shfl(iwu, 63, 64);
     }
-    loss = wave_sum(loss);
-    if (lane == 0) atomic_add_f32(loss_sum, loss);
+    loss_acc += loss;
+    }
+    loss_acc = wave_sum(loss_acc);
+    if (lane == 0) red[threadIdx.x >> 6] = loss_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f32(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1256,9 +1263,10 @@ interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, cons
                   const float *__restrict__ wp, long long R, int n, int p, float *__restrict__ loss_sum,
                   float *__restrict__ g_wp) {
     extern __shared__ float lds[];
+    __shared__ float red[kBlock / 64];  // one atomic on loss_sum per block (see distortion_kernel)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long ray = (long long)blockIdx.x * (kBlock / 64) + wave;
-    if (ray >= R) return;
+    float loss_acc = 0.0f;
+    for (long long ray = (long long)blockIdx.x * (kBlock / 64) + wave; ray < R; ray += (long long)gridDim.x * (kBlock / 64)) {
     const int stride = 4 * (p + 2);
     float *edges = lds + wave * stride;  // [p+1]
     float *cum = edges + (p + 2);        // [p+1] exclusive cumsum of wp (cum[p] = total)
@@ -1309,8 +1317,14 @@ interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, cons
         s_hi += __shfl(rh, 0, 64);
         s_lo += __shfl(rl, 0, 64);
     }
-    loss = wave_sum(loss);
-    if (lane == 0) atomic_add_f32(loss_sum, loss);
+    loss_acc += loss;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();  // the next ray of this wave reuses the LDS arrays
+    }
+    loss_acc = wave_sum(loss_acc);
+    if (lane == 0) red[wave] = loss_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f32(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 }  // namespace
@@ -1653,7 +1667,7 @@ int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t 
     if (num_rays == 0) return TN_OK;
     if (!spacing_bins || !weights || !loss_sum || !d_weights) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
-    hipLaunchKernelGGL(distortion_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(distortion_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), 0, (hipStream_t)stream,
                        spacing_bins, weights, (long long)num_rays, n, loss_sum, d_weights);
     TN_LAUNCH_CHECK();
     return TN_OK;
@@ -1666,7 +1680,7 @@ int tn_interlevel_loss(const float *c, const float *w, const float *cp, const fl
     if (num_rays < 0 || n < 1 || p < 1 || p > kMaxP) return TN_ERR_SHAPE;
     const size_t lds = (size_t)(kBlock / 64) * 4 * (p + 2) * sizeof(float);
     if (lds > 48 * 1024 && !tn_ensure_dynamic_lds<interlevel_kernel>(lds)) return TN_ERR_LAUNCH;
-    hipLaunchKernelGGL(interlevel_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), lds, (hipStream_t)stream, c, w,
+    hipLaunchKernelGGL(interlevel_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), lds, (hipStream_t)stream, c, w,
                        cp, wp, (long long)num_rays, n, p, loss_sum, d_wp);
     TN_LAUNCH_CHECK();
     return TN_OK;
