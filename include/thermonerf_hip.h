@@ -310,11 +310,13 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
                   float *d_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* density = average_init_density * trunc_exp(raw) * selector (NS get_density); raw rows ld_raw floats apart.
- * backward: d_raw = d_density * average_init_density * exp(min(raw, 15)) * selector (NS trunc_exp.backward). */
+ * backward: d_raw = d_density * average_init_density * exp(min(raw, 15)) * selector (NS trunc_exp.backward), written to
+ * column 0 of rows ld_d_raw apart; columns 1 .. clear_cols-1 of each row are set to zero (clear_cols <= 1: untouched) so that
+ * the row can be the += target of the stages behind it without a separate fill. */
 int tn_density_act_fwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density, int64_t n,
                        float *density, void *stream);
 int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density,
-                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, void *stream);
+                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, int32_t clear_cols, void *stream);
 
 /* backward of tn_weights_fwd: d_weights [R,n] -> d_densities [R,n]. */
 int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
@@ -389,15 +391,15 @@ int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const 
                        int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
                        float *d_appearance, const float *directions, float *d_directions, void *stream);
 
-/* NS losses.distortion_loss on one level: spacing bins [R,n+1], weights [R,n] -> loss_sum[0] (+=) = sum over rays
- * of lossfun_distortion (divide by R for the mean), d_weights [R,n] (=) = d(sum)/dw.  O(n) per ray. */
-int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float *loss_sum,
-                       float *d_weights, void *stream);
+/* NS losses.distortion_loss on one level: spacing bins [R,n+1], weights [R,n] -> loss_sum[0] (+=) = scale * sum over rays
+ * of lossfun_distortion (scale = 1/R for nerfstudio's mean), d_weights [R,n] (=) = scale * d(sum)/dw.  O(n) per ray. */
+int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float scale,
+                       float *loss_sum, float *d_weights, void *stream);
 /* NS losses.interlevel_loss, one proposal level: final bins c [R,n+1] / weights w [R,n] (constants), proposal bins
- * cp [R,p+1] / weights wp [R,p] -> loss_sum[0] (+=) = sum over rays and samples of lossfun_outer (divide by R*n),
- * d_wp [R,p] (=) = d(sum)/dwp.  p <= 1024. */
+ * cp [R,p+1] / weights wp [R,p] -> loss_sum[0] (+=) = scale * sum over rays and samples of lossfun_outer (scale = 1/(R*n)),
+ * d_wp [R,p] (=) = scale * d(sum)/dwp.  p <= 1024.  Several levels may add into the same loss_sum. */
 int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
-                       int32_t p, float *loss_sum, float *d_wp, void *stream);
+                       int32_t p, float scale, float *loss_sum, float *d_wp, void *stream);
 
 /* library identification: returns a static string "thermonerf_hip <version> gfx950". */
 const char *tn_version(void);

@@ -185,7 +185,7 @@ SIGNATURES = {
     "tn_linear_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
                                 _sz, _vp]),
     "tn_density_act_fwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _i64, _vp, _vp]),
-    "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _vp, _i64, _vp, _i32, _vp]),
+    "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _vp, _i64, _vp, _i32, _i32, _vp]),
     "tn_weights_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tn_gradient_scale_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tn_linear_chain_bwd_workspace_bytes": (_sz, []),
@@ -196,8 +196,8 @@ SIGNATURES = {
     "tn_color_input_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "tn_hash_encode_bwd_input": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),
     "tn_frustum_positions_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
-    "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
-    "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp, _vp]),
+    "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_version": (C.c_char_p, []),
 }
 

@@ -760,6 +760,44 @@ linear_bwd_reduce_kernel(const float *__restrict__ partials, int blocks, int INP
     }
 }
 
+// the same for all layers of a chain in one launch (blockIdx.z = layer; slabs are [65][64] per block)
+struct RedChainArgs {
+    const float *partials[kChainMax];
+    float *dW[kChainMax], *db[kChainMax];
+    int IN[kChainMax], OUT[kChainMax];
+};
+__global__ void __launch_bounds__(kBlock) linear_bwd_reduce_chain_kernel(RedChainArgs a, int blocks) {
+    __shared__ float red[kBlock];
+    const int j = blockIdx.z;
+    const float *partials = a.partials[j];
+    float *dW = a.dW[j], *db = a.db[j];
+    if (!dW && !db) return;
+    const int IN = a.IN[j], OUT = a.OUT[j];
+    const int i = blockIdx.x, o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (i != 64 && i >= IN) return;  // rows of padded inputs
+    const int per = (blocks + kRedSplit - 1) / kRedSplit;
+    const int b0 = blockIdx.y * per, b1 = min(blocks, b0 + per);
+    const float *p = partials + (size_t)i * 64 + o;
+    const size_t st = (size_t)65 * 64;
+    float s0 = 0.0f, s1 = 0.0f;
+    int b = b0 + q;
+    for (; b + 4 < b1; b += 8) {
+        s0 += p[(size_t)b * st];
+        s1 += p[(size_t)(b + 4) * st];
+    }
+    if (b < b1) s0 += p[(size_t)b * st];
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && o < OUT) {
+        const float tot = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
+        if (i == 64) {
+            if (db) atomic_add_f32(db + o, tot);
+        } else if (dW) {
+            atomic_add_f32(dW + o * IN + i, tot);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Linear forward, lane = row.  A wave-uniform operand costs nothing when it comes through the SCALAR cache (s_load +
 // v_pk_fma with SGPR sources), while the same value broadcast from LDS costs LDS->VGPR bandwidth for all 64 lanes (what
@@ -843,9 +881,19 @@ density_act_fwd_kernel(const float *__restrict__ raw, int ld, const float *__res
 }
 __global__ void __launch_bounds__(kBlock)
 density_act_bwd_kernel(const float *__restrict__ raw, int ld, const float *__restrict__ sel, float avg,
-                       const float *__restrict__ dd, long long n, float *__restrict__ d_raw, int ldd) {
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
-        d_raw[i * ldd] = dd[i] * sel[i] * avg * expf(fminf(raw[i * ld], 15.0f));
+                       const float *__restrict__ dd, long long n, float *__restrict__ d_raw, int ldd, int clear_cols) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float g = dd[i] * sel[i] * avg * expf(fminf(raw[i * ld], 15.0f));
+        float *row = d_raw + i * ldd;
+        if (clear_cols > 1 && (ldd & 3) == 0 && (clear_cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0) {
+            // the row's other columns are the += targets of later stages: whole 16-byte pieces (a 16-float row = one line)
+            *reinterpret_cast<float4 *>(row) = make_float4(g, 0.0f, 0.0f, 0.0f);
+            for (int c = 4; c < clear_cols; c += 4) *reinterpret_cast<float4 *>(row + c) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            row[0] = g;
+            for (int c = 1; c < clear_cols; ++c) row[c] = 0.0f;
+        }
+    }
 }
 
 // NS scale_gradients_by_distance_squared (use_gradient_scaling, REF thermal_nerf_model.py:228-231): backward-only —
@@ -1200,7 +1248,7 @@ color_input_bwd_dir_kernel(int sh_shifted, const float *__restrict__ d_cin, cons
 //   loss = sum_i w_i S_i + sum_i w_i^2 d_i / 3,   dloss/dw_i = 2 S_i + 2 w_i d_i / 3
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weights, long long R, int n,
+distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weights, long long R, int n, float scale,
                   float *__restrict__ loss_sum, float *__restrict__ gw) {
     // a wave walks several rays and a block adds ONE value to loss_sum: atomics on a single address retire one at a time in
     // L2 (~12 ns each), so one per ray made this kernel 50 us of waiting for 4096 rays
@@ -1230,7 +1278,7 @@ distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weig
         const float Wgt = W - Wlt - wi, WUgt = WU - WUlt - wi * ui;
         const float Si = ui * (Wlt - Wgt) - (WUlt - WUgt);
         if (live) {
-            gw[ray * n + i] = 2.0f * Si + 2.0f * wi * di / 3.0f;
+            gw[ray * n + i] = scale * (2.0f * Si + 2.0f * wi * di / 3.0f);
             loss += wi * Si + wi * wi * di / 3.0f;
         }
         cW += __shfl(iw, 63, 64);
@@ -1241,7 +1289,7 @@ distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weig
     loss_acc = wave_sum(loss_acc);
     if (lane == 0) red[threadIdx.x >> 6] = loss_acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f32(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) atomic_add_f32(loss_sum, scale * ((red[0] + red[1]) + (red[2] + red[3])));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1260,7 +1308,7 @@ __device__ __forceinline__ int upper_bound(const float *a, int len, float x) {  
 
 __global__ void __launch_bounds__(kBlock)
 interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, const float *__restrict__ cp,
-                  const float *__restrict__ wp, long long R, int n, int p, float *__restrict__ loss_sum,
+                  const float *__restrict__ wp, long long R, int n, int p, float scale, float *__restrict__ loss_sum,
                   float *__restrict__ g_wp) {
     extern __shared__ float lds[];
     __shared__ float red[kBlock / 64];  // one atomic on loss_sum per block (see distortion_kernel)
@@ -1313,7 +1361,7 @@ interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, cons
         const float vl = k < p ? dlo[k + 1] : 0.0f;  // shifted by one: sum_{j >= k} dlo[j + 1] = sum_{l > k} dlo[l]
         const float rh = wave_incl_scan_rev(vh, lane);
         const float rl = wave_incl_scan_rev(vl, lane);
-        if (k < p) g_wp[ray * p + k] = (s_hi + rh) - (s_lo + rl);
+        if (k < p) g_wp[ray * p + k] = scale * ((s_hi + rh) - (s_lo + rl));
         s_hi += __shfl(rh, 0, 64);
         s_lo += __shfl(rl, 0, 64);
     }
@@ -1324,7 +1372,7 @@ interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, cons
     loss_acc = wave_sum(loss_acc);
     if (lane == 0) red[wave] = loss_acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f32(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) atomic_add_f32(loss_sum, scale * ((red[0] + red[1]) + (red[2] + red[3])));
 }
 
 }  // namespace
@@ -1509,11 +1557,19 @@ int tn_linear_chain_bwd(const tn_chain_layer *layers, int32_t num_layers, const 
         hipLaunchKernelGGL(linear_chain_bwd_kernel<3>, dim3(blocks), dim3(kBlock), smem, st, a);
     }
     TN_LAUNCH_CHECK();
-    for (int j = 0; j < num_layers; ++j) {
-        if (!layers[j].d_weight && !layers[j].d_bias) continue;
-        hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(65, kRedSplit), dim3(kBlock), 0, st,
-                           a.partials + (size_t)j * blocks * 65 * 64, blocks, 64, layers[j].lin.in_dim, layers[j].lin.out_dim,
-                           layers[j].d_weight, layers[j].d_bias);
+    RedChainArgs ra;
+    bool any = false;
+    for (int j = 0; j < kChainMax; ++j) {
+        const bool on = j < num_layers;
+        ra.partials[j] = a.partials + (size_t)j * blocks * 65 * 64;
+        ra.dW[j] = on ? layers[j].d_weight : nullptr;
+        ra.db[j] = on ? layers[j].d_bias : nullptr;
+        ra.IN[j] = on ? layers[j].lin.in_dim : 0;
+        ra.OUT[j] = on ? layers[j].lin.out_dim : 0;
+        any = any || ra.dW[j] || ra.db[j];
+    }
+    if (any) {
+        hipLaunchKernelGGL(linear_bwd_reduce_chain_kernel, dim3(65, kRedSplit, num_layers), dim3(kBlock), 0, st, ra, blocks);
         TN_LAUNCH_CHECK();
     }
     return TN_OK;
@@ -1531,12 +1587,12 @@ int tn_density_act_fwd(const float *raw, int32_t ld_raw, const float *selector, 
 }
 
 int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density,
-                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, void *stream) {
+                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, int32_t clear_cols, void *stream) {
     if (n == 0) return TN_OK;
     if (!raw || !selector || !d_density || !d_raw) return TN_ERR_NULL;
-    if (n < 0 || ld_raw < 1 || ld_d_raw < 1) return TN_ERR_SHAPE;
+    if (n < 0 || ld_raw < 1 || ld_d_raw < 1 || clear_cols < 0 || clear_cols > ld_d_raw) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(density_act_bwd_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, raw,
-                       ld_raw, selector, average_init_density, d_density, (long long)n, d_raw, ld_d_raw);
+                       ld_raw, selector, average_init_density, d_density, (long long)n, d_raw, ld_d_raw, clear_cols);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -1662,26 +1718,26 @@ int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const 
     return TN_OK;
 }
 
-int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float *loss_sum,
-                       float *d_weights, void *stream) {
+int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float scale,
+                       float *loss_sum, float *d_weights, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!spacing_bins || !weights || !loss_sum || !d_weights) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(distortion_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), 0, (hipStream_t)stream,
-                       spacing_bins, weights, (long long)num_rays, n, loss_sum, d_weights);
+                       spacing_bins, weights, (long long)num_rays, n, scale, loss_sum, d_weights);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
 
 int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
-                       int32_t p, float *loss_sum, float *d_wp, void *stream) {
+                       int32_t p, float scale, float *loss_sum, float *d_wp, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!c || !w || !cp || !wp || !loss_sum || !d_wp) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1 || p < 1 || p > kMaxP) return TN_ERR_SHAPE;
     const size_t lds = (size_t)(kBlock / 64) * 4 * (p + 2) * sizeof(float);
     if (lds > 48 * 1024 && !tn_ensure_dynamic_lds<interlevel_kernel>(lds)) return TN_ERR_LAUNCH;
     hipLaunchKernelGGL(interlevel_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), lds, (hipStream_t)stream, c, w,
-                       cp, wp, (long long)num_rays, n, p, loss_sum, d_wp);
+                       cp, wp, (long long)num_rays, n, p, scale, loss_sum, d_wp);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

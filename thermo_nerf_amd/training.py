@@ -202,7 +202,7 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
     g_raw = _f32((n, 1), g_w.device)
     _hip.check(lib.tn_density_act_bwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density,
-                                      g_density.data_ptr(), n, g_raw.data_ptr(), 1, _stream()), "tn_density_act_bwd")
+                                      g_density.data_ptr(), n, g_raw.data_ptr(), 1, 0, _stream()), "tn_density_act_bwd")
     names = [f"{prefix}.mlp_base.encoder.hash_table", f"{prefix}.mlp_base.mlp.layers.0.weight",
              f"{prefix}.mlp_base.mlp.layers.0.bias", f"{prefix}.mlp_base.mlp.layers.1.weight",
              f"{prefix}.mlp_base.mlp.layers.1.bias"]
@@ -425,9 +425,9 @@ class RenderTrain(torch.autograd.Function):
             _hip.check(lib.tn_gradient_scale_bwd(starts.data_ptr(), ends.data_ptr(), N, g_density.data_ptr(), _hip.ptr(g_rgb_s),
                                                  _hip.ptr(g_th_s), _stream()), "tn_gradient_scale_bwd")
         ldb = bo.shape[1]
-        g_bo = torch.zeros((N, ldb), dtype=torch.float32, device=dev)
+        g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass
         _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density,
-                                          g_density.data_ptr(), N, g_bo.data_ptr(), ldb, _stream()), "tn_density_act_bwd")
+                                          g_density.data_ptr(), N, g_bo.data_ptr(), ldb, ldb, _stream()), "tn_density_act_bwd")
         W = 64
         chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
         if g_th_s is not None:  # thermal branch [REF thermal_field.py:170-179]
@@ -502,10 +502,11 @@ class _Distortion(torch.autograd.Function):
         b = _hip.require_device_tensor(spacing_bins, "spacing_bins")
         loss = torch.zeros((1,), dtype=torch.float32, device=w.device)
         g = _f32((R, n), w.device)
-        _hip.check(_hip.load().tn_distortion_loss(b.data_ptr(), w.data_ptr(), R, n, loss.data_ptr(), g.data_ptr(), _stream()),
-                   "tn_distortion_loss")
-        ctx.g, ctx.shape = g / R, weights.shape
-        return loss[0] / R
+        # the mean over rays is applied inside the kernel (loss and gradient): no elementwise launches around it
+        _hip.check(_hip.load().tn_distortion_loss(b.data_ptr(), w.data_ptr(), R, n, 1.0 / R, loss.data_ptr(), g.data_ptr(),
+                                                  _stream()), "tn_distortion_loss")
+        ctx.g, ctx.shape = g, weights.shape
+        return loss[0]
 
     @staticmethod
     def backward(ctx, go):
@@ -513,23 +514,34 @@ class _Distortion(torch.autograd.Function):
 
 
 class _Interlevel(torch.autograd.Function):
+    """Both proposal levels of NS interlevel_loss in one Function: apply(w, c, wp_0, cp_0, wp_1, cp_1, ...) — the levels'
+    kernels add into one loss scalar, each already scaled by 1 / (R n)."""
+
     @staticmethod
-    def forward(ctx, wp: Tensor, cp: Tensor, w: Tensor, c: Tensor):
-        R, p = wp.shape[0], wp.shape[1]
-        n = w.shape[1]
-        wp2 = _hip.require_device_tensor(wp.reshape(R, p), "proposal weights")
+    def forward(ctx, w: Tensor, c: Tensor, *levels: Tensor):
+        R, n = w.shape[0], w.shape[1]
         w2 = _hip.require_device_tensor(w.reshape(R, n), "weights")
-        cp2, c2 = _hip.require_device_tensor(cp, "proposal bins"), _hip.require_device_tensor(c, "bins")
-        loss = torch.zeros((1,), dtype=torch.float32, device=wp2.device)
-        g = _f32((R, p), wp2.device)
-        _hip.check(_hip.load().tn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), cp2.data_ptr(), wp2.data_ptr(), R, n, p,
-                                                  loss.data_ptr(), g.data_ptr(), _stream()), "tn_interlevel_loss")
-        ctx.g, ctx.shape = g / (R * n), wp.shape
-        return loss[0] / (R * n)
+        c2 = _hip.require_device_tensor(c, "bins")
+        loss = torch.zeros((1,), dtype=torch.float32, device=w2.device)
+        lib = _hip.load()
+        ctx.g, ctx.shapes = [], []
+        for wp, cp in zip(levels[0::2], levels[1::2]):
+            p = wp.shape[1]
+            wp2 = _hip.require_device_tensor(wp.reshape(R, p), "proposal weights")
+            cp2 = _hip.require_device_tensor(cp, "proposal bins")
+            g = _f32((R, p), wp2.device)
+            _hip.check(lib.tn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), cp2.data_ptr(), wp2.data_ptr(), R, n, p, 1.0 / (R * n),
+                                              loss.data_ptr(), g.data_ptr(), _stream()), "tn_interlevel_loss")
+            ctx.g.append(g)
+            ctx.shapes.append(wp.shape)
+        return loss[0]
 
     @staticmethod
     def backward(ctx, go):
-        return (go * ctx.g).view(ctx.shape), None, None, None
+        out = [None, None]
+        for g, shape in zip(ctx.g, ctx.shapes):
+            out += [(go * g).view(shape), None]
+        return tuple(out)
 
 
 def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) -> Tensor:
@@ -541,11 +553,10 @@ def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) 
     """NS losses.interlevel_loss: final level detached, one term per proposal level."""
     c = ray_samples_list[-1].spacing_bins.detach()
     w = weights_list[-1].detach()
-    loss = None
+    levels = []
     for s, wp in zip(ray_samples_list[:-1], weights_list[:-1]):
-        term = _Interlevel.apply(wp, s.spacing_bins, w, c)
-        loss = term if loss is None else loss + term
-    return loss
+        levels += [wp, s.spacing_bins]
+    return _Interlevel.apply(w, c, *levels)
 
 
 # --------------------------------------------------------------------------------------------------
