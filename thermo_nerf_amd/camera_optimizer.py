@@ -51,11 +51,14 @@ class _ApplyPoseAdjustment(torch.autograd.Function):
                                                  pose.shape[0], out_o.data_ptr(), out_d.data_ptr(), _hip.current_stream()),
                    "tn_camera_opt_fwd")
         ctx.save_for_backward(pose, cam, d)
+        ctx.set_materialize_grads(False)
         return out_o, out_d
 
     @staticmethod
     def backward(ctx, g_o, g_d):
         pose, cam, d = ctx.saved_tensors
+        if g_o is None and g_d is None:
+            return None, None, None, None
         g_o = None if g_o is None else _hip.require_device_tensor(g_o, "d origins")
         g_d = None if g_d is None else _hip.require_device_tensor(g_d, "d directions")
         d_pose = torch.zeros_like(pose)

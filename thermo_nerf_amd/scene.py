@@ -40,12 +40,17 @@ class NearFarCollider(nn.Module):
         self.near_plane = near_plane
         self.far_plane = far_plane
         self.reset_near_plane = reset_near_plane
+        self._last = None  # (key, nears, fars): the two constant planes of the previous call, reused when nothing changed
 
     def set_nears_and_fars(self, ray_bundle: RayBundle) -> RayBundle:
         near = self.near_plane if (self.training or not self.reset_near_plane) else 0.0
         shape = (*ray_bundle.origins.shape[:-1], 1)
-        ray_bundle.nears = torch.full(shape, float(near), dtype=torch.float32, device=ray_bundle.origins.device)
-        ray_bundle.fars = torch.full(shape, float(self.far_plane), dtype=torch.float32, device=ray_bundle.origins.device)
+        key = (shape, float(near), float(self.far_plane), ray_bundle.origins.device)
+        if self._last is None or self._last[0] != key:
+            # constant tensors, read-only downstream: a training loop asks for the same two every step
+            self._last = (key, torch.full(shape, float(near), dtype=torch.float32, device=ray_bundle.origins.device),
+                          torch.full(shape, float(self.far_plane), dtype=torch.float32, device=ray_bundle.origins.device))
+        ray_bundle.nears, ray_bundle.fars = self._last[1], self._last[2]
         return ray_bundle
 
     def forward(self, ray_bundle: RayBundle) -> RayBundle:

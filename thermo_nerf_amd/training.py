@@ -362,6 +362,7 @@ class RenderTrain(torch.autograd.Function):
                                         pd.data_ptr(), None, None, _stream()), "tn_depth_fwd")
             prop_depths.append(pd)
 
+        ctx.set_materialize_grads(False)  # outputs nobody differentiates arrive as None in backward, not as zero tensors
         ctx.model, ctx.tapes, ctx.field_tape = model, tapes, f
         ctx.acts = (h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s)
         ctx.acc, ctx.o, ctx.d, ctx.cam = acc, o, d, cam
