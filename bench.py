@@ -76,7 +76,8 @@ def parse():
                     help="rays per launch = eval_num_rays_per_chunk; 0 (default) = the whole frame in one launch pair "
                          "(--shard frame: 65 536, the reference config)")
     ap.add_argument("--weights", default="scene", choices=["init", "stress", "scene"])
-    ap.add_argument("--dense-mb", type=int, default=0)
+    ap.add_argument("--dense-mb", type=int, default=64, help="config.dense_grid_budget_mb (default = the config's default)")
+    ap.add_argument("--field-dense-mb", type=int, default=16, help="config.field_dense_grid_budget_mb")
     ap.add_argument("--no-mfma", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="MLP product arithmetic of the field kernel (f16x3 = three f16 MFMA products per fp32 product)")
@@ -253,7 +254,7 @@ def build_render(dev, S, chunk, args, want_cpu_sd=False, streams=None):
     from thermo_nerf_amd.engine import RayRenderEngine
 
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=chunk,
-                                 dense_grid_budget_mb=args.dense_mb, use_mfma=not args.no_mfma,
+                                 dense_grid_budget_mb=args.dense_mb, field_dense_grid_budget_mb=args.field_dense_mb, use_mfma=not args.no_mfma,
                                  mlp_precision=args.precision, early_termination_eps=args.early_eps)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box

@@ -654,6 +654,39 @@ def test_uniform_initial_sampler(form, far):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
+def test_dense_relayout_is_bit_identical(precision, family):
+    """dense_grid_budget_mb / field_dense_grid_budget_mb (on by default): the dense copies of the leading levels hold the
+    same values as the hashed tables, and the kernels do the same arithmetic on them — every output is identical to the
+    hashed-table render, on the full-size grids (where the lane = ray field kernels read 6 levels densely)."""
+    gm, sd, ocfg = gpu_model("scene", 64, small=False, family=family)
+    gm.config.mlp_precision = precision
+    assert gm.config.dense_grid_budget_mb > 0 and gm.config.field_dense_grid_budget_mb > 0
+    assert gm.field.dense_budget_bytes > 0 and gm.proposal_networks[0].dense_budget_bytes > 0
+    o, d = helpers.rays(24, 24, view=2)
+    with torch.no_grad():
+        dense = {k: v.clone() for k, v in gm(bundle(o, d)).items()}
+        assert gm.field.c_struct(prepare=True).grid.num_dense_levels >= 6
+        assert gm.proposal_networks[0].c_struct().grid.num_dense_levels == 5
+        assert gm.proposal_networks[1].c_struct().grid.num_dense_levels == 4
+        budgets = (gm.field.dense_budget_bytes, [n.dense_budget_bytes for n in gm.proposal_networks])
+        gm.field.dense_budget_bytes = 0
+        for n in gm.proposal_networks:
+            n.dense_budget_bytes = 0
+        gm.invalidate_prepared()
+        hashed = gm(bundle(o, d))
+        assert gm.field.c_struct(prepare=True).grid.num_dense_levels == 0
+        gm.field.dense_budget_bytes = budgets[0]
+        for n, b in zip(gm.proposal_networks, budgets[1]):
+            n.dense_budget_bytes = b
+        gm.invalidate_prepared()
+    for k in ("rgb", "thermal", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1"):
+        assert torch.equal(dense[k], hashed[k]), k
+    if precision == "f32":
+        check_outputs(dense, H.get_outputs(sd, o, d, None, ocfg), f"dense default, {family}")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_small_calls_take_the_ray_per_wave_kernels(precision):
     """Automatic dispatch: below ~60-80 k rays the one-ray-per-wave kernels run (a 64-ray tile marches serially, so the
     lane = ray kernels have a ~2.6 ms floor).  Same oracle tolerances; with f16x3 a small call is served in exact fp32."""

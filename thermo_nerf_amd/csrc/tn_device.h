@@ -157,18 +157,27 @@ __device__ __forceinline__ float2 encode_level(const Grid &g, int l, float px, f
     if (DENSE) {
         // dense[x][y][z] = table[hash(x,y,z)]; ceil corner == floor+1 whenever its weight is non-zero
         const int res = g.dense_res[l];
-        const float2 *d = g.dense + g.dense_off[l];
-        const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
-        const int i00 = (fx * res + fy) * res + fz;
-        const int i10 = i00 + res * res;  // x+1
-        const int i01 = i00 + res;        // y+1
-        const int i11 = i10 + res;
-        // z is the fastest axis: the (.,.,f) and (.,.,c) corners are one 16-byte (8-byte aligned) load
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-        const f4u v00 = *reinterpret_cast<const f4u *>(d + i00);
-        const f4u v01 = *reinterpret_cast<const f4u *>(d + i01);
-        const f4u v10 = *reinterpret_cast<const f4u *>(d + i10);
-        const f4u v11 = *reinterpret_cast<const f4u *>(d + i11);
+        const float4 *d = reinterpret_cast<const float4 *>(g.dense) + g.dense_off[l];
+        // every dense element is the pair (entry(z), entry(z+1)): the (.,.,f) and (.,.,c) corners are ONE aligned 16-byte load
+        float4 v00, v01, v10, v11;
+        if (FAST) {
+            // 32-bit byte offsets from a wave-uniform level base (scalar-base global_load), 24-bit multiplies (side <= 1024)
+            const unsigned ures = (unsigned)res;
+            const unsigned i00 = __umul24(__umul24((unsigned)(int)fxf, ures) + (unsigned)(int)fyf, ures) + (unsigned)(int)fzf;
+            const unsigned b00 = i00 << 4, sy = ures << 4, sx = __umul24(ures, ures) << 4;
+            const char *db = reinterpret_cast<const char *>(d);
+            v00 = *reinterpret_cast<const float4 *>(db + b00);
+            v01 = *reinterpret_cast<const float4 *>(db + (b00 + sy));
+            v10 = *reinterpret_cast<const float4 *>(db + (b00 + sx));
+            v11 = *reinterpret_cast<const float4 *>(db + (b00 + sx + sy));
+        } else {
+            const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
+            const int i00 = (fx * res + fy) * res + fz;
+            const int i10 = i00 + res * res;  // x+1
+            const int i01 = i00 + res;        // y+1
+            const int i11 = i10 + res;
+            v00 = d[i00]; v01 = d[i01]; v10 = d[i10]; v11 = d[i11];
+        }
         f6 = make_float2(v00.x, v00.y);  // (f,f,f)
         f2 = make_float2(v00.z, v00.w);  // (f,f,c)
         f7 = make_float2(v01.x, v01.y);  // (f,c,f)
@@ -276,6 +285,40 @@ __device__ __forceinline__ void hash_gather(const G &g, int l, const HashTaps &t
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2 *>(tb + t.off[k]);
 }
+// How many leading levels the lane = ray field kernels read from the dense re-layout when the grid carries at least that
+// many (6 levels of the reference's 16-level grid = 14.5 MB; 4 / 8 / 10 levels measured within 0.3 % of it).
+#ifndef TN_FIELD_DENSE_LEVELS
+#define TN_FIELD_DENSE_LEVELS 6
+#endif
+constexpr int kFieldDense = TN_FIELD_DENSE_LEVELS;
+
+// The same two stages for a level of the DENSE re-layout (elements = aligned (entry(z), entry(z+1)) pairs): four byte offsets,
+// four 16-byte gathers, landing in the f0..f7 order of the hashed form.
+template <typename G>
+__device__ __forceinline__ void dense_taps(const G &g, int l, float px, float py, float pz, HashTaps &t) {
+    const float s = g.scal[l];
+    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+    t.ox = __builtin_amdgcn_fractf(sx);
+    t.oy = __builtin_amdgcn_fractf(sy);
+    t.oz = __builtin_amdgcn_fractf(sz);
+    const unsigned ures = (unsigned)g.dense_res[l];
+    const unsigned i00 = __umul24(__umul24((unsigned)(int)sx, ures) + (unsigned)(int)sy, ures) + (unsigned)(int)sz;
+    const unsigned b00 = i00 << 4, dy = ures << 4, dx = __umul24(ures, ures) << 4;
+    t.off[0] = b00;            // (x0, y0): f6 | f2
+    t.off[1] = b00 + dy;       // (x0, y1): f7 | f3
+    t.off[2] = b00 + dx;       // (x1, y0): f5 | f1
+    t.off[3] = b00 + dx + dy;  // (x1, y1): f4 | f0
+}
+template <typename G>
+__device__ __forceinline__ void dense_gather(const G &g, int l, const HashTaps &t, float2 (&f)[8]) {
+    const char *db = reinterpret_cast<const char *>(reinterpret_cast<const float4 *>(g.dense) + g.dense_off[l]);
+    const float4 v00 = *reinterpret_cast<const float4 *>(db + t.off[0]), v01 = *reinterpret_cast<const float4 *>(db + t.off[1]);
+    const float4 v10 = *reinterpret_cast<const float4 *>(db + t.off[2]), v11 = *reinterpret_cast<const float4 *>(db + t.off[3]);
+    f[6] = make_float2(v00.x, v00.y); f[2] = make_float2(v00.z, v00.w);
+    f[7] = make_float2(v01.x, v01.y); f[3] = make_float2(v01.z, v01.w);
+    f[5] = make_float2(v10.x, v10.y); f[1] = make_float2(v10.z, v10.w);
+    f[4] = make_float2(v11.x, v11.y); f[0] = make_float2(v11.z, v11.w);
+}
 // Pins the interpolation of a level BELOW the point where this is called: the interpolation weights pass through an opaque
 // asm, so the (pure) arithmetic that reads them cannot be placed earlier — without it instruction selection emits each
 // level's interpolation right behind its own eight gathers and the load queue drains once per level.
@@ -303,27 +346,35 @@ __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f
 // g+1 are issued before group g is interpolated, so two groups (2 x 8*LG gathers, <= 64 = the vmcnt range) are in flight and
 // the memory round trip is paid about once per position instead of once per level.  Levels base .. base+NL-1;
 // emit(level - base, features) is called in level order.  Values are those of encode_level<false, true>, bit for bit.
-template <int NL, int LG, typename G, typename Emit>
+// ND > 0 (with base == 0): levels 0 .. ND-1 are read from the dense re-layout (a compile-time split: a run-time branch between
+// the stages would cost the exact wait counts the pipelining lives on).
+template <int NL, int LG, int ND = 0, typename G, typename Emit>
 __device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, float py, float pz, Emit emit, int base = 0) {
     static_assert(NL % LG == 0 && 16 * LG <= 64, "two groups of 8*LG gathers must fit the 6-bit vmcnt counter");
     constexpr int NG = NL / LG;
     HashTaps taps[2][LG];
     float2 fv[2][LG][8];
+    auto taps_of = [&](int lvl, HashTaps &t) {  // lvl is a constant after unrolling
+        if (lvl < ND) dense_taps(g, lvl, px, py, pz, t); else hash_taps(g, base + lvl, px, py, pz, t);
+    };
+    auto gather_of = [&](int lvl, const HashTaps &t, float2 (&f)[8]) {
+        if (lvl < ND) dense_gather(g, lvl, t, f); else hash_gather(g, base + lvl, t, f);
+    };
 #pragma unroll
-    for (int q = 0; q < LG; ++q) hash_taps(g, base + q, px, py, pz, taps[0][q]);
+    for (int q = 0; q < LG; ++q) taps_of(q, taps[0][q]);
     TN_STAGE_FENCE();
 #pragma unroll
-    for (int q = 0; q < LG; ++q) hash_gather(g, base + q, taps[0][q], fv[0][q]);
+    for (int q = 0; q < LG; ++q) gather_of(q, taps[0][q], fv[0][q]);
     TN_STAGE_FENCE();
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
         const int cur = gi & 1, nxt = cur ^ 1;
         if (gi + 1 < NG) {
 #pragma unroll
-            for (int q = 0; q < LG; ++q) hash_taps(g, base + (gi + 1) * LG + q, px, py, pz, taps[nxt][q]);
+            for (int q = 0; q < LG; ++q) taps_of((gi + 1) * LG + q, taps[nxt][q]);
             TN_STAGE_FENCE();
 #pragma unroll
-            for (int q = 0; q < LG; ++q) hash_gather(g, base + (gi + 1) * LG + q, taps[nxt][q], fv[nxt][q]);
+            for (int q = 0; q < LG; ++q) gather_of((gi + 1) * LG + q, taps[nxt][q], fv[nxt][q]);
         }
 #pragma unroll
         for (int q = 0; q < LG; ++q) hash_hold(taps[cur][q]);  // group gi is interpolated below group gi+1's gathers

@@ -7,13 +7,15 @@
 
 namespace {
 
-__global__ void dense_fill_kernel(const float2 *__restrict__ table, unsigned mask, int res, float2 *__restrict__ dense) {
+__global__ void dense_fill_kernel(const float2 *__restrict__ table, unsigned mask, int res, float4 *__restrict__ dense) {
     const long long n = (long long)res * res * res;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const unsigned z = (unsigned)(i % res);
         const unsigned y = (unsigned)((i / res) % res);
         const unsigned x = (unsigned)(i / ((long long)res * res));
-        dense[i] = table[(x ^ (y * TN_P1) ^ (z * TN_P2)) & mask];
+        // an entry and its z-neighbour as one aligned 16-byte piece (every entry is stored twice: no unaligned pair loads)
+        const float2 a = table[(x ^ (y * TN_P1) ^ (z * TN_P2)) & mask], b = table[(x ^ (y * TN_P1) ^ ((z + 1) * TN_P2)) & mask];
+        dense[i] = make_float4(a.x, a.y, b.x, b.y);
     }
 }
 
@@ -24,7 +26,7 @@ int plan_dense(const tn_hashgrid *g, long long max_bytes, long long *offsets, in
     for (int l = 0; l < g->num_levels; ++l) {
         const long long side = (long long)g->scalings[l] + 2;
         const long long elems = side * side * side;
-        if ((off + elems) * 8 > max_bytes || side > 1024) break;
+        if ((off + elems) * 16 > max_bytes || side > 1024) break;
         offsets[l] = off;
         res[l] = (int)side;
         off += elems;
@@ -44,7 +46,7 @@ size_t tn_hashgrid_prepare_bytes(const tn_hashgrid *grid, int64_t max_bytes) {
     int res[TN_MAX_LEVELS];
     long long total = 0;
     plan_dense(grid, max_bytes, offsets, res, &total);
-    return (size_t)total * 8;
+    return (size_t)total * 16;
 }
 
 int tn_hashgrid_prepare(const tn_hashgrid *grid_in, tn_hashgrid *grid_out, void *dense_dev, size_t dense_bytes,
@@ -64,7 +66,7 @@ int tn_hashgrid_prepare(const tn_hashgrid *grid_in, tn_hashgrid *grid_out, void 
         const unsigned mask = (1u << grid_in->log2_hashmap_size) - 1u;
         for (int l = 0; l < nd; ++l) {
             const float2 *table = reinterpret_cast<const float2 *>(grid_in->table) + ((size_t)l << grid_in->log2_hashmap_size);
-            float2 *dst = reinterpret_cast<float2 *>(dense_dev) + offsets[l];
+            float4 *dst = reinterpret_cast<float4 *>(dense_dev) + offsets[l];
             const long long n = (long long)res[l] * res[l] * res[l];
             const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
             hipLaunchKernelGGL(dense_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, mask, res[l], dst);

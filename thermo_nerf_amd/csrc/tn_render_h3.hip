@@ -313,7 +313,21 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             // ---- hash grid -> two K=16 steps of B operands per N tile --------------------------------------
             HL e0[2], e1[2];  // [ks] for tile 0 / tile 1
-            if (a.g.num_dense == 0) {
+            if (a.g.num_dense >= kFieldDense) {
+                // the first kFieldDense (<= 8) levels from the dense re-layout: 4 aligned 16-byte gathers per level
+                static_assert(kFieldDense <= 8, "the dense levels sit in the first half");
+                float v[16];
+                hash_encode_pipelined<8, 2, kFieldDense>(a.g, px, py, pz, [&](int l, float2 f) {
+                    v[2 * l] = f.x;
+                    v[2 * l + 1] = f.y;
+                }, 0);
+                pack_step(v, e0[0], e1[0]);
+                hash_encode_pipelined<8, 2>(a.g, px, py, pz, [&](int l, float2 f) {
+                    v[2 * l] = f.x;
+                    v[2 * l + 1] = f.y;
+                }, 8);
+                pack_step(v, e0[1], e1[1]);
+            } else if (a.g.num_dense == 0) {
                 // hashed levels: index arithmetic | gathers | interpolation in explicit stages; two groups of 2 levels (2 x 16
                 // gathers) in flight — this kernel has ~30 fewer free VGPRs than the fp32 one
 #pragma unroll

@@ -563,20 +563,10 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                  frustum_pos(oz, dz, st, en), px, py, pz);
             float bt0[16], bt1[16];
-            if (!DENSE) {
-                // hashed levels: index arithmetic | gathers | interpolation in explicit stages, two groups of LG levels in flight
-                hash_encode_pipelined<L16, LG>(a.g, px, py, pz, [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });
-            } else {
-#pragma unroll
-                for (int l0 = 0; l0 < L16; l0 += LG) {
-                    float2 f[LG];
-#pragma unroll
-                    for (int q = 0; q < LG; ++q) f[q] = encode_level_any<true>(a.g, l0 + q, px, py, pz);
-#pragma unroll
-                    for (int q = 0; q < LG; ++q) swap32(f[q].x, f[q].y, bt0[l0 + q], bt1[l0 + q]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            // index arithmetic | gathers | interpolation in explicit stages, two groups of LG levels in flight; DENSE: the first
+            // kFieldDense levels come from the dense re-layout (4 aligned 16-byte gathers per level instead of 8 8-byte ones)
+            hash_encode_pipelined<L16, LG, DENSE ? kFieldDense : 0>(a.g, px, py, pz,
+                                                                    [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });
             f32x16 h1[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -908,7 +898,7 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     const bool small_call = cfg->kernel_family == 2 || (cfg->kernel_family == 0 && num_rays < 57344);
     if (!cfg->training && !out->weights[2] && !small_call) {
         // eval: lane = ray (64 consecutive rays per wave), coherent gathers
-        const bool dense = a.g.num_dense > 0;
+        const bool dense = a.g.num_dense >= kFieldDense;  // the dense variant reads exactly kFieldDense levels densely
         if (!(dense ? tn_ensure_dynamic_lds<main_mfma_rays_kernel<true>>(smem) : tn_ensure_dynamic_lds<main_mfma_rays_kernel<false>>(smem)))
             return TN_ERR_LAUNCH;
         const long long groups = (num_rays + 63) / 64;

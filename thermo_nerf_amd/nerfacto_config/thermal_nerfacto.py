@@ -74,8 +74,14 @@ class NerfactoModelConfig:
     """Training: let d loss / d directions flow through the SH basis.  False (default) = nerfstudio's torch fallback, whose
     SHEncoding.pytorch_fwd runs under @torch.no_grad() (SURVEY A.6): camera-pose gradients then come from the sample
     positions only.  True = the behaviour of a differentiable (tcnn) SH encoding."""
-    dense_grid_budget_mb: int = 0
-    """>0: re-lay the coarse hash levels densely within this budget (layout only, bit-identical)."""
+    dense_grid_budget_mb: int = 64
+    """>0: the proposal networks' eval kernels read their leading hash levels from a dense re-layout built within this budget
+    per network (dense[x][y][z] = (table[hash(x,y,z)], table[hash(x,y,z+1)]): layout only, bit-identical values; the two
+    z-corners of a cell are one aligned 16-byte load, so a level costs 4 gather instructions instead of 8).  64 MB holds 5
+    and 4 of the reference's 2 x 5 proposal levels (45 + 41 MB); rebuilt when the tables change; never used in training."""
+    field_dense_grid_budget_mb: int = 16
+    """The same for the main field's 16-level grid: 16 MB holds the 6 levels (14.5 MB) the lane = ray field kernels read
+    densely; a smaller budget leaves those kernels on the hashed tables."""
     use_mfma: bool = True
     """Use the MFMA form of the main-field kernel when the library provides it."""
     early_termination_eps: float = 0.0

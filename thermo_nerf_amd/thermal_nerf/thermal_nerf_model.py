@@ -81,7 +81,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
             use_transient_embedding=cfg.use_transient_embedding, pass_thermal_gradients=cfg.pass_thermal_gradients,
             sh_input=cfg.sh_input,
         )
-        self.field.dense_budget_bytes = budget
+        self.field.dense_budget_bytes = int(cfg.field_dense_grid_budget_mb) << 20
         self.camera_optimizer = cfg.camera_optimizer.setup(num_cameras=self.num_train_data, device="cpu")
 
         self.density_fns = []
