@@ -245,11 +245,21 @@ __global__ void prop_weights_kmajor_kernel(PropNet n0, PropNet n1, float *__rest
 // density of the 5-level / 16-hidden proposal net with the weights as SCALAR operands in k-major order: per input feature
 // eight packed FMAs (v_pk_fma_f32, SGPR-pair source) update the 16 hidden units.  Per hidden unit the accumulation order is
 // bias, then the features in level order — the order of hidden_from_grid: bit-identical results.
-template <bool FAST>
+// ND = levels read from the dense re-layout: a compile-time split (-1: by the grid's run-time count, level by level), so that
+// all of a sample's gathers are issued together and waited for with exact counts.
+template <bool FAST, int ND = -1>
 __device__ __forceinline__ float proposal_density_kmajor(const Grid &g, const tn_cfloat *wk, float avg, float px, float py,
                                                          float pz, float sel) {
     float2 f[5];
-    if (g.num_dense == 0) {
+    if (ND >= 0) {
+        // two groups (3 + 2 levels): all five levels' 16-byte gathers at once need more registers than 4 waves per SIMD leave
+        // (measured: 3 + 2 -> 3.87 ms per 640 k rays with a few spills; 2 + 2 + 1 without spills -> 4.13; all five -> 4.03)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);
+        if (ND > 0) TN_STAGE_FENCE();
+#pragma unroll
+        for (int l = 3; l < 5; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);
+    } else if (g.num_dense == 0) {
 #pragma unroll
         for (int l = 0; l < 5; ++l) f[l] = encode_level<false, FAST>(g, l, px, py, pz);
     } else {
@@ -331,6 +341,9 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     for (; j < nb; ++j) emit(j, b0);
 }
 
+// ND0 / ND1: dense levels of the two networks as compile-time constants (5, 4 = what the default 64 MB budget holds of the
+// reference's proposal grids), or -1 / -1 = whatever the grids carry, decided per level at run time.
+template <int ND0, int ND1>
 __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PropArgs &a = ra.p;
@@ -392,7 +405,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp0, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                            frustum_pos(oz, dz, st, en), px, py, pz);
-                const float dens = fast0 ? proposal_density_kmajor<true>(a.net[0].g, as_scalar(a.wk), a.net[0].avg, px, py, pz, sel)
+                const float dens = fast0 ? proposal_density_kmajor<true, ND0>(a.net[0].g, as_scalar(a.wk), a.net[0].avg, px, py, pz, sel)
                                          : proposal_density_eval<PH, 0, true>(a.net[0].g, w0, a.net[0].avg, px, py, pz, sel);
                 const float dd = mul_rn(sub_rn(en, st), dens);
                 const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
@@ -431,7 +444,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                 float px, py, pz;
                 const float sel = normalize_position<true>(sp1, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
                                                            frustum_pos(oz, dz, st, en), px, py, pz);
-                const float dens = fast1 ? proposal_density_kmajor<true>(a.net[1].g, as_scalar(a.wk + kPropWFloats), a.net[1].avg, px, py,
+                const float dens = fast1 ? proposal_density_kmajor<true, ND1>(a.net[1].g, as_scalar(a.wk + kPropWFloats), a.net[1].avg, px, py,
                                                                          pz, sel)
                                          : proposal_density_eval<PH, 0, true>(a.net[1].g, w1, a.net[1].avg, px, py, pz, sel);
                 const float dd = mul_rn(sub_rn(en, st), dens);
@@ -711,7 +724,14 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
                              sizeof(float);
         const long long need = ((long long)tiles + kWaves - 1) / kWaves;
         const unsigned grid = (unsigned)(need < 1024 ? (need < 1 ? 1 : need) : 1024);  // 4 workgroups (16 waves) per CU
-        hipLaunchKernelGGL(proposal_rays_kernel, dim3(grid), dim3(kBlock), rsmem, s, ra);
+        const int nd0 = pa.net[0].g.num_dense, nd1 = pa.net[1].g.num_dense;
+        const bool five = pa.net[0].g.num_levels == 5 && pa.net[1].g.num_levels == 5;
+        if (five && nd0 == 5 && nd1 == 4)
+            hipLaunchKernelGGL((proposal_rays_kernel<5, 4>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+        else if (nd0 == 0 && nd1 == 0)
+            hipLaunchKernelGGL((proposal_rays_kernel<0, 0>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+        else
+            hipLaunchKernelGGL((proposal_rays_kernel<-1, -1>), dim3(grid), dim3(kBlock), rsmem, s, ra);
         TN_LAUNCH_CHECK();
         return TN_OK;
     }
