@@ -1,4 +1,4 @@
-"""Static per-phase instruction counts of one pass (64 rays x 1 sample) of main_mfma_rays_kernel<false>: section markers
+"""Static per-phase instruction counts of one pass (64 rays x 1 sample) of main_mfma_rays_kernel (both forms): section markers
 (volatile asm comments at the anchors of the `timing` ablation) are compiled into the kernel, the ISA of the sample loop is
 split at the markers and VALU / MFMA / LDS / vector-memory / scalar instructions are counted per section.  The scheduler may
 move a few instructions across a marker; the totals match SQ_INSTS_* / pass of the PMC profiles within a few per cent.
@@ -41,9 +41,16 @@ def main():
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function",
                     "-Wno-undefined-internal", "-Wno-pass-failed", "-S", "--cuda-device-only", f"-I{CSRC}", tmp, "-o", out], check=True)
     text = open(out).read()
-    m = re.search(r"^_ZN12_GLOBAL__N_121main_mfma_rays_kernelILb0EEEvNS_8MfmaArgsE:.*?s_endpgm", text, re.S | re.M)
-    assert m, "kernel not found"
-    body = m.group(0).splitlines()
+    stamp = os.path.join(ROOT, "tools", ".head_stamp")
+    if os.path.exists(stamp):
+        print("# source at commit", open(stamp).read().strip())
+    for tag, sym, what in (("ILb1", "<true>", "the default: first 6 levels from the dense re-layout"), ("ILb0", "<false>", "all 16 levels hashed")):
+        m = re.search(r"^_ZN12_GLOBAL__N_121main_mfma_rays_kernel" + tag + r"EEEvNS_8MfmaArgsE:.*?s_endpgm", text, re.S | re.M)
+        assert m, "kernel not found"
+        report(m.group(0).splitlines(), f"main_mfma_rays_kernel{sym} ({what})")
+
+
+def report(body, title):
     counts = collections.OrderedDict()
     cur = None
     for line in body:
@@ -73,10 +80,7 @@ def main():
             c["vmem"] += 1
         elif op.startswith("s_"):
             c["salu"] += 1
-    print("# static instruction counts of ONE pass (64 rays x 1 sample) of main_mfma_rays_kernel<false>, by phase (tools/valu_count.py)")
-    stamp = os.path.join(ROOT, "tools", ".head_stamp")
-    if os.path.exists(stamp):
-        print("# source at commit", open(stamp).read().strip())
+    print(f"# static instruction counts of ONE pass (64 rays x 1 sample) of {title}, by phase (tools/valu_count.py)")
     print("phase,valu,of_which_cross_lane,of_which_quarter_rate,mfma,lds,vmem,salu")
     tot = collections.Counter()
     for i, (_, name) in enumerate(MARKS):
