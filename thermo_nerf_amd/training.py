@@ -569,6 +569,9 @@ def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = N
     if cfg.num_proposal_iterations != 2 or cfg.predict_normals or not cfg.use_single_jitter:
         raise NotImplementedError("the training path implements two proposal iterations, single jitter and no predicted "
                                   "normals (the reference configuration)")
+    # a fused optimizer may have stepped since the last forward without bumping parameter versions: the MFMA blob of the
+    # fused taped forward (and every other derived copy) is rebuilt from the current weights
+    model.invalidate_prepared()
     o = _hip.require_device_tensor(ray_bundle.origins, "origins")
     d = _hip.require_device_tensor(ray_bundle.directions, "directions")
     R, dev = o.shape[0], o.device
