@@ -343,7 +343,10 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
 
 // ND0 / ND1: dense levels of the two networks as compile-time constants (5, 4 = what the default 64 MB budget holds of the
 // reference's proposal grids), or -1 / -1 = whatever the grids carry, decided per level at run time.
-template <int ND0, int ND1>
+// LEAN = the eval default as compile-time facts (no jitter, piecewise spacing, anneal 1, scene contraction, both nets the
+// 5-level / 16-hidden shape, no per-level outputs): the run-time switches of the general form cost scalar registers
+// (spilled to lanes and read back per sample) and branches inside the sample loops.
+template <int ND0, int ND1, bool LEAN>
 __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PropArgs &a = ra.p;
@@ -361,10 +364,17 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
     for (int i = threadIdx.x; i <= S; i += blockDim.x) u2[i] = a.u2[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const Space sp0 = make_space(a.net[0].space), sp1 = make_space(a.net[1].space);
-    const bool fast0 = a.net[0].g.num_levels == 5, fast1 = a.net[1].g.num_levels == 5;
-    const bool jittered = a.jitter != nullptr;
-    const bool lin = a.lin != 0;
+    Space sp0 = make_space(a.net[0].space), sp1 = make_space(a.net[1].space);
+    if (LEAN) sp0.contraction = sp1.contraction = 1;
+    const bool fast0 = LEAN || a.net[0].g.num_levels == 5, fast1 = LEAN || a.net[1].g.num_levels == 5;
+    const bool jittered = !LEAN && a.jitter != nullptr;
+    const bool lin = !LEAN && a.lin != 0;
+    const float anneal = LEAN ? 1.0f : a.anneal;
+    float *const osp0 = LEAN ? nullptr : a.out_spacing[0], *const osp1 = LEAN ? nullptr : a.out_spacing[1];
+    float *const osp2 = LEAN ? nullptr : a.out_spacing[2];
+    float *const oeu0 = LEAN ? nullptr : a.out_eucl[0], *const oeu1 = LEAN ? nullptr : a.out_eucl[1];
+    float *const oeu2 = LEAN ? nullptr : a.out_eucl[2];
+    float *const ow0 = LEAN ? nullptr : a.out_w[0], *const ow1 = LEAN ? nullptr : a.out_w[1];
     const long long tiles = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
     for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += stride) {
@@ -395,8 +405,8 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
             bool found = false;
             float sb = edge0(0);
             float en = spacing_to_eucl<true>(sb, s_near, s_far, lin);
-            if (live && a.out_spacing[0]) a.out_spacing[0][r * (P0 + 1)] = sb;
-            if (live && a.out_eucl[0]) a.out_eucl[0][r * (P0 + 1)] = en;
+            if (live && osp0) osp0[r * (P0 + 1)] = sb;
+            if (live && oeu0) oeu0[r * (P0 + 1)] = en;
             for (int i = 0; i < P0; ++i) {
                 const float st = en;
                 sb = edge0(i + 1);
@@ -416,15 +426,15 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                     med0 = step;
                 }
                 wsc[(size_t)i * 64] = wi;
-                total += add_rn((a.anneal == 1.0f) ? wi : powf(wi, a.anneal), 0.01f);
-                if (live && a.out_w[0]) a.out_w[0][r * P0 + i] = wi;
-                if (live && a.out_spacing[0]) a.out_spacing[0][r * (P0 + 1) + i + 1] = sb;
-                if (live && a.out_eucl[0]) a.out_eucl[0][r * (P0 + 1) + i + 1] = en;
+                total += add_rn((anneal == 1.0f) ? wi : powf(wi, anneal), 0.01f);
+                if (live && ow0) ow0[r * P0 + i] = wi;
+                if (live && osp0) osp0[r * (P0 + 1) + i + 1] = sb;
+                if (live && oeu0) oeu0[r * (P0 + 1) + i + 1] = en;
             }
             if (!found) med0 = step;
         }
         // ================= PDF resample 0 -> P1 + 1 edges ===================================================
-        pdf_walk(wsc, P0, total, a.anneal, u1, jittered, jittered ? a.jitter[a.R + rc] / (float)(P1 + 1) : 0.0f, P1,
+        pdf_walk(wsc, P0, total, anneal, u1, jittered, jittered ? a.jitter[a.R + rc] / (float)(P1 + 1) : 0.0f, P1,
                  edge0, [&](int j, float v) { b1sc[(size_t)j * 64] = v; });
         // ================= level 1: P1 samples through proposal net 1 =====================================
         float med1 = 0.0f;
@@ -434,8 +444,8 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
             bool found = false;
             float sb = b1sc[0];
             float en = spacing_to_eucl<true>(sb, s_near, s_far, lin);
-            if (live && a.out_spacing[1]) a.out_spacing[1][r * (P1 + 1)] = sb;
-            if (live && a.out_eucl[1]) a.out_eucl[1][r * (P1 + 1)] = en;
+            if (live && osp1) osp1[r * (P1 + 1)] = sb;
+            if (live && oeu1) oeu1[r * (P1 + 1)] = en;
             for (int i = 0; i < P1; ++i) {
                 const float st = en;
                 sb = b1sc[(size_t)(i + 1) * 64];
@@ -456,20 +466,20 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs r
                     med1 = step;
                 }
                 wsc[(size_t)i * 64] = wi;
-                total += add_rn((a.anneal == 1.0f) ? wi : powf(wi, a.anneal), 0.01f);
-                if (live && a.out_w[1]) a.out_w[1][r * P1 + i] = wi;
-                if (live && a.out_spacing[1]) a.out_spacing[1][r * (P1 + 1) + i + 1] = sb;
-                if (live && a.out_eucl[1]) a.out_eucl[1][r * (P1 + 1) + i + 1] = en;
+                total += add_rn((anneal == 1.0f) ? wi : powf(wi, anneal), 0.01f);
+                if (live && ow1) ow1[r * P1 + i] = wi;
+                if (live && osp1) osp1[r * (P1 + 1) + i + 1] = sb;
+                if (live && oeu1) oeu1[r * (P1 + 1) + i + 1] = en;
             }
             if (!found) med1 = step;
         }
         // ================= PDF resample 1 -> S + 1 final edges (ray-tiled workspace) ========================
-        pdf_walk(wsc, P1, total, a.anneal, u2, jittered, jittered ? a.jitter[2 * a.R + rc] / (float)(S + 1) : 0.0f, S,
+        pdf_walk(wsc, P1, total, anneal, u2, jittered, jittered ? a.jitter[2 * a.R + rc] / (float)(S + 1) : 0.0f, S,
                  [&](int j) -> float { return b1sc[(size_t)j * 64]; },
                  [&](int j, float v) {
                      fin[(size_t)j * 64] = v;
-                     if (live && a.out_spacing[2]) a.out_spacing[2][r * (S + 1) + j] = v;
-                     if (live && a.out_eucl[2]) a.out_eucl[2][r * (S + 1) + j] = spacing_to_eucl<true>(v, s_near, s_far, lin);
+                     if (live && osp2) osp2[r * (S + 1) + j] = v;
+                     if (live && oeu2) oeu2[r * (S + 1) + j] = spacing_to_eucl<true>(v, s_near, s_far, lin);
                  });
         if (live) {
             if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
@@ -726,12 +736,19 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         const unsigned grid = (unsigned)(need < 1024 ? (need < 1 ? 1 : need) : 1024);  // 4 workgroups (16 waves) per CU
         const int nd0 = pa.net[0].g.num_dense, nd1 = pa.net[1].g.num_dense;
         const bool five = pa.net[0].g.num_levels == 5 && pa.net[1].g.num_levels == 5;
-        if (five && nd0 == 5 && nd1 == 4)
-            hipLaunchKernelGGL((proposal_rays_kernel<5, 4>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+        bool lean = five && !pa.jitter && !pa.lin && pa.anneal == 1.0f && pa.net[0].space.contraction && pa.net[1].space.contraction &&
+                    !pa.out_w[0] && !pa.out_w[1];
+        for (int i = 0; i < 3; ++i) lean = lean && !pa.out_spacing[i] && !pa.out_eucl[i];
+        if (five && nd0 == 5 && nd1 == 4 && lean)
+            hipLaunchKernelGGL((proposal_rays_kernel<5, 4, true>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+        else if (five && nd0 == 5 && nd1 == 4)
+            hipLaunchKernelGGL((proposal_rays_kernel<5, 4, false>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+        else if (nd0 == 0 && nd1 == 0 && lean)
+            hipLaunchKernelGGL((proposal_rays_kernel<0, 0, true>), dim3(grid), dim3(kBlock), rsmem, s, ra);
         else if (nd0 == 0 && nd1 == 0)
-            hipLaunchKernelGGL((proposal_rays_kernel<0, 0>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+            hipLaunchKernelGGL((proposal_rays_kernel<0, 0, false>), dim3(grid), dim3(kBlock), rsmem, s, ra);
         else
-            hipLaunchKernelGGL((proposal_rays_kernel<-1, -1>), dim3(grid), dim3(kBlock), rsmem, s, ra);
+            hipLaunchKernelGGL((proposal_rays_kernel<-1, -1, false>), dim3(grid), dim3(kBlock), rsmem, s, ra);
         TN_LAUNCH_CHECK();
         return TN_OK;
     }

@@ -92,11 +92,23 @@ void rung(float *table, unsigned log2e) {
            adds / ms / 1e6, adds / GROUP / ms / 1e6);
 }
 
-int main() {
-    const unsigned log2e = 23;  // 8 M entries x 8 B = 64 MB (16 levels x 2^19)
+int main(int argc, char **argv) {
     float *table; unsigned *census;
-    CK(hipMalloc(&table, (size_t)8 << log2e));
+    CK(hipMalloc(&table, (size_t)8 << 23));
     CK(hipMalloc(&census, 4));
+    if (argc > 1) {
+        // L2-residency sweep: table of 2^log2e entries x 8 B, whole or sliced by XCD (slice = table / 8)
+        for (int i = 1; i < argc; ++i) {
+            const unsigned log2e = (unsigned)atoi(argv[i]);
+            printf("-- table 2^%u entries = %.2f MB (%.2f MB per XCD slice)\n", log2e, (double)(8u << log2e) / 1048576.0, (double)(1u << log2e) / 1048576.0);
+            run<1, false>("agent scope, whole table", table, log2e, census);
+            run<2, false>("workgroup scope, whole table", table, log2e, census);
+            run<1, true>("agent scope, XCD-partitioned", table, log2e, census);
+            run<2, true>("workgroup scope, XCD-partitioned", table, log2e, census);
+        }
+        return 0;
+    }
+    const unsigned log2e = 23;  // 8 M entries x 8 B = 64 MB (16 levels x 2^19)
     run<0, false>("unsafeAtomicAdd, whole table", table, log2e, census);
     run<1, false>("agent scope, whole table", table, log2e, census);
     run<2, false>("workgroup scope, whole table", table, log2e, census);

@@ -38,7 +38,7 @@ def main():
     tmp = "/tmp/valu_count_dir/valu_count.hip"
     open(tmp, "w").write(src[:a] + k + src[b:])
     out = "/tmp/valu_count.s"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-function",
                     "-Wno-undefined-internal", "-Wno-pass-failed", "-S", "--cuda-device-only", f"-I{CSRC}", tmp, "-o", out], check=True)
     text = open(out).read()
     stamp = os.path.join(ROOT, "tools", ".head_stamp")
