@@ -49,3 +49,87 @@ def build(kind: str = "stress", S: int = 48, small: bool = True, num_images: int
 def rays(h: int = 16, w: int = 16, view: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     o, d, _ = synthetic.orbit_camera_rays(h, w, view=view)
     return o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+
+
+# ---- BASELINE config 1 analogue: 1 k optimisation steps of the CPU reference path on a small analytic scene --------------------
+# (the reference's config 1 is "1k iters on the CPU PyTorch reference path: plumbing, no GPU"; its scene data does not exist in
+# the checkout, so the closed-form RGB + thermal scene of thermo_nerf_amd.synthetic stands in.)  Sized so that one oracle step
+# takes ~0.1 s on a few cores: 64-ray batches, (64, 32) proposal + 24 field samples, the SMALL tables.
+CONFIG1 = dict(steps=1000, rays_per_batch=64, views=6, res=20, proposal=(64, 32), S=24, seed=5)
+
+
+def config1_problem():
+    """Model / oracle config + the ray pool, per-step batch indices and jitter draws shared by the CPU run and the HIP run."""
+    c = CONFIG1
+    cm, sd, ocfg = build("init", c["S"], camera_optimizer_mode="off", num_proposal_samples_per_ray=c["proposal"], num_images=c["views"])
+    o, d, cam = [], [], []
+    for v in range(c["views"]):
+        ov, dv, _ = synthetic.orbit_camera_rays(c["res"], c["res"], view=v, num_views=c["views"], elevation_deg=(-10.0, 20.0, 50.0)[v % 3])
+        o.append(ov.reshape(-1, 3))
+        d.append(dv.reshape(-1, 3))
+        cam.append(torch.full((ov.shape[0] * ov.shape[1], 1), v, dtype=torch.long))
+    o, d, cam = torch.cat(o), torch.cat(d), torch.cat(cam)
+    img, th = synthetic.analytic_scene(o, d)
+    g = torch.Generator().manual_seed(c["seed"])
+    idx = torch.randint(0, o.shape[0], (c["steps"], c["rays_per_batch"]), generator=g)
+    jit = torch.rand(c["steps"], 3, c["rays_per_batch"], 1, generator=g)
+    ho, hd, _ = synthetic.orbit_camera_rays(c["res"], c["res"], view=0.5, num_views=c["views"], elevation_deg=5.0)
+    ho, hd = ho.reshape(-1, 3).contiguous(), hd.reshape(-1, 3).contiguous()
+    himg, hth = synthetic.analytic_scene(ho, hd)
+    return dict(model=cm, sd=sd, ocfg=ocfg, o=o, d=d, cam=cam, image=img, thermal=th, idx=idx, jitter=jit,
+                held_out=dict(o=ho, d=hd, image=himg, thermal=hth))
+
+
+def proposal_updates(steps: int):
+    """Per step: does the sampler update its networks?  nerfstudio's ProposalNetworkSampler.step_cb / generate_ray_samples with
+    the reference's schedule [REF thermal_nerf_model.py:152-161]."""
+    from oracle import training as T
+
+    since, flags = 0, []
+    for step in range(steps):
+        since += 1
+        upd = since > T.update_schedule(step) or step < 10
+        if upd:
+            since = 0
+        flags.append(upd)
+    return flags
+
+
+def config1_oracle_run(prob, steps=None, log=None):
+    """Adam (lr 1e-2, eps 1e-15 [REF config_thermal_nerf.py:32-45], no decay over this horizon) over torch autograd on the CPU
+    oracle.  Returns (loss per step, final state dict)."""
+    from oracle import training as T
+
+    sd, ocfg = prob["sd"], prob["ocfg"]
+    steps = steps or prob["idx"].shape[0]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))  # the oracle's ops are small: a 256-thread host runs them ~10x slower on all threads
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith((".aabb", ".scalings")) and not k.startswith("camera_optimizer")}
+    frozen = {k: v for k, v in sd.items() if k not in leaves}
+    opt = torch.optim.Adam(list(leaves.values()), lr=1e-2, eps=1e-15)
+    upd = proposal_updates(steps)
+    losses = []
+    for i in range(steps):
+        ix = prob["idx"][i]
+        batch = {"image": prob["image"][ix], "thermal": prob["thermal"][ix]}
+        out = H.get_outputs({**frozen, **leaves}, prob["o"][ix], prob["d"][ix], prob["cam"][ix], ocfg, training=True,
+                            jitter=list(prob["jitter"][i]), anneal=T.proposal_anneal(i), proposal_requires_grad=upd[i])
+        loss = sum(T.get_loss_dict(out, batch, T.get_metrics_dict(out, batch, True), True).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if log and i % log == 0:
+            print(i, losses[-1], flush=True)
+    torch.set_num_threads(threads)
+    return losses, {**frozen, **{k: v.detach() for k, v in leaves.items()}}
+
+
+def held_out_quality(prob, sd):
+    """(RGB PSNR dB, thermal MAE in normalised units) of the oracle's eval render of the held-out view."""
+    h = prob["held_out"]
+    with torch.no_grad():
+        out = H.get_outputs(sd, h["o"], h["d"], None, prob["ocfg"])
+    mse = ((out["rgb"] - h["image"]) ** 2).mean().item()
+    return -10.0 * torch.log10(torch.tensor(mse)).item(), (out["thermal"] - h["thermal"]).abs().mean().item()

@@ -409,12 +409,12 @@ def test_adam_steps_reduce_the_loss_and_eval_follows():
     with torch.no_grad():
         got = gm(rb)
     sd_new = {k: v.detach().cpu() for k, v in gm.state_dict().items()}
-    want = H.get_outputs(sd_new, o, d, None, ocfg)
-    # 20 Adam steps at lr 1e-2 move the touched table entries by ~0.2 next to untouched ~1e-4 neighbours: a field with
-    # steep spatial gradients, where ulp-level position differences show up at 1e-4.  Stale weights would be off by ~0.1.
+    # nerfstudio's sampler applies its current proposal-weight anneal in eval renders too: the oracle gets the
+    # value set_step(19) left behind.  Stale weights would be off by ~0.1.
+    want = H.get_outputs(sd_new, o, d, None, ocfg, anneal=float(gm.proposal_sampler._anneal))
     assert (got["rgb"].cpu() - want["rgb"]).abs().max().item() <= 2e-3
     assert (got["thermal"].cpu() - want["thermal"]).abs().max().item() <= 2e-3
-    assert (got["rgb"].cpu() - want["rgb"]).abs().mean().item() <= 2e-4
+    assert (got["rgb"].cpu() - want["rgb"]).abs().mean().item() <= 1e-4
 
 
 def test_loss_curve_follows_the_autograd_oracle():
@@ -469,6 +469,66 @@ def test_loss_curve_follows_the_autograd_oracle():
         if name.startswith("proposal_networks"):
             continue  # driven by the interlevel loss alone, which is ~0 here: their gradients are rounding noise throughout
         assert v <= (0.25 if name.endswith("hash_table") else 5e-2), (name, v)
+
+
+def test_config1_one_thousand_iterations_follow_the_cpu_reference_path():
+    """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of
+    tests/test_config1_cpu.py (CPU oracle, torch autograd) and the same 1000 steps on the HIP path — same batches, jitter
+    draws, anneal and proposal-update schedule.  Trajectories of a 1000-step Adam run separate chaotically at the fp32
+    rounding level, so the claim is: step for step over the first 20 steps (2e-3 relative), the 100-step means of the two
+    loss curves within 30 % of each other over the descent (600 steps), both staying converged after it, and the same final
+    quality on an unseen view (1 dB, 0.02 of the normalised thermal range)."""
+    import numpy as np
+
+    prob = helpers.config1_problem()
+    steps = helpers.CONFIG1["steps"]
+    want, sd_cpu = helpers.config1_oracle_run(prob)
+    gm = copy.deepcopy(prob["model"]).to(DEV)
+    gm.train()
+    params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
+    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, fused=True)
+    o, d, cam = prob["o"].to(DEV), prob["d"].to(DEV), prob["cam"].to(DEV)
+    img, th, idx = prob["image"].to(DEV), prob["thermal"].to(DEV), prob["idx"].to(DEV)
+    jitter = prob["jitter"].squeeze(-1).to(DEV)
+    upd = helpers.proposal_updates(steps)
+    got = []
+    for i in range(steps):
+        gm.set_step(i)
+        ix = idx[i]
+        rb = gm.collider(RayBundle(origins=o[ix], directions=d[ix], camera_indices=cam[ix]))
+        out = TR.get_outputs_train(gm, rb, jitter=jitter[i].contiguous())
+        assert (gm.proposal_sampler._steps_since_update == 0) == upd[i], i  # same update steps as the CPU run
+        b = {"image": img[ix], "thermal": th[ix]}
+        loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        got.append(loss.detach())
+    got = torch.stack(got).cpu().numpy()
+    want = np.asarray(want)
+    assert np.isfinite(got).all()
+    for i in range(20):
+        assert abs(got[i] - want[i]) <= 2e-3 * abs(want[i]), (i, got[i], want[i])
+    gw, ww = got.reshape(10, 100).mean(axis=1), want.reshape(10, 100).mean(axis=1)
+    # CPU runs that differ only in their thread count agree within 2 % / 5 % / 30 % / 20 % / 20 % on windows 1-5 and by up to 5x
+    # on the last windows (64-ray batches at a constant lr of 1e-2: the late stage wanders): the HIP run is held to the same band
+    assert (np.abs(gw[:6] - ww[:6]) <= 0.3 * ww[:6]).all(), (gw, ww)
+    assert (np.diff(gw[:6]) < 0).all() and gw[5] < 0.06 * gw[0], gw
+    assert (gw[6:] < gw[1]).all() and (ww[6:] < ww[1]).all(), (gw, ww)
+    # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
+    sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
+    (p_cpu, m_cpu), (p_hip, m_hip) = helpers.held_out_quality(prob, sd_cpu), helpers.held_out_quality(prob, sd_hip)
+    assert abs(p_cpu - p_hip) <= 1.0, (p_cpu, p_hip)
+    assert abs(m_cpu - m_hip) <= 0.02, (m_cpu, m_hip)
+    # and the HIP eval render of the HIP-trained model agrees with the oracle on the same weights (eval after 1000 fused steps)
+    gm.eval()
+    h = prob["held_out"]
+    with torch.no_grad():
+        out = gm(RayBundle(origins=h["o"].to(DEV), directions=h["d"].to(DEV)))
+    # (nerfstudio's sampler applies its current proposal-weight anneal in eval renders too: 0.9999 after set_step(999))
+    ref = H.get_outputs(sd_hip, h["o"], h["d"], None, prob["ocfg"], anneal=float(gm.proposal_sampler._anneal))
+    assert (out["rgb"].cpu() - ref["rgb"]).abs().mean() <= 1e-4
+    assert (out["thermal"].cpu() - ref["thermal"]).abs().mean() <= 1e-4
 
 
 @pytest.mark.parametrize("sh_grad", [False, True])

@@ -13,6 +13,8 @@
 //   main_mfma_kernel  same contract, MLPs on the f32 MFMA pipe (tn_render_mfma.hip).
 #include "tn_field_eval.h"
 
+#include <type_traits>
+
 using namespace tn;
 
 namespace tn {
@@ -252,13 +254,38 @@ __device__ __forceinline__ float proposal_density_kmajor(const Grid &g, const tn
                                                          float pz, float sel) {
     float2 f[5];
     if (ND >= 0) {
-        // two groups (3 + 2 levels): all five levels' 16-byte gathers at once need more registers than 4 waves per SIMD leave
-        // (measured: 3 + 2 -> 3.87 ms per 640 k rays with a few spills; 2 + 2 + 1 without spills -> 4.13; all five -> 4.03)
+        if (FAST) {
+            // Explicit stages per group of levels (index arithmetic | gathers | interpolation), 3 + 2 levels: left alone hipcc
+            // issues one level's gathers, waits and interpolates before it touches the next level — four memory round
+            // trips per sample where two do (3.44 -> 3.03 ms per 640 k rays; 2 + 3: 3.04, 4 + 1: 3.14; the second group's
+            // gathers issued ahead of the first group's interpolation: 2.94 with 20 spilled registers — not kept).  112 VGPRs,
+            // no spills.
+            auto group = [&](auto L0, auto L1) {
+                constexpr int l0 = decltype(L0)::value, l1 = decltype(L1)::value;
+                HashTaps t[l1 - l0];
+                float2 fv[l1 - l0][8];
 #pragma unroll
-        for (int l = 0; l < 3; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);
-        if (ND > 0) TN_STAGE_FENCE();
+                for (int l = l0; l < l1; ++l) {
+                    if (l < ND) dense_taps(g, l, px, py, pz, t[l - l0]); else hash_taps(g, l, px, py, pz, t[l - l0]);
+                }
+                TN_STAGE_FENCE();
 #pragma unroll
-        for (int l = 3; l < 5; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);
+                for (int l = l0; l < l1; ++l) {
+                    if (l < ND) dense_gather(g, l, t[l - l0], fv[l - l0]); else hash_gather(g, l, t[l - l0], fv[l - l0]);
+                }
+#pragma unroll
+                for (int l = l0; l < l1; ++l) hash_hold(t[l - l0]);
+                TN_STAGE_FENCE();
+#pragma unroll
+                for (int l = l0; l < l1; ++l) f[l] = hash_blend(t[l - l0], fv[l - l0]);
+                TN_STAGE_FENCE();
+            };
+            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+            group(std::integral_constant<int, 3>{}, std::integral_constant<int, 5>{});
+        } else {
+#pragma unroll
+            for (int l = 0; l < 5; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);
+        }
     } else if (g.num_dense == 0) {
 #pragma unroll
         for (int l = 0; l < 5; ++l) f[l] = encode_level<false, FAST>(g, l, px, py, pz);
