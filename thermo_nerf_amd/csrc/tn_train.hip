@@ -156,19 +156,30 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
 
 // Gradient of the encoding w.r.t. the WORLD position (camera-pose optimisation): d enc / d offset per level from the
 // same 8 corners (table reads this time), times the level scale; then back through `p * selector`, the
-// (x + 2) / 4 shift and the L-inf contraction (or the AABB normalisation).  One lane per sample, levels looped.
+// (x + 2) / 4 shift and the L-inf contraction (or the AABB normalisation).
+// One lane per (sample, level): LP = 16 or 8 adjacent lanes hold the levels of one sample, so every lane has ONE memory round
+// trip (a lane looping over the levels pays one per level: hipcc does not overlap the levels' gathers) and the d_enc read is
+// contiguous; the three sums over the levels are an xor-shuffle tree over the LP lanes, lane 0 of a group finishes the sample.
+template <int LP>
 __global__ void __launch_bounds__(kBlock)
 hash_encode_bwd_input_kernel(Grid g, tn_space space, const float *__restrict__ positions, const float *__restrict__ d_enc,
                              long long n, float *__restrict__ d_pos) {
     const Space sp = make_space(space);
     const int L = g.num_levels;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-        const float x = positions[i * 3], y = positions[i * 3 + 1], z = positions[i * 3 + 2];
+    constexpr int SPW = 64 / LP;  // samples per wave
+    const int lane = threadIdx.x & 63;
+    const int l = lane % LP, sub = lane / LP;
+    const long long wstride = (long long)gridDim.x * (kBlock / 64) * SPW;
+    for (long long base = ((long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * SPW; base < n; base += wstride) {
+        const long long i = base + sub;
+        const bool live = i < n;
+        const long long ic = live ? i : n - 1;
+        const float x = positions[ic * 3], y = positions[ic * 3 + 1], z = positions[ic * 3 + 2];
         float px, py, pz;
         const float sel = normalize_position(sp, x, y, z, px, py, pz);
         float gx = 0.0f, gy = 0.0f, gz = 0.0f;  // d loss / d p (p = normalised, selector applied)
-        for (int l = 0; l < L; ++l) {
-            const float2 ge = reinterpret_cast<const float2 *>(d_enc)[i * L + l];
+        if (live && l < L) {
+            const float2 ge = reinterpret_cast<const float2 *>(d_enc)[ic * L + l];
             const float s = g.scal[l];
             const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
             const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
@@ -198,6 +209,13 @@ hash_encode_bwd_input_kernel(Grid g, tn_space space, const float *__restrict__ p
             TN_DENC(y)
 #undef TN_DENC
         }
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1) {
+            gx += __shfl_xor(gx, o, 64);
+            gy += __shfl_xor(gy, o, 64);
+            gz += __shfl_xor(gz, o, 64);
+        }
+        if (!live || l != 0) continue;
         gx *= sel; gy *= sel; gz *= sel;  // p = p * selector
         float rx, ry, rz;
         if (sp.contraction) {
@@ -1412,7 +1430,11 @@ int tn_hash_encode_bwd_input(const tn_hashgrid *grid, const tn_space *space, con
     if (n == 0) return TN_OK;
     if (!positions || !d_enc || !d_positions) return TN_ERR_NULL;
     if (n < 0) return TN_ERR_SHAPE;
-    hipLaunchKernelGGL(hash_encode_bwd_input_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
+    if (grid->num_levels > 8)
+        hipLaunchKernelGGL(hash_encode_bwd_input_kernel<16>, dim3(grid_for(n * 16, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
+                       tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_positions);
+    else
+        hipLaunchKernelGGL(hash_encode_bwd_input_kernel<8>, dim3(grid_for(n * 8, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
                        tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_positions);
     TN_LAUNCH_CHECK();
     return TN_OK;
