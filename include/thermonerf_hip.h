@@ -184,6 +184,16 @@ int tn_composite_fwd(const float *values, const float *weights, int64_t num_rays
 int tn_depth_fwd(const float *weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
                  float *accumulation, float *median, float *expected, float *minmax_scratch, void *stream);
 
+/* torchmetrics.functional.structural_similarity_index_measure with its defaults (gaussian 11 x 11, sigma 1.5, k1 0.01,
+ * k2 0.03; torchmetrics 1.7.2, uv.lock:5468-5469) as the reference's models call it on a rendered frame
+ * [REF thermal_nerf_model.py:195,363; NS NerfactoModel.get_image_metrics_and_images]: pred / target [H,W,C] device floats
+ * (the renderers' layout), data_range = what torchmetrics derives when none is given, max(pred.max() - pred.min(),
+ * target.max() - target.min()); out[0] = mean index over the windows inside the image and the channels.
+ * height, width >= 11.  workspace: tn_ssim_workspace_bytes(height, width, channels) bytes of device scratch. */
+size_t tn_ssim_workspace_bytes(int32_t height, int32_t width, int32_t channels);
+int tn_ssim_fwd(const float *pred, const float *target, int32_t height, int32_t width, int32_t channels, float data_range,
+                void *workspace, size_t workspace_bytes, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Fused forward: Model.forward (collider) + ThermalNerfModel.get_outputs
  * [REF thermal_nerf_model.py:210-275]

@@ -778,6 +778,9 @@ def test_thermoscenes_style_tree_to_training_steps(tmp_path):
         assert len(res[key]) == 2 and res[f"{key}_mean"] == pytest.approx(sum(res[key]) / 2, rel=1e-6)
         assert res[f"{key}_std"] >= 0
     assert 0 < res["mae_thermal_mean"] < 19.0  # degrees: normalised error x (33 - 14)
+    for key in ("ssim", "ssim_thermal"):  # torchmetrics' SSIM of each frame (tn_ssim_fwd)
+        assert len(res[key]) == 2 and all(-1.0 <= v <= 1.0 for v in res[key])
+    assert all(v != v for v in res["lpips"]) and all(v != v for v in res["lpips_thermal"])  # NaN: no pretrained network offline
     ev.save_metrics(tmp_path / "eval")
     saved = json.loads((tmp_path / "eval" / "metrics.json").read_text())
     assert saved["method_name"] == "thermal-nerf" and saved["job_param_identifier"] == "t" and "psnr_mean" in saved["results"]

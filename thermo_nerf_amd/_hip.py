@@ -155,6 +155,8 @@ SIGNATURES = {
     "tn_sample_pdf": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "tn_composite_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "tn_depth_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tn_ssim_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "tn_ssim_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _sz, _vp, _vp]),
     "tn_render_workspace_bytes": (_sz, [C.POINTER(tn_render_config), _i64]),
     "tn_render_rays_fwd": (
         C.c_int,

@@ -1,8 +1,8 @@
 """Evaluation harness — counterpart of the reference's ``Evaluator`` [REF thermo_nerf/evaluator/evaluator.py:15-160]:
 render every image of the eval split ONCE (all modalities come out of one pass), compute the per-image metrics of
-``get_image_metrics_and_images`` that this path owns (RGB PSNR, thermal PSNR, thermal MAE in degrees for the whole image and
-for the foreground beyond ``threshold``), aggregate ``<key>``, ``<key>_mean``, ``<key>_std`` exactly as the reference does,
-write ``metrics.json`` and the rendered images.  SSIM / LPIPS (torchmetrics networks) are outside the hot path and absent.
+``ThermalNerfModel.get_image_metrics_and_images`` (RGB / thermal PSNR and SSIM, thermal MAE in degrees for the whole image
+and for the foreground beyond ``threshold``; LPIPS is NaN — its pretrained network does not exist offline), aggregate
+``<key>``, ``<key>_mean``, ``<key>_std`` exactly as the reference does, write ``metrics.json`` and the rendered images.
 """
 from __future__ import annotations
 
@@ -14,7 +14,6 @@ import numpy as np
 import torch
 from PIL import Image
 
-from .cameras import frame_metrics
 from .rays import RayBundle
 from .rendered_image_modalities import RenderedImageModality
 
@@ -58,20 +57,13 @@ class Evaluator:
             rb = RayBundle(origins=flat.origins.view(h, w, 3), directions=flat.directions.view(h, w, 3),
                            pixel_area=rb.pixel_area, camera_indices=rb.camera_indices)
             outputs = model.get_outputs_for_camera_ray_bundle(rb)
-            gt_rgb = item["image"].to(self.device)
-            gt_th = item[RenderedImageModality.THERMAL.value].to(self.device)
-            per_image.append(frame_metrics(outputs, gt_rgb, gt_th, model.max_temperature, model.min_temperature,
-                                           cold=model.config.cold, threshold=threshold))
-            images = {  # the images_dict entries of get_image_metrics_and_images [REF thermal_nerf_model.py:341-352]
-                RenderedImageModality.RGB: lambda: torch.cat([gt_rgb, outputs["rgb"]], dim=1),
-                RenderedImageModality.THERMAL: lambda: outputs["thermal"],
-                RenderedImageModality.THERMAL_COMBINED: lambda: torch.cat([gt_th, outputs["thermal"]], dim=1),
-                RenderedImageModality.ACCUMULATION: lambda: outputs["accumulation"],
-            }
-            for m in self.modalities_to_save:
-                if m not in images:
-                    raise NotImplementedError(f"saving modality {m.value} (colour-mapped depth) is not implemented")
-                self._evaluation_images[m].append((images[m]().clamp(0, 1) * 255).byte().cpu().numpy())
+            batch = {"image": item["image"].to(self.device),
+                     RenderedImageModality.THERMAL.value: item[RenderedImageModality.THERMAL.value].to(self.device)}
+            # REF :82-87: metrics and images of the frame come from the model
+            metrics, images = model.get_image_metrics_and_images(outputs, batch, threshold=threshold)
+            per_image.append(metrics)
+            for m in self.modalities_to_save:  # REF :89-92
+                self._evaluation_images[m].append((images[m.value].clamp(0, 1) * 255).byte().cpu().numpy())
         model.train(was_training)
         if not per_image:
             raise RuntimeError("Cannot evaluate without eval images")

@@ -28,6 +28,13 @@ class RGBRenderer(nn.Module):
             raise NotImplementedError("packed samples are not produced by ProposalNetworkSampler")
         return composite_last_sample(rgb, weights, training=self.training)
 
+    def blend_background(self, image: Tensor) -> Tensor:
+        """NS RGBRenderer.blend_background: an RGBA ground truth is composited over the background — black for the
+        "last_sample" / "random" settings, as nerfstudio substitutes — and an RGB one passes through."""
+        if image.shape[-1] < 4:
+            return image
+        return image[..., :3] * image[..., 3:]
+
     def blend_background_for_loss_computation(self, pred_image: Tensor, pred_accumulation: Tensor, gt_image: Tensor):
         """NS: with "last_sample" and an RGB (no alpha) ground truth there is nothing to blend."""
         return pred_image, gt_image[..., :3]

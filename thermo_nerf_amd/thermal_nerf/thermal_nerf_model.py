@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import weakref
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Type
+from typing import Dict, List, Optional, Sequence, Tuple, Type
 
 import numpy as np
 import torch
@@ -231,6 +231,61 @@ class ThermalNerfModel(ThermalNerfactoModel):
             loss_dict[RenderedImageModality.THERMAL.value] = torch.nn.functional.mse_loss(
                 outputs[RenderedImageModality.THERMAL.value], thermal_batch)
         return loss_dict
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor],
+                                     threshold: Optional[float] = None) -> Tuple[Dict[str, float], Dict[str, Tensor]]:
+        """[REF thermal_nerf_model.py:328-393] on top of NS NerfactoModel.get_image_metrics_and_images: per-frame metrics
+        and the images an evaluation saves, from the [H,W,C] outputs of ``get_outputs_for_camera_ray_bundle``.
+
+        Metrics: ``psnr`` / ``ssim`` (RGB), ``psnr_thermal`` / ``ssim_thermal``, ``mae_thermal`` / ``mae_thermal_foreground``
+        in degrees — PSNR as torchmetrics' PeakSignalNoiseRatio(data_range=1), SSIM as its
+        structural_similarity_index_measure defaults (``tn_ssim_fwd``).  ``lpips`` / ``lpips_thermal`` are NaN: LPIPS is a
+        pretrained AlexNet whose weights torchmetrics downloads; none exist offline.
+        Images: ``img`` (ground truth | prediction), ``thermal`` and ``thermal_combined`` (NS "gray" colormap = the value on
+        three channels), ``accumulation``, ``depth``, ``prop_depth_i`` — the last three as GREY maps with nerfstudio's depth
+        normalisation and accumulation blend, where nerfstudio applies matplotlib's "turbo" lookup table (not available here)."""
+        from ..metrics import psnr, ssim
+        from .thermal_metrics import mae_thermal
+
+        dev = outputs["rgb"].device
+        gt_rgb = self.renderer_rgb.blend_background(batch["image"].to(dev))
+        rgb, acc = outputs["rgb"], outputs[RenderedImageModality.ACCUMULATION.value]
+        th = outputs[RenderedImageModality.THERMAL.value]
+        gt_th = batch[RenderedImageModality.THERMAL.value].to(dev)
+
+        def grey(x: Tensor) -> Tensor:  # NS colormaps.apply_float_colormap(x, "gray")
+            return torch.nan_to_num(x, 0).repeat(1, 1, 3)
+
+        def depth_map(d: Tensor) -> Tensor:  # NS colormaps.apply_depth_colormap without the lookup table
+            near, far = float(torch.min(d)), float(torch.max(d))
+            g = grey(torch.clip((d - near) / (far - near + 1e-10), 0, 1))
+            return g * acc + (1 - acc)
+
+        images = {
+            "img": torch.cat([gt_rgb, rgb], dim=1),
+            "accumulation": grey(acc),
+            "depth": depth_map(outputs[RenderedImageModality.DEPTH.value]),
+            RenderedImageModality.THERMAL.value: grey(th),
+            RenderedImageModality.THERMAL_COMBINED.value: torch.cat([grey(gt_th), grey(th)], dim=1),
+        }
+        for i in range(self.config.num_proposal_iterations):
+            key = f"prop_depth_{i}"
+            if key in outputs:
+                images[key] = depth_map(outputs[key])
+        gt4, th4 = torch.moveaxis(gt_th, -1, 0)[None, ...], torch.moveaxis(th, -1, 0)[None, ...]  # [1,C,H,W] as the reference
+        metrics = {
+            "psnr": float(psnr(gt_rgb, rgb)),
+            "ssim": float(ssim(rgb, gt_rgb)),
+            "lpips": float("nan"),
+            "psnr_thermal": float(psnr(gt_th, th)),
+            "ssim_thermal": float(ssim(th, gt_th)),
+            "lpips_thermal": float("nan"),
+            "mae_thermal_foreground": float(mae_thermal(gt4, th4, self.config.cold, self.max_temperature,
+                                                        self.min_temperature, threshold=threshold)),
+            "mae_thermal": float(mae_thermal(gt4, th4, self.config.cold, self.max_temperature, self.min_temperature,
+                                             threshold=None)),
+        }
+        return metrics, images
 
     # --- the reference's call sequence, one HIP entry point per nerfstudio module ----------------------
     def _get_outputs_modular(self, ray_bundle: RayBundle, jitter: Optional[Sequence[Tensor]] = None) -> Dict[str, Tensor]:

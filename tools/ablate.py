@@ -177,10 +177,10 @@ def main():
         # the untouched translation units come from the regular build's objects (make in csrc/ first)
         others = [os.path.join(CSRC, "build", f.replace(".hip", ".o")) for f in
                   ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_mfma.hip", "tn_render_h3.hip", "tn_train.hip",
-                   "tn_prepare.hip") if f != target and hname not in HEADER_VARIANTS]
+                   "tn_prepare.hip", "tn_metrics.hip") if f != target and hname not in HEADER_VARIANTS]
         if hname in HEADER_VARIANTS:
             others = [os.path.join(CSRC, f) for f in ("tn_samplers.hip", "tn_fields.hip", "tn_render.hip", "tn_render_mfma.hip",
-                                                      "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip") if f != target]
+                                                      "tn_render_h3.hip", "tn_train.hip", "tn_prepare.hip", "tn_metrics.hip") if f != target]
         out = os.path.join(ROOT, f"ab_{name}.so")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *others, tmp, "-o", out], check=True)
         print("built", out)
