@@ -21,6 +21,7 @@ def to64(sd):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    torch.set_num_threads(min(16, torch.get_num_threads()))  # the oracle's small ops crawl on all 256 threads of the GPU box
     prob = helpers.config1_problem()
     gm = copy.deepcopy(prob["model"]).to(DEV)
     gm.train()
