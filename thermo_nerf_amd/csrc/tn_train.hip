@@ -154,6 +154,253 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same scatter WITHOUT global atomics: bucket, then accumulate in LDS.
+// The L2 atomic path retires ~21 G line-atomics/s whatever is done on the issuing side (about one per clock and XCD:
+// tools/micro/atomics*.hip), while the same lines are READ five times faster and streamed far faster still — so the
+// contributions are first written out as records, bucketed by the OWNER of the table entry they belong to, and every owner
+// then sums its bucket in LDS:
+//   * a level's table is cut into slices of 2^14 entries (128 KB of float2 = one CU's LDS); bin = (level, slice);
+//   * a record = the two x-neighbour corners of one (y, z) combination of one sample: (local index pair, 4 floats) — both
+//     corners are in the same slice because x only touches the low 12 bits of the hashed index;
+//   * count pass (bin sizes) -> exclusive scan -> emit pass (a block reserves a contiguous run per bin with ONE global
+//     atomic per bin and block, ranks come from LDS atomics) -> owner pass: one 1024-thread block per bin adds its records
+//     into the LDS slice (ds_add_f32) and adds the slice to d_table with plain coalesced loads / stores.
+// Traffic: 20 B per record written and read once (252 MB per 196 k-sample call) + the table once, all streaming.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kSortSliceLog2 = 14;         // entries per owner slice (x 8 B = 128 KB of LDS)
+constexpr int kSortSamples = 1024;         // samples per block (4 per thread) in the count / emit passes
+constexpr int kSortMaxOwners = 1024;       // log2_hashmap_size <= 24
+constexpr int kOwnerBlock = 1024;
+constexpr int kSortMinBins = 256;
+
+struct SortRec {
+    unsigned owner[4];   // slice of the (y, z) combination
+    unsigned pair[4];    // local index of the ceil-x corner | local index of the floor-x corner << 16
+    float4 val[4];       // (w_ceil ge.x, w_ceil ge.y, w_floor ge.x, w_floor ge.y)
+};
+
+// the four records of one (sample, level): the corner / offset arithmetic of hash_encode_bwd_kernel
+template <bool VALUES>
+__device__ __forceinline__ void sort_records(const Grid &g, int l, int slice_log2, float px, float py, float pz, float2 ge,
+                                             SortRec &r) {
+    const float s = g.scal[l];
+    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+    const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+    const unsigned cx = (unsigned)(int)ceilf(sx), cy = (unsigned)(int)ceilf(sy), cz = (unsigned)(int)ceilf(sz);
+    const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
+    const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
+    const unsigned m = g.mask, lm = (1u << slice_log2) - 1u;
+    // (y, z) combinations in the order of kPairs = {0,3} {1,2} {4,7} {5,6}: (cy,cz) (fy,cz) (cy,fz) (fy,fz)
+    const unsigned hyz[4] = {hcy ^ hcz, hfy ^ hcz, hcy ^ hfz, hfy ^ hfz};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned ia = (cx ^ hyz[p]) & m, ib = (fx ^ hyz[p]) & m;
+        r.owner[p] = ia >> slice_log2;
+        r.pair[p] = (ia & lm) | ((ib & lm) << 16);
+    }
+    if (VALUES) {
+        const float ox = sub_rn(sx, fxf), oy = sub_rn(sy, fyf), oz = sub_rn(sz, fzf);
+        const float qx = sub_rn(1.0f, ox), qy = sub_rn(1.0f, oy), qz = sub_rn(1.0f, oz);
+        // enc = ((f0 ox + f3 qx) oy + (f1 ox + f2 qx) qy) oz + ((f4 ox + f7 qx) oy + (f5 ox + f6 qx) qy) qz
+        // weights as the atomic kernel forms them: (ox * oy) * oz ... — keep its association
+        const float wc[4] = {ox * oy * oz, ox * qy * oz, ox * oy * qz, ox * qy * qz};
+        const float wf[4] = {qx * oy * oz, qx * qy * oz, qx * oy * qz, qx * qy * qz};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) r.val[p] = make_float4(wc[p] * ge.x, wc[p] * ge.y, wf[p] * ge.x, wf[p] * ge.y);
+    }
+}
+
+struct SortArgs {
+    Grid g;
+    tn_space space;
+    const float *positions, *d_enc;
+    long long n;
+    int owners, slice_log2;
+    unsigned *counts, *cursors;
+    const unsigned *starts;
+    unsigned *rec_pair;
+    float4 *rec_val;
+};
+
+// EMIT == false: bin sizes.  EMIT == true: reserve and write.  blockIdx.x = chunk * L + level.
+template <bool EMIT>
+__global__ void __launch_bounds__(kBlock) sort_pass_kernel(SortArgs a) {
+    __shared__ unsigned hist[kSortMaxOwners];
+    __shared__ unsigned base[kSortMaxOwners];
+    const Space sp = make_space(a.space);
+    const int L = a.g.num_levels;
+    const long long chunk = blockIdx.x / L;
+    const int l = (int)(blockIdx.x - chunk * L);
+    for (int o = threadIdx.x; o < a.owners; o += kBlock) hist[o] = 0u;
+    __syncthreads();
+    unsigned slot[kSortSamples / kBlock][4];
+#pragma unroll
+    for (int k = 0; k < kSortSamples / kBlock; ++k) {
+        const long long i = chunk * kSortSamples + k * kBlock + threadIdx.x;
+        float2 ge = make_float2(0.0f, 0.0f);
+        if (i < a.n) ge = reinterpret_cast<const float2 *>(a.d_enc)[i * L + l];
+        const bool on = ge.x != 0.0f || ge.y != 0.0f;  // a sample without gradient writes no record (same test in both passes)
+        if (on) {
+            float px, py, pz;
+            normalize_position(sp, a.positions[i * 3], a.positions[i * 3 + 1], a.positions[i * 3 + 2], px, py, pz);
+            SortRec r;
+            sort_records<false>(a.g, l, a.slice_log2, px, py, pz, ge, r);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const unsigned rank = atomicAdd(&hist[r.owner[p]], 1u);
+                slot[k][p] = rank;
+            }
+        }
+    }
+    __syncthreads();
+    if (!EMIT) {
+        for (int o = threadIdx.x; o < a.owners; o += kBlock)
+            if (hist[o]) atomicAdd(&a.counts[(size_t)l * a.owners + o], hist[o]);
+        return;
+    }
+    for (int o = threadIdx.x; o < a.owners; o += kBlock) {
+        const size_t bin = (size_t)l * a.owners + o;
+        base[o] = hist[o] ? a.starts[bin] + atomicAdd(&a.cursors[bin], hist[o]) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortSamples / kBlock; ++k) {
+        const long long i = chunk * kSortSamples + k * kBlock + threadIdx.x;
+        float2 ge = make_float2(0.0f, 0.0f);
+        if (i < a.n) ge = reinterpret_cast<const float2 *>(a.d_enc)[i * L + l];
+        if (ge.x != 0.0f || ge.y != 0.0f) {
+            float px, py, pz;
+            normalize_position(sp, a.positions[i * 3], a.positions[i * 3 + 1], a.positions[i * 3 + 2], px, py, pz);
+            SortRec r;
+            sort_records<true>(a.g, l, a.slice_log2, px, py, pz, ge, r);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const size_t at = (size_t)base[r.owner[p]] + slot[k][p];
+                a.rec_pair[at] = r.pair[p];
+                a.rec_val[at] = r.val[p];
+            }
+        }
+    }
+}
+
+// exclusive scan of the bin sizes (<= 16 x 1024 bins) by one block; starts[bins] = total
+__global__ void __launch_bounds__(1024) sort_scan_kernel(const unsigned *__restrict__ counts, int bins, unsigned *__restrict__ starts) {
+    __shared__ unsigned part[1024];
+    const int per = (bins + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
+    unsigned s = 0;
+    for (int b = b0; b < b1; ++b) s += counts[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;
+    for (int b = b0; b < b1; ++b) {
+        starts[b] = run;
+        run += counts[b];
+    }
+    if (threadIdx.x == 1023) starts[bins] = part[1023];
+}
+
+// fp32 add into LDS through a compare-and-swap loop: ds_add_f32 retires 0.33 lanes per clock and CU on this part whatever the
+// addresses, ds_cmpst_rtn_b32 / ds_add_u32 ~5-6 (tools/micro/lds_atomics.hip); a slice sees ~3 adds per float, so a loop
+// almost never repeats.
+__device__ __forceinline__ void lds_add_f32(float *p, float v) {
+    unsigned *u = reinterpret_cast<unsigned *>(p);
+    unsigned old = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (true) {
+        const unsigned got = atomicCAS(u, old, __float_as_uint(__uint_as_float(old) + v));
+        if (got == old) break;
+        old = got;
+    }
+}
+
+// one block per bin: the bucket's records into the LDS slice, the slice into d_table (+=)
+__global__ void __launch_bounds__(kOwnerBlock, 1)
+sort_owner_kernel(const unsigned *__restrict__ starts, const unsigned *__restrict__ rec_pair, const float4 *__restrict__ rec_val,
+                  int owners, int slice_log2, unsigned tsize, float *__restrict__ d_table) {
+    extern __shared__ __attribute__((aligned(16))) float slice[];  // [2 << slice_log2]
+    const unsigned bin = blockIdx.x;
+    const unsigned r0 = starts[bin], r1 = starts[bin + 1];
+    if (r0 == r1) return;  // nothing touched this slice
+    const int nfl = 2 << slice_log2;
+    for (int e = threadIdx.x * 4; e < nfl; e += kOwnerBlock * 4) *reinterpret_cast<float4 *>(slice + e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __syncthreads();
+    // Consecutive records of a bin come from consecutive samples of a ray, which share their cell at the coarse levels: a wave
+    // takes 64 CONSECUTIVE records, sums runs of equal index pairs with a segmented scan and only a run's last lane touches
+    // LDS — same-address ds_add_f32 retire one after the other (~12 cycles each measured), and level 0 has ~300 addresses
+    // per slice for ~100 k adds.
+    const int lane = threadIdx.x & 63;
+    for (unsigned rb = r0 + (threadIdx.x & ~63u); rb < r1; rb += kOwnerBlock) {
+        const unsigned r = rb + lane;
+        const bool live = r < r1;
+        const unsigned pk = live ? rec_pair[r] : 0xffffffffu - lane;  // dead lanes: distinct keys nobody shares
+        float4 v = live ? rec_val[r] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const unsigned up = (unsigned)__shfl_up((int)pk, 1, 64);
+        int f = (lane > 0 && up == pk) ? 0 : 1;  // head of a run
+        const int next_head = __shfl_down(f, 1, 64);
+        const bool tail = (lane == 63) | (next_head != 0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int o = 1 << k;
+            const int fu = __shfl_up(f, o, 64);
+            const bool take = lane >= o && f == 0;
+            const float ux = __shfl_up(v.x, o, 64), uy = __shfl_up(v.y, o, 64), uz = __shfl_up(v.z, o, 64), uw = __shfl_up(v.w, o, 64);
+            if (take) { v.x += ux; v.y += uy; v.z += uz; v.w += uw; }
+            if (lane >= o) f |= fu;
+        }
+        if (live && tail) {
+            float *pa = slice + 2 * (pk & 0xffffu), *pb = slice + 2 * (pk >> 16);
+            if (v.x != 0.0f) lds_add_f32(pa, v.x);
+            if (v.y != 0.0f) lds_add_f32(pa + 1, v.y);
+            if (v.z != 0.0f) lds_add_f32(pb, v.z);
+            if (v.w != 0.0f) lds_add_f32(pb + 1, v.w);
+        }
+    }
+    __syncthreads();
+    const unsigned level = bin / owners, o = bin - level * owners;
+    float *dst = d_table + ((size_t)level * tsize + ((size_t)o << slice_log2)) * 2;
+    for (int e = threadIdx.x * 4; e < nfl; e += kOwnerBlock * 4) {
+        const float4 add = *reinterpret_cast<const float4 *>(slice + e);
+        if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f || add.w != 0.0f) {
+            float4 cur = *reinterpret_cast<float4 *>(dst + e);
+            cur.x += add.x; cur.y += add.y; cur.z += add.z; cur.w += add.w;
+            *reinterpret_cast<float4 *>(dst + e) = cur;
+        }
+    }
+}
+
+struct SortLayout {
+    int owners, slice_log2, bins;
+    size_t slots, off_cursors, off_starts, off_pair, off_val, bytes;
+};
+inline bool sort_layout(const tn_hashgrid &h, long long n, SortLayout &w) {
+    w.slice_log2 = h.log2_hashmap_size < kSortSliceLog2 ? h.log2_hashmap_size : kSortSliceLog2;
+    w.owners = 1 << (h.log2_hashmap_size - w.slice_log2);
+    w.bins = w.owners * h.num_levels;
+    // both x-neighbours of a record must fall into one slice: x (<= finest scaling + 1) may only touch bits below the slice
+    float top = 0.0f;
+    for (int l = 0; l < h.num_levels; ++l) top = h.scalings[l] > top ? h.scalings[l] : top;
+    if (w.owners > 1 && top + 2.0f >= (float)(1 << w.slice_log2)) return false;
+    if (w.owners > kSortMaxOwners || w.slice_log2 > 16) return false;
+
+    const long long slots = n * h.num_levels * 4;
+    if (slots >= (1LL << 32) - 4096) return false;
+    w.slots = (size_t)slots;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    w.off_cursors = up((size_t)w.bins * 4);
+    w.off_starts = w.off_cursors + up((size_t)w.bins * 4);
+    w.off_pair = w.off_starts + up((size_t)(w.bins + 1) * 4);
+    w.off_val = w.off_pair + up(w.slots * 4);
+    w.bytes = w.off_val + w.slots * 16;
+    return true;
+}
+
 // Gradient of the encoding w.r.t. the WORLD position (camera-pose optimisation): d enc / d offset per level from the
 // same 8 corners (table reads this time), times the level scale; then back through `p * selector`, the
 // (x + 2) / 4 shift and the L-inf contraction (or the AABB normalisation).
@@ -1419,6 +1666,62 @@ int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const flo
     if (n < 0) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(hash_encode_bwd_kernel, dim3(grid_for(((n + 63) / 64) * grid->num_levels, kBlock / 64, 1 << 16)), dim3(kBlock), 0,
                        (hipStream_t)stream, tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_table);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n) {
+    SortLayout w;
+    if (!grid || n <= 0 || tn_check_grid(*grid) != TN_OK || !sort_layout(*grid, n, w)) return 0;
+    return w.bytes;
+}
+
+// one block per bin owns a CU's LDS: fewer bins than CUs (the proposal grids: 5 levels x 8 slices) leave most of the chip idle
+// behind a few very long buckets — the atomic scatter is faster there (measured: 1.16 against 0.90 ms per training step)
+int tn_hash_encode_bwd_sorted_pays(const tn_hashgrid *grid, int64_t n) {
+    SortLayout w;
+    if (!grid || n <= 0 || tn_check_grid(*grid) != TN_OK || !sort_layout(*grid, n, w)) return 0;
+    return w.bins >= kSortMinBins ? 1 : 0;
+}
+
+int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!grid || !space) return TN_ERR_NULL;
+    TN_TRY(tn_check_grid(*grid));
+    if (n == 0) return TN_OK;
+    if (!positions || !d_enc || !d_table || !workspace) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    SortLayout w;
+    if (!sort_layout(*grid, n, w)) return TN_ERR_UNSUPPORTED;
+    if (workspace_bytes < w.bytes) return TN_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return TN_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace);
+    SortArgs a;
+    a.g = tn_make_grid(*grid);
+    a.space = *space;
+    a.positions = positions; a.d_enc = d_enc; a.n = n;
+    a.owners = w.owners; a.slice_log2 = w.slice_log2;
+    a.counts = reinterpret_cast<unsigned *>(ws);
+    a.cursors = reinterpret_cast<unsigned *>(ws + w.off_cursors);
+    unsigned *starts = reinterpret_cast<unsigned *>(ws + w.off_starts);
+    a.starts = starts;
+    a.rec_pair = reinterpret_cast<unsigned *>(ws + w.off_pair);
+    a.rec_val = reinterpret_cast<float4 *>(ws + w.off_val);
+    if (hipMemsetAsync(ws, 0, w.off_starts, s) != hipSuccess) return TN_ERR_LAUNCH;  // counts and cursors
+    const long long chunks = (n + kSortSamples - 1) / kSortSamples;
+    const long long blocks = chunks * grid->num_levels;
+    if (blocks > 0x7fffffffLL) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(sort_pass_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    TN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, a.counts, w.bins, starts);
+    TN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_pass_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    TN_LAUNCH_CHECK();
+    const size_t smem = (size_t)(2 << w.slice_log2) * sizeof(float);
+    if (smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_owner_kernel>(smem)) return TN_ERR_LAUNCH;
+    hipLaunchKernelGGL(sort_owner_kernel, dim3((unsigned)w.bins), dim3(kOwnerBlock), smem, s, starts, a.rec_pair, a.rec_val, w.owners,
+                       w.slice_log2, 1u << grid->log2_hashmap_size, d_table);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -47,9 +47,24 @@ def hash_encode_fwd(grid, space, pos: Tensor) -> Tuple[Tensor, Tensor]:
     return enc, sel
 
 
-def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor) -> None:
-    _hip.check(_hip.load().tn_hash_encode_bwd(grid, space, pos.data_ptr(), d_enc.data_ptr(), pos.shape[0],
-                                              d_table.data_ptr(), _stream()), "tn_hash_encode_bwd")
+def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False) -> None:
+    """d_table += adjoint of the hash encoding: the global-atomic scatter (tn_hash_encode_bwd), or with ``bucketed``
+    (config.bucketed_table_scatter, off by default) contributions written out as records bucketed by the owning table
+    slice and summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 20 B of scratch per (sample, level, corner
+    pair)) where the library says that pays."""
+    lib = _hip.load()
+    n = pos.shape[0]
+    # bucketed=True: where the library says it pays (>= 256 bins: the field's grid, not the proposal grids); "force": wherever
+    # the geometry allows it (tests)
+    use = bucketed == "force" or (bool(bucketed) and lib.tn_hash_encode_bwd_sorted_pays(grid, n))
+    need = lib.tn_hash_encode_bwd_sorted_workspace_bytes(grid, n) if use else 0
+    if need:
+        ws = torch.empty(need, dtype=torch.uint8, device=pos.device)
+        _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(),
+                                                 ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
+        return
+    _hip.check(lib.tn_hash_encode_bwd(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), _stream()),
+               "tn_hash_encode_bwd")
 
 
 def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor:
@@ -196,7 +211,7 @@ def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, 
 
 
 def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict,
-                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True) -> None:
+                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True, bucketed: bool = False) -> None:
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
@@ -220,7 +235,7 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
         g_hid = _f32((n, H), g_w.device)
         linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
         linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
-    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]])
+    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed)
     if ray_grads is not None:
         _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads)
 
@@ -471,7 +486,8 @@ class RenderTrain(torch.autograd.Function):
             g_h1 = _f32((N, W), dev)
             linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
             linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
-        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"))
+        bucketed = bool(getattr(cfg, "bucketed_table_scatter", False))
+        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
 
@@ -484,7 +500,7 @@ class RenderTrain(torch.autograd.Function):
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
                 net = model.proposal_networks[which].c_struct(dense=False)
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
-                                    ray_grads, chained)
+                                    ray_grads, chained, bucketed)
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
         result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)

@@ -1,0 +1,46 @@
+"""Scratch timing of the two table-gradient scatters (global atomics | bucketed + LDS) on the full-size field grid, with the
+real level scalings, all levels at the finest and all at the coarsest.  usage: [THERMONERF_HIP_LIB=ab_x.so] python tools/scatter_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, _hip, synthetic  # noqa: E402
+from thermo_nerf_amd import training as TR  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    model = ThermalNerfModel(ThermalNerfModelConfig(), metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+    synthetic.fill_model_(model, "scene")
+    model.to(dev).train()
+    fld = model.field.c_struct(prepare=False, dense=False)
+    real = [fld.grid.scalings[i] for i in range(16)]
+    g = torch.Generator(device=dev).manual_seed(0)
+    n = 4096 * 48
+    o = (torch.rand(4096, 1, 3, device=dev, generator=g) - 0.5) * 1.2
+    d = torch.nn.functional.normalize(torch.randn(4096, 1, 3, device=dev, generator=g), dim=-1)
+    t = torch.sort(torch.rand(4096, 48, 1, device=dev, generator=g), dim=1).values * 3.0
+    pos = (o + d * t).reshape(-1, 3).contiguous()
+    ge = torch.randn(n, 32, device=dev, generator=g)
+    out = torch.zeros(16 << 19, 2, device=dev)
+    for name, sc in (("real scalings", real), ("all finest", [real[-1]] * 16), ("all level 6", [real[6]] * 16), ("all coarsest", [real[0]] * 16)):
+        for i in range(16):
+            fld.grid.scalings[i] = sc[i]
+        for bucketed in (False, True):
+            for _ in range(3):
+                TR.hash_encode_bwd(fld.grid, fld.space, pos, ge, out, bucketed=bucketed)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                TR.hash_encode_bwd(fld.grid, fld.space, pos, ge, out, bucketed=bucketed)
+            b.record()
+            torch.cuda.synchronize()
+            print(f"{os.environ.get('THERMONERF_HIP_LIB', 'lib')[-16:]}: {name:14s} {'bucketed' if bucketed else 'atomics '}: {a.elapsed_time(b) / 20 * 1e3:8.1f} us")
+    for i in range(16):
+        fld.grid.scalings[i] = real[i]
+
+
+if __name__ == "__main__":
+    main()
