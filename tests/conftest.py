@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's ops are small: on the GPU box's 256 hardware threads (shared with other jobs) torch's default pool
+    # makes them several times slower than 16 threads do (bench.py's cpu_baseline probes the same)
+    try:
+        import torch
+
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+    except Exception:  # pragma: no cover
+        pass
 
 
 @pytest.fixture(scope="session")

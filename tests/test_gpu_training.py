@@ -535,18 +535,24 @@ def test_bucketed_table_scatter_in_the_training_step():
             assert rel(got[n], want[n]) <= 1e-5, n  # (atomic orders differ from run to run)
 
 
-def test_config1_one_thousand_iterations_follow_the_cpu_reference_path():
-    """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of
-    tests/test_config1_cpu.py (CPU oracle, torch autograd) and the same 1000 steps on the HIP path — same batches, jitter
-    draws, anneal and proposal-update schedule.  Trajectories of a 1000-step Adam run separate chaotically at the fp32
-    rounding level, so the claim is: step for step over the first 20 steps (2e-3 relative), the 100-step means of the two
-    loss curves within 30 % of each other over the descent (600 steps), both staying converged after it, and the same final
-    quality on an unseen view (2 dB, 0.03 of the normalised thermal range: the spread of the CPU runs among themselves)."""
+def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_dir):
+    """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of the
+    CPU reference path (torch autograd over the oracle; tests/test_config1_cpu.py runs them live, tools/make_config1_golden.py
+    recorded them in tests/golden/config1_oracle.npz — the GPU box's shared host cores can be 40x slower under load) and the
+    same 1000 steps on the HIP path: same batches, jitter draws, anneal and proposal-update schedule.  Trajectories of a
+    1000-step Adam run separate chaotically at the fp32 rounding level (two CPU runs do), so the claim is: step for step over
+    the first 20 steps (2e-3 relative), the 100-step means of the two loss curves within 40 % of each other over the descent
+    (600 steps), both staying converged after it, and the same final quality on an unseen view (2 dB, 0.03 of the normalised
+    thermal range: the spread of the CPU runs among themselves)."""
+    import os
+
     import numpy as np
 
     prob = helpers.config1_problem()
     steps = helpers.CONFIG1["steps"]
-    want, sd_cpu = helpers.config1_oracle_run(prob)
+    gold = np.load(os.path.join(golden_dir, "config1_oracle.npz"))
+    want, p_cpu, m_cpu = gold["losses"], float(gold["psnr"]), float(gold["mae"])
+    assert want.shape == (steps,)
     gm = copy.deepcopy(prob["model"]).to(DEV)
     gm.train()
     params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
@@ -569,19 +575,19 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path():
         opt.step()
         got.append(loss.detach())
     got = torch.stack(got).cpu().numpy()
-    want = np.asarray(want)
     assert np.isfinite(got).all()
     for i in range(20):
         assert abs(got[i] - want[i]) <= 2e-3 * abs(want[i]), (i, got[i], want[i])
     gw, ww = got.reshape(10, 100).mean(axis=1), want.reshape(10, 100).mean(axis=1)
-    # CPU runs that differ only in their thread count agree within 2 % / 5 % / 30 % / 20 % / 20 % on windows 1-5 and by up to 5x
+    # CPU runs that differ only in their thread count agree within 2 % / 5 % / 33 % / 20 % / 20 % on windows 1-5 (window 3:
+    # 0.0039 ... 0.0052) and by up to 5x
     # on the last windows (64-ray batches at a constant lr of 1e-2: the late stage wanders): the HIP run is held to the same band
-    assert (np.abs(gw[:6] - ww[:6]) <= 0.3 * ww[:6]).all(), (gw, ww)
+    assert (np.abs(gw[:6] - ww[:6]) <= 0.4 * ww[:6]).all(), (gw, ww)
     assert (np.diff(gw[:6]) < 0).all() and gw[5] < 0.06 * gw[0], gw
     assert (gw[6:] < gw[1]).all() and (ww[6:] < ww[1]).all(), (gw, ww)
     # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
     sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
-    (p_cpu, m_cpu), (p_hip, m_hip) = helpers.held_out_quality(prob, sd_cpu), helpers.held_out_quality(prob, sd_hip)
+    p_hip, m_hip = helpers.held_out_quality(prob, sd_hip)
     # CPU runs that differ only in thread count / host end between 15.9 and 17.1 dB (0.208 ... 0.221 thermal MAE) after the
     # wandering late stage; the HIP runs seen so far: 16.0 ... 16.3 dB
     assert abs(p_cpu - p_hip) <= 2.0, (p_cpu, p_hip)
