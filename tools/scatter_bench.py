@@ -23,6 +23,17 @@ def main():
     d = torch.nn.functional.normalize(torch.randn(4096, 1, 3, device=dev, generator=g), dim=-1)
     t = torch.sort(torch.rand(4096, 48, 1, device=dev, generator=g), dim=1).values * 3.0
     pos = (o + d * t).reshape(-1, 3).contiguous()
+    if "--surface" in sys.argv:
+        # a trained scene: the final level's samples sit within a few centimetres of the surface the ray hits (a sphere of
+        # radius 0.3 seen from an orbit of radius 0.8), so every level's hot cells are shared by thousands of rays
+        cam = torch.nn.functional.normalize(torch.randn(4096, 1, 3, device=dev, generator=g), dim=-1) * 0.8
+        aim = torch.nn.functional.normalize(torch.randn(4096, 1, 3, device=dev, generator=g), dim=-1) * 0.3 * torch.rand(4096, 1, 1, device=dev, generator=g)
+        dd = torch.nn.functional.normalize(aim - cam, dim=-1)
+        b = (cam * dd).sum(-1, keepdim=True)
+        disc = (b * b - ((cam * cam).sum(-1, keepdim=True) - 0.09)).clamp_min(0)
+        th = -b - torch.sqrt(disc)
+        t = th + torch.sort(torch.randn(4096, 48, 1, device=dev, generator=g) * 0.02, dim=1).values
+        pos = (cam + dd * t).reshape(-1, 3).contiguous()
     ge = torch.randn(n, 32, device=dev, generator=g)
     out = torch.zeros(16 << 19, 2, device=dev)
     for name, sc in (("real scalings", real), ("all finest", [real[-1]] * 16), ("all level 6", [real[6]] * 16), ("all coarsest", [real[0]] * 16)):
