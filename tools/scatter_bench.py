@@ -35,8 +35,15 @@ def main():
         t = th + torch.sort(torch.randn(4096, 48, 1, device=dev, generator=g) * 0.02, dim=1).values
         pos = (cam + dd * t).reshape(-1, 3).contiguous()
     ge = torch.randn(n, 32, device=dev, generator=g)
+    if "--real" in sys.argv:  # the inputs of a real training step's field-level call (tools/time_scatter.py saves them)
+        blob = torch.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "real_scatter_inputs.pt"))
+        pos, ge = blob["pos"].to(dev), blob["ge"].to(dev)
+        n = pos.shape[0]
     out = torch.zeros(16 << 19, 2, device=dev)
-    for name, sc in (("real scalings", real), ("all finest", [real[-1]] * 16), ("all level 6", [real[6]] * 16), ("all coarsest", [real[0]] * 16)):
+    cases = [("real scalings", real), ("all finest", [real[-1]] * 16), ("all level 6", [real[6]] * 16), ("all coarsest", [real[0]] * 16)]
+    if "--levels" in sys.argv:
+        cases = [("real scalings", real)] + [(f"all level {l}", [real[l]] * 16) for l in range(16)]
+    for name, sc in cases:
         for i in range(16):
             fld.grid.scalings[i] = sc[i]
         for bucketed in (False, True):
