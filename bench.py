@@ -41,6 +41,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense, f32 i
 FIELD_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 63 * 64 + 64 * 64 + 64 * 3 + 15 * 64 + 64 * 64 + 64 * 1)  # 33 024
 PROP_FLOPS_PER_SAMPLE = 2 * (10 * 16 + 16)  # 352
 P0, P1 = 256, 96
+ATOMIC_SCATTER = False  # --atomic-scatter: config.bucketed_table_scatter = False in the train-step variants (A/B)
 ATOMIC_PEAK_GTPS = 21.0  # measured on MI355X: scattered fp32 atomic adds, transactions (64-byte lines) per second (tools/micro/atomics.hip)
 REF_CHUNK = 1 << 16  # REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:30
 
@@ -61,6 +62,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--atomic-scatter", action="store_true",
+                    help="train steps with config.bucketed_table_scatter = False (global atomics on every level): A/B")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render (default): the BASELINE metric.  train: one optimisation step per 'step' "
                          "(BASELINE configs 3/5; with N ranks every rank trains its own scene replica, no collective)")
@@ -86,7 +89,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (profiling runs)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per CPU-baseline repeat")
-    return ap.parse_args()
+    a = ap.parse_args()
+    global ATOMIC_SCATTER
+    ATOMIC_SCATTER = bool(a.atomic_scatter)
+    return a
 
 
 def cpu_model_name() -> str:
@@ -165,7 +171,8 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.rays import RayBundle
 
-    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=samples)  # camera_optimizer_mode = SO3xR3, the reference default
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=samples,  # camera_optimizer_mode = SO3xR3, the reference default
+                                 bucketed_table_scatter=not ATOMIC_SCATTER)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, "scene")
     sd_cpu = synthetic.model_state_dict_cpu(model) if cpu else None

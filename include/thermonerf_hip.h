@@ -297,17 +297,23 @@ int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const flo
 int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
                        int64_t n, float *d_table, void *stream);
 
-/* The same adjoint without global atomics: contributions are written out as records bucketed by the table slice (2^14
- * entries) that owns them and summed per slice in LDS, then added to d_table (+=) with plain loads / stores.  Needs
- * tn_hash_encode_bwd_sorted_workspace_bytes(grid, n) bytes of 16-byte aligned device scratch (20 B per (sample, level,
- * corner pair)); that function returns 0 — and this one TN_ERR_UNSUPPORTED — for a geometry the bucketing does not cover
- * (finest scaling + 2 >= 2^14 with more than one slice, or >= 2^32 records): use tn_hash_encode_bwd then. */
-size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n);
-/* 1 when the bucketed form is the faster one for this grid: at least 256 (level, slice) bins, one LDS-owning block each;
- * the reference's proposal grids (5 levels x 8 slices) are better served by tn_hash_encode_bwd. */
-int tn_hash_encode_bwd_sorted_pays(const tn_hashgrid *grid, int64_t n);
+/* tn_hash_encode_bwd restricted to the levels [level_begin, level_end) (d_enc keeps all num_levels columns). */
+int tn_hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, int32_t level_begin, int32_t level_end, void *stream);
+
+/* The same adjoint without global atomics for the levels [level_begin, num_levels): contributions are written out as records
+ * bucketed by the table slice (2^14 entries) that owns them and summed per slice in LDS, then added to d_table (+=) with plain
+ * loads / stores.  Needs tn_hash_encode_bwd_sorted_workspace_bytes(grid, n, level_begin) bytes of 16-byte aligned device
+ * scratch (20 B per (sample, level, corner pair)); that function returns 0 — and tn_hash_encode_bwd_sorted
+ * TN_ERR_UNSUPPORTED — for a geometry the bucketing does not cover (finest scaling + 2 >= 2^14 with more than one slice, or
+ * >= 2^32 records).  tn_hash_encode_bwd_sorted_first_level: the level from which this form is the faster one on this part
+ * (levels with a scaling >= 256, at least 128 (level, slice) bins), or -1: the caller runs tn_hash_encode_bwd_levels on the
+ * levels below it and this on the rest. */
+size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n, int32_t level_begin);
+int tn_hash_encode_bwd_sorted_first_level(const tn_hashgrid *grid, int64_t n);
 int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
-                              int64_t n, float *d_table, void *workspace, size_t workspace_bytes, void *stream);
+                              int64_t n, float *d_table, int32_t level_begin, void *workspace, size_t workspace_bytes,
+                              void *stream);
 
 /* and w.r.t. the WORLD positions (camera-pose optimisation, NS CameraOptimizer applied at REF thermal_nerf_model.py:
  * 218-219): through the trilinear offsets, `p * selector`, (x + 2) / 4 and the L-inf contraction (or the AABB

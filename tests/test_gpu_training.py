@@ -146,7 +146,7 @@ def test_hash_encode_fwd_bwd(contraction):
     e, s = TR.hash_encode_fwd(grid, space, pos.to(DEV))
     assert torch.equal(s.cpu(), sel.float())
     assert (e.cpu() - enc.detach()).abs().max().item() <= 1e-6
-    for bucketed in ("force", False):  # records bucketed by owning slice + LDS sums | global atomics
+    for bucketed in (0, 5, False):  # records bucketed by owning slice + LDS sums | global atomics
         d_table = torch.zeros_like(td)
         TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), d_table, bucketed=bucketed)
         assert rel(d_table, table.grad) <= 1e-5, bucketed
@@ -181,11 +181,14 @@ def test_bucketed_table_scatter_matches_the_atomic_one(L, log2T, max_res, n):
     for i, s in enumerate(scal.tolist()):
         grid.scalings[i] = s
     space = _hip.make_space(True, torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]))
-    assert _hip.load().tn_hash_encode_bwd_sorted_workspace_bytes(grid, n) > 0
-    # fewer (level, slice) bins than CUs: the library advises the atomic form (bucketed=True follows it; "force" here)
-    assert bool(_hip.load().tn_hash_encode_bwd_sorted_pays(grid, n)) == ((L << max(0, log2T - 14)) >= 256)
+    assert _hip.load().tn_hash_encode_bwd_sorted_workspace_bytes(grid, n, 0) > 0
+    # the library's advice (bucketed=True follows it; explicit levels here): from the first level with a scaling >= 256, if
+    # that leaves at least 128 (level, slice) bins
+    fine = [i for i, sc in enumerate(scal.tolist()) if sc >= 256]
+    advised = fine[0] if fine and ((L - fine[0]) << max(0, log2T - 14)) >= 128 else -1
+    assert _hip.load().tn_hash_encode_bwd_sorted_first_level(grid, n) == advised
     a, b = torch.zeros(L << log2T, 2, device=DEV), torch.zeros(L << log2T, 2, device=DEV)
-    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), a, bucketed="force")
+    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), a, bucketed=0)
     TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), b, bucketed=False)
     assert float(b.abs().sum()) > 0
     assert rel(a, b) <= 1e-5
@@ -193,7 +196,7 @@ def test_bucketed_table_scatter_matches_the_atomic_one(L, log2T, max_res, n):
     # (+=): on top of what the table gradient already holds
     start = torch.randn(L << log2T, 2, generator=g).to(DEV)
     c = start.clone()
-    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), c, bucketed="force")
+    TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), c, bucketed=min(2, L - 1))
     assert rel(c, start + b) <= 1e-6
     assert torch.equal(c[b == 0], start[b == 0])            # untouched entries keep their value bit for bit
 
@@ -517,15 +520,19 @@ def test_loss_curve_follows_the_autograd_oracle():
 
 
 def test_bucketed_table_scatter_in_the_training_step():
-    """config.bucketed_table_scatter on the reference's full-size field grid (16 levels x 32 slices): the step's table
-    gradient equals the atomic scatter's; the proposal grids (40 bins) keep the atomic form either way."""
+    """config.bucketed_table_scatter (on by default) on the reference's full-size field grid: levels 9-15 (scaling >= 256,
+    7 x 32 table slices) go through the bucketed records, levels 0-8 and the proposal grids (40 bins) keep the atomic scatter;
+    the step's gradients equal those of the all-atomic step."""
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("scene", 48, small=False)
-    assert gm.config.bucketed_table_scatter is False
+    assert gm.config.bucketed_table_scatter is True
+    fld = gm.field.c_struct(prepare=False, dense=False)
+    assert _hip.load().tn_hash_encode_bwd_sorted_first_level(fld.grid, o.shape[0] * 48) == 9
+    assert _hip.load().tn_hash_encode_bwd_sorted_first_level(gm.proposal_networks[0].c_struct(dense=False).grid, 4096 * 256) == -1
     _gpu_step(gm, o, d, jit, cam, batch)
-    want = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
-    gm.config.bucketed_table_scatter = True
+    got = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+    gm.config.bucketed_table_scatter = False
     _gpu_step(gm, o, d, jit, cam, batch)
-    got = {n: p.grad for n, p in gm.named_parameters() if p.grad is not None}
+    want = {n: p.grad for n, p in gm.named_parameters() if p.grad is not None}
     assert set(got) == set(want)
     name = "field.mlp_base.encoder.hash_table"
     assert float(want[name].abs().sum()) > 0 and rel(got[name], want[name]) <= 1e-5

@@ -182,9 +182,10 @@ SIGNATURES = {
     # training step
     "tn_hash_encode_fwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _i64, _vp, _vp, _vp]),
     "tn_hash_encode_bwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),
-    "tn_hash_encode_bwd_sorted_workspace_bytes": (_sz, [C.POINTER(tn_hashgrid), _i64]),
-    "tn_hash_encode_bwd_sorted_pays": (C.c_int, [C.POINTER(tn_hashgrid), _i64]),
-    "tn_hash_encode_bwd_sorted": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tn_hash_encode_bwd_levels": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "tn_hash_encode_bwd_sorted_workspace_bytes": (_sz, [C.POINTER(tn_hashgrid), _i64, _i32]),
+    "tn_hash_encode_bwd_sorted_first_level": (C.c_int, [C.POINTER(tn_hashgrid), _i64]),
+    "tn_hash_encode_bwd_sorted": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
     "tn_linear_fwd": (C.c_int, [_vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _vp]),
     "tn_linear_bwd_workspace_bytes": (_sz, []),
     "tn_linear_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,

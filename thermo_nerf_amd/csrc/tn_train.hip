@@ -59,16 +59,16 @@ hash_encode_fwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
 // run issues the atomics (x3.9 / x1.8 / x1.3 fewer on the 256- / 96- / 48-sample levels of the reference config).
 __global__ void __launch_bounds__(kBlock)
 hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positions, const float *__restrict__ d_enc,
-                       long long n, float *__restrict__ d_table) {
+                       long long n, float *__restrict__ d_table, int level_begin, int level_end) {
     const Space sp = make_space(space);
-    const int L = g.num_levels;
+    const int L = g.num_levels, LS = level_end - level_begin;  // levels [level_begin, level_end) of the L in d_enc
     const int lane = threadIdx.x & 63;
     const long long chunks = (n + 63) >> 6;
-    const long long waves = chunks * L;
+    const long long waves = chunks * LS;
     const long long wstride = (long long)gridDim.x * (kBlock / 64);
     for (long long wv = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); wv < waves; wv += wstride) {
-        const long long chunk = wv / L;
-        const int l = (int)(wv - chunk * L);
+        const long long chunk = wv / LS;
+        const int l = level_begin + (int)(wv - chunk * LS);
         const long long i = chunk * 64 + lane;
         const bool live = i < n;
         const long long ic = live ? i : n - 1;
@@ -172,7 +172,8 @@ constexpr int kSortSliceLog2 = 14;         // entries per owner slice (x 8 B = 1
 constexpr int kSortSamples = 1024;         // samples per block (4 per thread) in the count / emit passes
 constexpr int kSortMaxOwners = 1024;       // log2_hashmap_size <= 24
 constexpr int kOwnerBlock = 1024;
-constexpr int kSortMinBins = 256;
+constexpr int kSortMinBins = 128;
+constexpr float kSortMinScaling = 256.0f;
 
 struct SortRec {
     unsigned owner[4];   // slice of the (y, z) combination
@@ -216,7 +217,7 @@ struct SortArgs {
     tn_space space;
     const float *positions, *d_enc;
     long long n;
-    int owners, slice_log2;
+    int owners, slice_log2, level_begin, levels;  // levels [level_begin, level_begin + levels)
     unsigned *counts, *cursors;
     const unsigned *starts;
     unsigned *rec_pair;
@@ -230,8 +231,8 @@ __global__ void __launch_bounds__(kBlock) sort_pass_kernel(SortArgs a) {
     __shared__ unsigned base[kSortMaxOwners];
     const Space sp = make_space(a.space);
     const int L = a.g.num_levels;
-    const long long chunk = blockIdx.x / L;
-    const int l = (int)(blockIdx.x - chunk * L);
+    const long long chunk = blockIdx.x / a.levels;
+    const int lb = (int)(blockIdx.x - chunk * a.levels), l = a.level_begin + lb;  // lb: level index inside the bins
     for (int o = threadIdx.x; o < a.owners; o += kBlock) hist[o] = 0u;
     __syncthreads();
     unsigned slot[kSortSamples / kBlock][4];
@@ -256,11 +257,11 @@ __global__ void __launch_bounds__(kBlock) sort_pass_kernel(SortArgs a) {
     __syncthreads();
     if (!EMIT) {
         for (int o = threadIdx.x; o < a.owners; o += kBlock)
-            if (hist[o]) atomicAdd(&a.counts[(size_t)l * a.owners + o], hist[o]);
+            if (hist[o]) atomicAdd(&a.counts[(size_t)lb * a.owners + o], hist[o]);
         return;
     }
     for (int o = threadIdx.x; o < a.owners; o += kBlock) {
-        const size_t bin = (size_t)l * a.owners + o;
+        const size_t bin = (size_t)lb * a.owners + o;
         base[o] = hist[o] ? a.starts[bin] + atomicAdd(&a.cursors[bin], hist[o]) : 0u;
     }
     __syncthreads();
@@ -323,7 +324,7 @@ __device__ __forceinline__ void lds_add_f32(float *p, float v) {
 // one block per bin: the bucket's records into the LDS slice, the slice into d_table (+=)
 __global__ void __launch_bounds__(kOwnerBlock, 1)
 sort_owner_kernel(const unsigned *__restrict__ starts, const unsigned *__restrict__ rec_pair, const float4 *__restrict__ rec_val,
-                  int owners, int slice_log2, unsigned tsize, float *__restrict__ d_table) {
+                  int owners, int slice_log2, unsigned tsize, int level_begin, float *__restrict__ d_table) {
     extern __shared__ __attribute__((aligned(16))) float slice[];  // [2 << slice_log2]
     const unsigned bin = blockIdx.x;
     const unsigned r0 = starts[bin], r1 = starts[bin + 1];
@@ -363,7 +364,7 @@ sort_owner_kernel(const unsigned *__restrict__ starts, const unsigned *__restric
         }
     }
     __syncthreads();
-    const unsigned level = bin / owners, o = bin - level * owners;
+    const unsigned lb = bin / owners, o = bin - lb * owners, level = level_begin + lb;
     float *dst = d_table + ((size_t)level * tsize + ((size_t)o << slice_log2)) * 2;
     for (int e = threadIdx.x * 4; e < nfl; e += kOwnerBlock * 4) {
         const float4 add = *reinterpret_cast<const float4 *>(slice + e);
@@ -379,17 +380,19 @@ struct SortLayout {
     int owners, slice_log2, bins;
     size_t slots, off_cursors, off_starts, off_pair, off_val, bytes;
 };
-inline bool sort_layout(const tn_hashgrid &h, long long n, SortLayout &w) {
+inline bool sort_layout(const tn_hashgrid &h, long long n, int level_begin, SortLayout &w) {
+    if (level_begin < 0 || level_begin >= h.num_levels) return false;
+    const int levels = h.num_levels - level_begin;
     w.slice_log2 = h.log2_hashmap_size < kSortSliceLog2 ? h.log2_hashmap_size : kSortSliceLog2;
     w.owners = 1 << (h.log2_hashmap_size - w.slice_log2);
-    w.bins = w.owners * h.num_levels;
+    w.bins = w.owners * levels;
     // both x-neighbours of a record must fall into one slice: x (<= finest scaling + 1) may only touch bits below the slice
     float top = 0.0f;
     for (int l = 0; l < h.num_levels; ++l) top = h.scalings[l] > top ? h.scalings[l] : top;
     if (w.owners > 1 && top + 2.0f >= (float)(1 << w.slice_log2)) return false;
     if (w.owners > kSortMaxOwners || w.slice_log2 > 16) return false;
 
-    const long long slots = n * h.num_levels * 4;
+    const long long slots = n * levels * 4;
     if (slots >= (1LL << 32) - 4096) return false;
     w.slots = (size_t)slots;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1657,42 +1660,63 @@ int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const flo
     return TN_OK;
 }
 
-int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
-                       int64_t n, float *d_table, void *stream) {
+static int hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                                  int64_t n, float *d_table, int level_begin, int level_end, void *stream) {
     if (!grid || !space) return TN_ERR_NULL;
     TN_TRY(tn_check_grid(*grid));
-    if (n == 0) return TN_OK;
+    if (level_begin < 0 || level_end > grid->num_levels || level_begin > level_end) return TN_ERR_SHAPE;
+    if (n == 0 || level_begin == level_end) return TN_OK;
     if (!positions || !d_enc || !d_table) return TN_ERR_NULL;
     if (n < 0) return TN_ERR_SHAPE;
-    hipLaunchKernelGGL(hash_encode_bwd_kernel, dim3(grid_for(((n + 63) / 64) * grid->num_levels, kBlock / 64, 1 << 16)), dim3(kBlock), 0,
-                       (hipStream_t)stream, tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_table);
+    hipLaunchKernelGGL(hash_encode_bwd_kernel, dim3(grid_for(((n + 63) / 64) * (level_end - level_begin), kBlock / 64, 1 << 16)),
+                       dim3(kBlock), 0, (hipStream_t)stream, tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_table,
+                       level_begin, level_end);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
 
-size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n) {
+int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                       int64_t n, float *d_table, void *stream) {
+    if (!grid) return TN_ERR_NULL;
+    return hash_encode_bwd_levels(grid, space, positions, d_enc, n, d_table, 0, grid->num_levels, stream);
+}
+
+int tn_hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, int32_t level_begin, int32_t level_end, void *stream) {
+    return hash_encode_bwd_levels(grid, space, positions, d_enc, n, d_table, level_begin, level_end, stream);
+}
+
+size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n, int32_t level_begin) {
     SortLayout w;
-    if (!grid || n <= 0 || tn_check_grid(*grid) != TN_OK || !sort_layout(*grid, n, w)) return 0;
+    if (!grid || n <= 0 || tn_check_grid(*grid) != TN_OK || !sort_layout(*grid, n, level_begin, w)) return 0;
     return w.bytes;
 }
 
-// one block per bin owns a CU's LDS: fewer bins than CUs (the proposal grids: 5 levels x 8 slices) leave most of the chip idle
-// behind a few very long buckets — the atomic scatter is faster there (measured: 1.16 against 0.90 ms per training step)
-int tn_hash_encode_bwd_sorted_pays(const tn_hashgrid *grid, int64_t n) {
+// Where the bucketed form pays: the first level from which it should take over (the atomic kernel keeps the levels below), or
+// -1 = nowhere.  Measured on a real step's inputs (tools/scatter_bench.py --real --levels): below a scaling of ~256 the samples
+// of a ray — and of its neighbours — crowd into few entries and the owner pass's compare-and-swap adds retry (40-90 us per
+// level against 20-30 for the atomics); from there up the bucketed form costs 16-20 us per level against 29-33.  And one block
+// per bin owns a CU's LDS: fewer than 128 bins (the proposal grids: 5 levels x 8 slices) leave the chip idle behind a few long
+// buckets.
+int tn_hash_encode_bwd_sorted_first_level(const tn_hashgrid *grid, int64_t n) {
+    if (!grid || n <= 0 || tn_check_grid(*grid) != TN_OK) return -1;
+    int first = 0;
+    while (first < grid->num_levels && grid->scalings[first] < kSortMinScaling) ++first;
     SortLayout w;
-    if (!grid || n <= 0 || tn_check_grid(*grid) != TN_OK || !sort_layout(*grid, n, w)) return 0;
-    return w.bins >= kSortMinBins ? 1 : 0;
+    if (first >= grid->num_levels || !sort_layout(*grid, n, first, w)) return -1;
+    return w.bins >= kSortMinBins ? first : -1;
 }
 
 int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
-                              int64_t n, float *d_table, void *workspace, size_t workspace_bytes, void *stream) {
+                              int64_t n, float *d_table, int32_t level_begin, void *workspace, size_t workspace_bytes,
+                              void *stream) {
     if (!grid || !space) return TN_ERR_NULL;
     TN_TRY(tn_check_grid(*grid));
     if (n == 0) return TN_OK;
     if (!positions || !d_enc || !d_table || !workspace) return TN_ERR_NULL;
     if (n < 0) return TN_ERR_SHAPE;
     SortLayout w;
-    if (!sort_layout(*grid, n, w)) return TN_ERR_UNSUPPORTED;
+    if (!sort_layout(*grid, n, level_begin, w)) return TN_ERR_UNSUPPORTED;
     if (workspace_bytes < w.bytes) return TN_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return TN_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -1702,6 +1726,7 @@ int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, co
     a.space = *space;
     a.positions = positions; a.d_enc = d_enc; a.n = n;
     a.owners = w.owners; a.slice_log2 = w.slice_log2;
+    a.level_begin = level_begin; a.levels = grid->num_levels - level_begin;
     a.counts = reinterpret_cast<unsigned *>(ws);
     a.cursors = reinterpret_cast<unsigned *>(ws + w.off_cursors);
     unsigned *starts = reinterpret_cast<unsigned *>(ws + w.off_starts);
@@ -1710,7 +1735,7 @@ int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, co
     a.rec_val = reinterpret_cast<float4 *>(ws + w.off_val);
     if (hipMemsetAsync(ws, 0, w.off_starts, s) != hipSuccess) return TN_ERR_LAUNCH;  // counts and cursors
     const long long chunks = (n + kSortSamples - 1) / kSortSamples;
-    const long long blocks = chunks * grid->num_levels;
+    const long long blocks = chunks * a.levels;
     if (blocks > 0x7fffffffLL) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(sort_pass_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     TN_LAUNCH_CHECK();
@@ -1721,7 +1746,7 @@ int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, co
     const size_t smem = (size_t)(2 << w.slice_log2) * sizeof(float);
     if (smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_owner_kernel>(smem)) return TN_ERR_LAUNCH;
     hipLaunchKernelGGL(sort_owner_kernel, dim3((unsigned)w.bins), dim3(kOwnerBlock), smem, s, starts, a.rec_pair, a.rec_val, w.owners,
-                       w.slice_log2, 1u << grid->log2_hashmap_size, d_table);
+                       w.slice_log2, 1u << grid->log2_hashmap_size, level_begin, d_table);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -92,9 +92,10 @@ class NerfactoModelConfig:
     """Training: the final level's field forward (encode + mlp_base + heads, with its tape) as ONE MFMA kernel
     (tn_field_fwd_taped); False: the stage-by-stage entry points (one launch per nerfstudio module)."""
     fused_train_backward: bool = True
-    # hash-table gradient of the field as bucketed records + LDS sums instead of global atomics (tn_hash_encode_bwd_sorted):
-    # measured 5.22 against 5.38 ms per step at S=192, 2.39 against 2.29 at S=48 — off by default (DESIGN §5.6)
-    bucketed_table_scatter: bool = False
+    # hash-table gradient of the field: the fine levels (scaling >= 256) as bucketed records + LDS sums instead of global
+    # atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,
+    # 2.24 against 2.27 at S=48 (DESIGN §5.6)
+    bucketed_table_scatter: bool = True
     """Training: the backward of each MLP (mlp_head, mlp_thermal + head, mlp_base, the proposal MLPs) as ONE launch per MLP
     (tn_linear_chain_bwd: one tile read per layer); False: one tn_linear_bwd launch per layer."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"

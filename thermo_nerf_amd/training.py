@@ -48,23 +48,27 @@ def hash_encode_fwd(grid, space, pos: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False) -> None:
-    """d_table += adjoint of the hash encoding: the global-atomic scatter (tn_hash_encode_bwd), or with ``bucketed``
-    (config.bucketed_table_scatter, off by default) contributions written out as records bucketed by the owning table
-    slice and summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 20 B of scratch per (sample, level, corner
-    pair)) where the library says that pays."""
+    """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
+    ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 256, enough table slices: the
+    field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
+    summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 20 B of scratch per (sample, level, corner pair)), the
+    coarser levels keep the atomics.  An int (tests): bucketed from that level on, whatever the library advises."""
     lib = _hip.load()
     n = pos.shape[0]
-    # bucketed=True: where the library says it pays (>= 256 bins: the field's grid, not the proposal grids); "force": wherever
-    # the geometry allows it (tests)
-    use = bucketed == "force" or (bool(bucketed) and lib.tn_hash_encode_bwd_sorted_pays(grid, n))
-    need = lib.tn_hash_encode_bwd_sorted_workspace_bytes(grid, n) if use else 0
-    if need:
-        ws = torch.empty(need, dtype=torch.uint8, device=pos.device)
-        _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(),
-                                                 ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
+    args = (grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr())
+    first = -1
+    if bucketed is True:
+        first = lib.tn_hash_encode_bwd_sorted_first_level(grid, n)
+    elif bucketed is not False and bucketed is not None:
+        first = int(bucketed)
+    need = lib.tn_hash_encode_bwd_sorted_workspace_bytes(grid, n, first) if first >= 0 else 0
+    if not need:
+        _hip.check(lib.tn_hash_encode_bwd(*args, _stream()), "tn_hash_encode_bwd")
         return
-    _hip.check(lib.tn_hash_encode_bwd(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), _stream()),
-               "tn_hash_encode_bwd")
+    if first > 0:
+        _hip.check(lib.tn_hash_encode_bwd_levels(*args, 0, first, _stream()), "tn_hash_encode_bwd_levels")
+    ws = torch.empty(need, dtype=torch.uint8, device=pos.device)
+    _hip.check(lib.tn_hash_encode_bwd_sorted(*args, first, ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
 
 
 def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor:
@@ -486,7 +490,7 @@ class RenderTrain(torch.autograd.Function):
             g_h1 = _f32((N, W), dev)
             linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
             linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
-        bucketed = bool(getattr(cfg, "bucketed_table_scatter", False))
+        bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
         hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)

@@ -20,14 +20,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--weights", default="scene")
     ap.add_argument("--no-opt", action="store_true")
-    ap.add_argument("--bucketed", action="store_true", help="config.bucketed_table_scatter (tn_hash_encode_bwd_sorted)")
+    ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt,
-                                 bucketed_table_scatter=a.bucketed)
+                                 bucketed_table_scatter=not a.atomic_scatter)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
