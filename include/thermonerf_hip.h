@@ -304,7 +304,8 @@ int tn_hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, co
 /* The same adjoint without global atomics for the levels [level_begin, num_levels): contributions are written out as records
  * bucketed by the table slice (2^14 entries) that owns them and summed per slice in LDS, then added to d_table (+=) with plain
  * loads / stores.  Needs tn_hash_encode_bwd_sorted_workspace_bytes(grid, n, level_begin) bytes of 16-byte aligned device
- * scratch (20 B per (sample, level, corner pair)); that function returns 0 — and tn_hash_encode_bwd_sorted
+ * scratch (a fixed region per (level, slice) bin sized 1.25 x an even spread: ~25 B per (sample, level, corner pair); a
+ * record that does not fit its bin's region is added with global atomics instead); that function returns 0 — and tn_hash_encode_bwd_sorted
  * TN_ERR_UNSUPPORTED — for a geometry the bucketing does not cover (finest scaling + 2 >= 2^14 with more than one slice, or
  * >= 2^32 records).  tn_hash_encode_bwd_sorted_first_level: the level from which this form is the faster one on this part
  * (levels with a scaling >= 256, at least 128 (level, slice) bins), or -1: the caller runs tn_hash_encode_bwd_levels on the

@@ -163,9 +163,12 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
 //   * a level's table is cut into slices of 2^14 entries (128 KB of float2 = one CU's LDS); bin = (level, slice);
 //   * a record = the two x-neighbour corners of one (y, z) combination of one sample: (local index pair, 4 floats) — both
 //     corners are in the same slice because x only touches the low 12 bits of the hashed index;
-//   * count pass (bin sizes) -> exclusive scan -> emit pass (a block reserves a contiguous run per bin with ONE global
-//     atomic per bin and block, ranks come from LDS atomics) -> owner pass: one 1024-thread block per bin adds its records
-//     into the LDS slice (ds_add_f32) and adds the slice to d_table with plain coalesced loads / stores.
+//   * emit pass: every bin has a fixed region of `capacity` records (1.25 x its share of an even spread + 1024: the hash
+//     spreads the fine levels' entries evenly over the slices); a block reserves a contiguous run per bin with ONE global
+//     atomic per bin and block, ranks come from LDS atomics; a record that no longer fits its bin's region (forced coarse
+//     levels, degenerate inputs) is added to d_table with global atomics right there — always correct, no counting pass;
+//   * owner pass: one 1024-thread block per bin adds its records into the LDS slice and adds the slice to d_table with plain
+//     coalesced loads / stores.
 // Traffic: 20 B per record written and read once (252 MB per 196 k-sample call) + the table once, all streaming.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kSortSliceLog2 = 14;         // entries per owner slice (x 8 B = 128 KB of LDS)
@@ -218,15 +221,15 @@ struct SortArgs {
     const float *positions, *d_enc;
     long long n;
     int owners, slice_log2, level_begin, levels;  // levels [level_begin, level_begin + levels)
-    unsigned *counts, *cursors;
-    const unsigned *starts;
-    unsigned *rec_pair;
+    unsigned *cursors;   // [bins] records reserved so far (may run past capacity)
+    unsigned capacity;   // records per bin region
+    unsigned *rec_pair;  // [bins][capacity]
     float4 *rec_val;
+    float *d_table;      // for the records that overflow a region
 };
 
-// EMIT == false: bin sizes.  EMIT == true: reserve and write.  blockIdx.x = chunk * L + level.
-template <bool EMIT>
-__global__ void __launch_bounds__(kBlock) sort_pass_kernel(SortArgs a) {
+// blockIdx.x = chunk * levels + level: 1024 consecutive samples at one level -> ranks, one reservation per bin, records
+__global__ void __launch_bounds__(kBlock) sort_emit_kernel(SortArgs a) {
     __shared__ unsigned hist[kSortMaxOwners];
     __shared__ unsigned base[kSortMaxOwners];
     const Space sp = make_space(a.space);
@@ -241,30 +244,20 @@ __global__ void __launch_bounds__(kBlock) sort_pass_kernel(SortArgs a) {
         const long long i = chunk * kSortSamples + k * kBlock + threadIdx.x;
         float2 ge = make_float2(0.0f, 0.0f);
         if (i < a.n) ge = reinterpret_cast<const float2 *>(a.d_enc)[i * L + l];
-        const bool on = ge.x != 0.0f || ge.y != 0.0f;  // a sample without gradient writes no record (same test in both passes)
-        if (on) {
+        if (ge.x != 0.0f || ge.y != 0.0f) {  // a sample without gradient writes no record
             float px, py, pz;
             normalize_position(sp, a.positions[i * 3], a.positions[i * 3 + 1], a.positions[i * 3 + 2], px, py, pz);
             SortRec r;
             sort_records<false>(a.g, l, a.slice_log2, px, py, pz, ge, r);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned rank = atomicAdd(&hist[r.owner[p]], 1u);
-                slot[k][p] = rank;
-            }
+            for (int p = 0; p < 4; ++p) slot[k][p] = atomicAdd(&hist[r.owner[p]], 1u);
         }
     }
     __syncthreads();
-    if (!EMIT) {
-        for (int o = threadIdx.x; o < a.owners; o += kBlock)
-            if (hist[o]) atomicAdd(&a.counts[(size_t)lb * a.owners + o], hist[o]);
-        return;
-    }
-    for (int o = threadIdx.x; o < a.owners; o += kBlock) {
-        const size_t bin = (size_t)lb * a.owners + o;
-        base[o] = hist[o] ? a.starts[bin] + atomicAdd(&a.cursors[bin], hist[o]) : 0u;
-    }
+    for (int o = threadIdx.x; o < a.owners; o += kBlock)
+        base[o] = hist[o] ? atomicAdd(&a.cursors[(size_t)lb * a.owners + o], hist[o]) : 0u;
     __syncthreads();
+    float *tb = a.d_table + ((size_t)l * a.g.tsize) * 2;
 #pragma unroll
     for (int k = 0; k < kSortSamples / kBlock; ++k) {
         const long long i = chunk * kSortSamples + k * kBlock + threadIdx.x;
@@ -277,35 +270,23 @@ __global__ void __launch_bounds__(kBlock) sort_pass_kernel(SortArgs a) {
             sort_records<true>(a.g, l, a.slice_log2, px, py, pz, ge, r);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const size_t at = (size_t)base[r.owner[p]] + slot[k][p];
-                a.rec_pair[at] = r.pair[p];
-                a.rec_val[at] = r.val[p];
+                const unsigned o = r.owner[p], at = base[o] + slot[k][p];
+                if (at < a.capacity) {
+                    const size_t w = ((size_t)lb * a.owners + o) * a.capacity + at;
+                    a.rec_pair[w] = r.pair[p];
+                    a.rec_val[w] = r.val[p];
+                } else {  // the bin's region is full: straight into the table
+                    float *pa = tb + (((size_t)o << a.slice_log2) + (r.pair[p] & 0xffffu)) * 2;
+                    float *pb = tb + (((size_t)o << a.slice_log2) + (r.pair[p] >> 16)) * 2;
+                    const float4 v = r.val[p];
+                    if (v.x != 0.0f) atomic_add_f32(pa, v.x);
+                    if (v.y != 0.0f) atomic_add_f32(pa + 1, v.y);
+                    if (v.z != 0.0f) atomic_add_f32(pb, v.z);
+                    if (v.w != 0.0f) atomic_add_f32(pb + 1, v.w);
+                }
             }
         }
     }
-}
-
-// exclusive scan of the bin sizes (<= 16 x 1024 bins) by one block; starts[bins] = total
-__global__ void __launch_bounds__(1024) sort_scan_kernel(const unsigned *__restrict__ counts, int bins, unsigned *__restrict__ starts) {
-    __shared__ unsigned part[1024];
-    const int per = (bins + 1023) / 1024;
-    const int b0 = threadIdx.x * per, b1 = min(bins, b0 + per);
-    unsigned s = 0;
-    for (int b = b0; b < b1; ++b) s += counts[b];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned run = part[threadIdx.x] - s;
-    for (int b = b0; b < b1; ++b) {
-        starts[b] = run;
-        run += counts[b];
-    }
-    if (threadIdx.x == 1023) starts[bins] = part[1023];
 }
 
 // fp32 add into LDS through a compare-and-swap loop: ds_add_f32 retires 0.33 lanes per clock and CU on this part whatever the
@@ -323,12 +304,17 @@ __device__ __forceinline__ void lds_add_f32(float *p, float v) {
 
 // one block per bin: the bucket's records into the LDS slice, the slice into d_table (+=)
 __global__ void __launch_bounds__(kOwnerBlock, 1)
-sort_owner_kernel(const unsigned *__restrict__ starts, const unsigned *__restrict__ rec_pair, const float4 *__restrict__ rec_val,
-                  int owners, int slice_log2, unsigned tsize, int level_begin, float *__restrict__ d_table) {
+sort_owner_kernel(const unsigned *__restrict__ cursors, unsigned capacity, const unsigned *__restrict__ rec_pair,
+                  const float4 *__restrict__ rec_val, int owners, int slice_log2, unsigned tsize, int level_begin,
+                  float *__restrict__ d_table) {
     extern __shared__ __attribute__((aligned(16))) float slice[];  // [2 << slice_log2]
     const unsigned bin = blockIdx.x;
-    const unsigned r0 = starts[bin], r1 = starts[bin + 1];
-    if (r0 == r1) return;  // nothing touched this slice
+    const unsigned filled = min(cursors[bin], capacity);
+    if (filled == 0u) return;  // nothing touched this slice
+    const size_t region = (size_t)bin * capacity;
+    rec_pair += region;
+    rec_val += region;
+    const unsigned r0 = 0u, r1 = filled;
     const int nfl = 2 << slice_log2;
     for (int e = threadIdx.x * 4; e < nfl; e += kOwnerBlock * 4) *reinterpret_cast<float4 *>(slice + e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
@@ -378,7 +364,8 @@ sort_owner_kernel(const unsigned *__restrict__ starts, const unsigned *__restric
 
 struct SortLayout {
     int owners, slice_log2, bins;
-    size_t slots, off_cursors, off_starts, off_pair, off_val, bytes;
+    unsigned capacity;
+    size_t slots, off_pair, off_val, bytes;
 };
 inline bool sort_layout(const tn_hashgrid &h, long long n, int level_begin, SortLayout &w) {
     if (level_begin < 0 || level_begin >= h.num_levels) return false;
@@ -391,14 +378,15 @@ inline bool sort_layout(const tn_hashgrid &h, long long n, int level_begin, Sort
     for (int l = 0; l < h.num_levels; ++l) top = h.scalings[l] > top ? h.scalings[l] : top;
     if (w.owners > 1 && top + 2.0f >= (float)(1 << w.slice_log2)) return false;
     if (w.owners > kSortMaxOwners || w.slice_log2 > 16) return false;
-
-    const long long slots = n * levels * 4;
-    if (slots >= (1LL << 32) - 4096) return false;
+    // a bin's region: its share of an even spread of the level's 4 n records, + 25 % + 1024
+    const long long share = (n * 4 + w.owners - 1) / w.owners;
+    const long long cap = ((share + share / 4 + 1024) + 63) & ~63LL;
+    const long long slots = cap * w.bins;
+    if (cap >= (1LL << 31) || slots >= (1LL << 40)) return false;
+    w.capacity = (unsigned)cap;
     w.slots = (size_t)slots;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    w.off_cursors = up((size_t)w.bins * 4);
-    w.off_starts = w.off_cursors + up((size_t)w.bins * 4);
-    w.off_pair = w.off_starts + up((size_t)(w.bins + 1) * 4);
+    w.off_pair = up((size_t)w.bins * 4);
     w.off_val = w.off_pair + up(w.slots * 4);
     w.bytes = w.off_val + w.slots * 16;
     return true;
@@ -1727,26 +1715,21 @@ int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, co
     a.positions = positions; a.d_enc = d_enc; a.n = n;
     a.owners = w.owners; a.slice_log2 = w.slice_log2;
     a.level_begin = level_begin; a.levels = grid->num_levels - level_begin;
-    a.counts = reinterpret_cast<unsigned *>(ws);
-    a.cursors = reinterpret_cast<unsigned *>(ws + w.off_cursors);
-    unsigned *starts = reinterpret_cast<unsigned *>(ws + w.off_starts);
-    a.starts = starts;
+    a.cursors = reinterpret_cast<unsigned *>(ws);
+    a.capacity = w.capacity;
     a.rec_pair = reinterpret_cast<unsigned *>(ws + w.off_pair);
     a.rec_val = reinterpret_cast<float4 *>(ws + w.off_val);
-    if (hipMemsetAsync(ws, 0, w.off_starts, s) != hipSuccess) return TN_ERR_LAUNCH;  // counts and cursors
+    a.d_table = d_table;
+    if (hipMemsetAsync(ws, 0, (size_t)w.bins * 4, s) != hipSuccess) return TN_ERR_LAUNCH;
     const long long chunks = (n + kSortSamples - 1) / kSortSamples;
     const long long blocks = chunks * a.levels;
     if (blocks > 0x7fffffffLL) return TN_ERR_SHAPE;
-    hipLaunchKernelGGL(sort_pass_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
-    TN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, a.counts, w.bins, starts);
-    TN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_pass_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(sort_emit_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
     TN_LAUNCH_CHECK();
     const size_t smem = (size_t)(2 << w.slice_log2) * sizeof(float);
     if (smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_owner_kernel>(smem)) return TN_ERR_LAUNCH;
-    hipLaunchKernelGGL(sort_owner_kernel, dim3((unsigned)w.bins), dim3(kOwnerBlock), smem, s, starts, a.rec_pair, a.rec_val, w.owners,
-                       w.slice_log2, 1u << grid->log2_hashmap_size, level_begin, d_table);
+    hipLaunchKernelGGL(sort_owner_kernel, dim3((unsigned)w.bins), dim3(kOwnerBlock), smem, s, a.cursors, w.capacity, a.rec_pair,
+                       a.rec_val, w.owners, w.slice_log2, 1u << grid->log2_hashmap_size, level_begin, d_table);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

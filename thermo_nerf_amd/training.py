@@ -51,7 +51,7 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
     """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
     ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 256, enough table slices: the
     field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
-    summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 20 B of scratch per (sample, level, corner pair)), the
+    summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 25 B of scratch per (sample, level, corner pair)), the
     coarser levels keep the atomics.  An int (tests): bucketed from that level on, whatever the library advises."""
     lib = _hip.load()
     n = pos.shape[0]
