@@ -339,13 +339,15 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
                   float *d_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* density = average_init_density * trunc_exp(raw) * selector (NS get_density); raw rows ld_raw floats apart.
- * backward: d_raw = d_density * average_init_density * exp(min(raw, 15)) * selector (NS trunc_exp.backward), written to
+ * backward: d_raw = d_density * average_init_density * exp(clamp(raw, trunc_exp_min, 15)) * selector (NS trunc_exp.backward:
+ * trunc_exp_min = -15 is nerfstudio's / torch-ngp's two-sided clamp, -INFINITY clamps from above only), written to
  * column 0 of rows ld_d_raw apart; columns 1 .. clear_cols-1 of each row are set to zero (clear_cols <= 1: untouched) so that
  * the row can be the += target of the stages behind it without a separate fill. */
 int tn_density_act_fwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density, int64_t n,
                        float *density, void *stream);
 int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density,
-                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, int32_t clear_cols, void *stream);
+                       float trunc_exp_min, const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw,
+                       int32_t clear_cols, void *stream);
 
 /* backward of tn_weights_fwd: d_weights [R,n] -> d_densities [R,n]. */
 int tn_weights_bwd(const float *deltas, const float *densities, const float *d_weights, int64_t num_rays, int32_t n,
@@ -381,6 +383,35 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
                        const int32_t *camera_indices, int64_t num_rays, int32_t n, float *enc, float *selector, float *h1,
                        float *bo, float *density, float *c1, float *c2, float *rgb, float *t1, float *t2, float *thermal,
                        void *stream);
+
+/* The tape-free pair of the final level's training pass [REF thermal_field.py:108-201 differentiated; the modules
+ * constructed at thermal_field.py:62-102].  tn_field_fwd_train is tn_field_fwd_taped keeping only what compositing, the
+ * losses and the backward read: enc [N,32], selector [N], density [N], rgb [N,3], thermal [N].  `ray_bias` [R,64] = mlp_head.0's
+ * bias plus its SH(direction) and appearance-embedding columns applied to each ray's constants (tn_color_input_fwd with n = 1
+ * and zero geo rows, then tn_linear_fwd with mlp_head.0): the colour layer sees them as a per-ray bias.
+ *
+ * tn_field_bwd_fused recomputes the five hidden layers from `enc` in registers and runs their adjoints next to them (no
+ * [N,64] activation ever touches HBM).  Inputs: enc / selector / rgb of the forward, ray_bias, the per-sample output
+ * gradients d_rgb [N,3], d_thermal [N] (either may be NULL: that branch is skipped), d_density [N].  Outputs: d_enc [N,32]
+ * (=), d_ray_sum [R,64] (+=, zero it first) = per-ray sums of mlp_head.0's pre-activation gradient — the ray-level
+ * tn_linear_bwd(x = the ray rows of tn_color_input_fwd, dy = d_ray_sum) then yields mlp_head.0's bias gradient, its SH and
+ * appearance weight columns and, through tn_color_input_bwd with n = 1, the embedding / direction gradients — and the
+ * gradients of every other Linear of the field (+=; NULL entries skipped; head0_w receives its geo columns 16..30 only).
+ * trunc_exp_min: lower clamp of trunc_exp's backward (g * exp(clamp(x, min, 15)); -15 = torch-ngp / nerfstudio's
+ * two-sided clamp, -INFINITY = upper clamp only).  pass_thermal_gradients = 0 keeps the thermal branch from the geo
+ * features [REF thermal_field.py:171-172].  The reference geometry only (16 levels, geo 15, appearance 32). */
+typedef struct tn_field_grads {
+    float *base0_w, *base0_b, *base1_w, *base1_b;
+    float *head0_w, *head1_w, *head1_b, *head2_w, *head2_b;
+    float *th0_w, *th0_b, *th1_w, *th1_b, *thead_w, *thead_b;
+} tn_field_grads;
+int tn_field_fwd_train(const tn_thermal_field *field, const float *positions, const float *ray_bias, int64_t num_rays,
+                       int32_t n, float *enc, float *selector, float *density, float *rgb, float *thermal, void *stream);
+size_t tn_field_bwd_fused_workspace_bytes(void);
+int tn_field_bwd_fused(const tn_thermal_field *field, int64_t num_rays, int32_t n, const float *enc, const float *selector,
+                       const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
+                       const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, float *d_enc,
+                       float *d_ray_sum, const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
 
 /* NS scale_gradients_by_distance_squared [REF thermal_nerf_model.py:228-231, use_gradient_scaling]: the forward is the
  * identity; in the backward the gradient of EVERY field output of a sample (density [n], rgb [n,3], thermal [n]; any may

@@ -11,9 +11,13 @@ the nerfstudio 1.1.5 symbol (``NS``; third-party, pinned in uv.lock, source not 
 
 PARITY PINNING STATUS
 ---------------------
-* Pinned against the real reference code (run in the build container, fixtures under tests/golden/):
-  ``render_thermal`` (G1: thermo_nerf/thermal_nerf/thermal_renderer.py) and ``mae_thermal``
-  (G2: thermo_nerf/thermal_nerf/thermal_metrics.py).
+* Pinned against the real reference code (run in the build container by tools/make_golden.py, fixtures under
+  tests/golden/, checked in tests/test_oracle_golden.py): ``render_thermal`` (G1: thermal_renderer.py), ``mae_thermal``
+  (G2: thermal_metrics.py), ``render_rgb`` (G4: rgb_concat/rgbt_renderer.py), the thermal head (G5:
+  thermal_field_head.py), the wiring of ``field_outputs`` (G6: thermal_field.py run on oracle-built nerfstudio stand-ins)
+  and the orchestration / loss dictionary of ``get_outputs`` + ``oracle.training.get_loss_dict`` (G7:
+  thermal_nerf_model.py:210-326 run the same way).  G6 / G7 pin WIRING (which module sees which tensor, keys, gates,
+  multipliers), not nerfstudio's arithmetic.
 * **Parity unpinned** at the nerfstudio boundary: the reference's own tests hold no numeric vector for
   this path and nerfstudio cannot be imported here.  Everything tagged ``NS`` below
   restates nerfstudio 1.1.5's published torch-fallback algorithm.
@@ -68,6 +72,10 @@ class OracleConfig:
     use_same_proposal_network: bool = False  # [REF thermal_nerf_model.py:127-139]: one network for every proposal level
     use_gradient_scaling: bool = False  # [REF :228-231]: NS scale_gradients_by_distance_squared on the field outputs
     proposal_initial_sampler: str = "piecewise"  # [REF :164-170]: "uniform" -> NS UniformSampler
+    # NS field_components/activations.py trunc_exp (taken from torch-ngp): backward g * exp(clamp(x, min=-15, max=15)).
+    # SURVEY A.3 tags the bounds [UNSURE]: -inf here gives the upper-clamp-only form.  Differs only for raw densities below
+    # -15 (gradient factor < 3e-7).  The product mirrors it as config.trunc_exp_clamp_min.
+    trunc_exp_clamp_min: float = -15.0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -201,20 +209,23 @@ def sh4(d: Tensor) -> Tensor:
 
 
 class _TruncExp(torch.autograd.Function):
-    """NS field_components.activations.trunc_exp: forward exp(x), backward g * exp(clamp(x, max=15))."""
+    """NS field_components.activations.trunc_exp: forward exp(x), backward g * exp(clamp(x, min=lo, max=15)); lo = -15 in
+    nerfstudio (from torch-ngp), -inf = clamp from above only (OracleConfig.trunc_exp_clamp_min)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, lo):
         ctx.save_for_backward(x)
+        ctx.lo = lo
         return torch.exp(x)
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        return g * torch.exp(torch.clamp(x, max=15.0))
+        return g * torch.exp(torch.clamp(x, min=ctx.lo, max=15.0)), None
 
 
-trunc_exp = _TruncExp.apply
+def trunc_exp(x: Tensor, lo: float = -15.0) -> Tensor:
+    return _TruncExp.apply(x, float(lo))
 
 
 class _GradientScaler(torch.autograd.Function):
@@ -250,7 +261,7 @@ def proposal_density(sd: Dict[str, Tensor], level: int, positions: Tensor, cfg: 
         args["log2_hashmap_size"],
     )
     raw = mlp(enc, _layers(sd, f"{pre}.mlp_base.mlp", 2), None).view(*shape, -1)
-    density = 1.0 * trunc_exp(raw)  # average_init_density default 1.0
+    density = 1.0 * trunc_exp(raw, cfg.trunc_exp_clamp_min)  # average_init_density default 1.0
     return density * selector[..., None]
 
 
@@ -264,7 +275,7 @@ def field_density(sd: Dict[str, Tensor], positions: Tensor, cfg: OracleConfig) -
     )
     h = mlp(enc, _layers(sd, "field.mlp_base.mlp", 2), None).view(*shape, -1)
     raw, geo = torch.split(h, [1, cfg.geo_feat_dim], dim=-1)
-    density = cfg.average_init_density * trunc_exp(raw)
+    density = cfg.average_init_density * trunc_exp(raw, cfg.trunc_exp_clamp_min)
     density = density * selector[..., None]
     return density, geo
 

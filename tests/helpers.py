@@ -28,6 +28,7 @@ def oracle_config(cfg: ThermalNerfModelConfig) -> H.OracleConfig:
         disable_scene_contraction=cfg.disable_scene_contraction, sh_input=cfg.sh_input,
         sh_grad=cfg.sh_direction_gradient, use_same_proposal_network=cfg.use_same_proposal_network,
         use_gradient_scaling=cfg.use_gradient_scaling, proposal_initial_sampler=cfg.proposal_initial_sampler,
+        trunc_exp_clamp_min=cfg.trunc_exp_clamp_min,
     )
 
 

@@ -320,20 +320,23 @@ def _gpu_step(gm, o, d, jit, cam, batch):
 ONE_NET = {"one_proposal_network": True}  # helpers.build: use_same_proposal_network + a one-entry proposal_net_args_list
 
 
-@pytest.mark.parametrize("variant", ["default", "stage_forward", "gradient_scaling", "same_proposal_network",
-                                     "uniform_initial_sampler"])
+@pytest.mark.parametrize("variant", ["default", "taped", "stage_forward", "gradient_scaling", "same_proposal_network",
+                                     "uniform_initial_sampler", "trunc_exp_one_sided"])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 @pytest.mark.parametrize("S", [48, 64, 192])  # 192 = BASELINE config 3 (multi-chunk scans in every per-ray kernel)
 def test_training_step_matches_autograd_oracle(kind, S, variant):
     """variant: the reference's config switches on this path — use_gradient_scaling [REF thermal_nerf_model.py:228-231],
     use_same_proposal_network [REF :122-139] and proposal_initial_sampler="uniform" [REF :164-170] — next to the default
     configuration."""
-    if variant not in ("default", "stage_forward") and S != 48:
+    if variant not in ("default", "taped", "stage_forward") and S != 48:
         pytest.skip("config variants are checked at the reference's default sample count")
-    # default = the final level's forward as one fused MFMA kernel (tn_field_fwd_taped) and each MLP's backward as one launch
-    # (tn_linear_chain_bwd); stage_forward = one launch per nerfstudio module / layer in both directions
+    # default = the tape-free final level (tn_field_fwd_train + tn_field_bwd_fused: the hidden layers recomputed in the backward);
+    # taped = the final level's forward as one MFMA kernel writing the tape (tn_field_fwd_taped) and each MLP's backward as one
+    # launch (tn_linear_chain_bwd); stage_forward = one launch per nerfstudio module / layer in both directions
     over = {"gradient_scaling": {"use_gradient_scaling": True}, "same_proposal_network": ONE_NET,
-            "stage_forward": {"fused_train_forward": False, "fused_train_backward": False},
+            "taped": {"tape_free_training": False},
+            "stage_forward": {"tape_free_training": False, "fused_train_forward": False, "fused_train_backward": False},
+            "trunc_exp_one_sided": {"trunc_exp_clamp_min": float("-inf")},
             "uniform_initial_sampler": {"proposal_initial_sampler": "uniform", "far_plane": 6.0}}.get(variant, {})
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, **over)
     if variant == "same_proposal_network":
@@ -410,6 +413,57 @@ def test_fused_field_forward_writes_the_stage_chain_tape(hw):
         err = (got - want).abs().max().item()
         assert err <= tol * max(1.0, want.abs().max().item()), f"{name}: {err:.3e}"
     assert rel(dens, dens_s) <= 1e-5
+
+
+@pytest.mark.parametrize("hw", [(12, 12), (7, 5), (1, 1), (1, 3)])  # (7,5) x 48 = 1680 samples: a ragged last 32-sample tile
+@pytest.mark.parametrize("S", [48, 192, 5])
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+def test_tape_free_step_equals_the_taped_step(kind, S, hw):
+    """tn_field_fwd_train + tn_field_bwd_fused (nothing but 38 floats per sample kept, the hidden layers recomputed in the
+    backward) against the taped forward + chained backward on the same batch: same outputs, losses and parameter gradients up
+    to fp32 summation order (the oracle comparison of both is test_training_step_matches_autograd_oracle)."""
+    got = {}
+    for tape_free in (True, False):
+        gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, R_hw=hw, tape_free_training=tape_free)
+        out, loss = _gpu_step(gm, o, d, jit, cam, batch)
+        got[tape_free] = (out, loss, {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None})
+    (o1, l1, g1), (o0, l0, g0) = got[True], got[False]
+    for k in ("rgb", "thermal", "accumulation", "depth", "expected_depth"):
+        assert (o1[k] - o0[k]).abs().max().item() <= 1e-5, k
+    for k in l0:
+        assert abs(l1[k].item() - l0[k].item()) <= 1e-5 * abs(l0[k].item()) + 1e-9, k
+    assert set(g1) == set(g0)
+    for n, g in g0.items():
+        if g.norm().item() < 1e-10:
+            assert g1[n].norm().item() < 1e-9, n
+            continue
+        assert rel(g1[n], g) <= 2e-4, f"{n}: rel {rel(g1[n], g):.2e} (|g| {g.norm().item():.2e})"
+
+
+def test_trunc_exp_backward_clamp():
+    """NS activations.trunc_exp backward = g * exp(clamp(x, -15, 15)) (two-sided, from torch-ngp; SURVEY A.3 [UNSURE]) against
+    the upper-clamp-only form, with a raw-density bias that puts the samples below -15, where the two differ: the raw-density
+    row of mlp_base.1 (which only the density gradient reaches) of the product — tape-free and taped — against torch autograd
+    over the oracle in the same setting."""
+    rows = {}
+    for clamp_min in (-15.0, float("-inf")):
+        for tape_free in (True, False):
+            gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48, trunc_exp_clamp_min=clamp_min, tape_free_training=tape_free)
+            assert ocfg.trunc_exp_clamp_min == clamp_min
+            sd = {k: v.clone() for k, v in sd.items()}
+            with torch.no_grad():
+                gm.field.mlp_base.mlp.layers[1].bias[0] -= 30.0
+                sd["field.mlp_base.mlp.layers.1.bias"][0] -= 30.0
+            _gpu_step(gm, o, d, jit, cam, batch)
+            _, _, want = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit)
+            named = dict(gm.named_parameters())
+            gw, gb = named["field.mlp_base.mlp.layers.1.weight"].grad[0], named["field.mlp_base.mlp.layers.1.bias"].grad[0]
+            ww, wb = want["field.mlp_base.mlp.layers.1.weight"][0], want["field.mlp_base.mlp.layers.1.bias"][0]
+            assert ww.norm().item() > 0
+            assert rel(gw, ww) <= 2e-3 and rel(gb, wb) <= 2e-3, (clamp_min, tape_free, rel(gw, ww), rel(gb, wb))
+            assert rel(named["field.mlp_base.encoder.hash_table"].grad, want["field.mlp_base.encoder.hash_table"]) <= 2e-3
+            rows[(clamp_min, tape_free)] = gw.detach().cpu()
+    assert rel(rows[(-15.0, True)], rows[(float("-inf"), True)]) > 0.1, "the bias did not move the samples below the clamp"
 
 
 def test_proposal_networks_frozen_between_updates():

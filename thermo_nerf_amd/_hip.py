@@ -54,6 +54,11 @@ class tn_chain_layer(C.Structure):
                 ("d_bias", C.c_void_p)]
 
 
+class tn_field_grads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("base0_w", "base0_b", "base1_w", "base1_b", "head0_w", "head1_w", "head1_b", "head2_w",
+                                         "head2_b", "th0_w", "th0_b", "th1_w", "th1_b", "thead_w", "thead_b")]
+
+
 class tn_space(C.Structure):
     _fields_ = [
         ("contraction", C.c_int32),
@@ -191,12 +196,16 @@ SIGNATURES = {
     "tn_linear_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, C.POINTER(tn_linear), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
                                 _sz, _vp]),
     "tn_density_act_fwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _i64, _vp, _vp]),
-    "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "tn_density_act_bwd": (C.c_int, [_vp, _i32, _vp, C.c_float, C.c_float, _vp, _i64, _vp, _i32, _i32, _vp]),
     "tn_weights_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tn_gradient_scale_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tn_linear_chain_bwd_workspace_bytes": (_sz, []),
     "tn_linear_chain_bwd": (C.c_int, [C.POINTER(tn_chain_layer), _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
     "tn_field_fwd_taped": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32] + [_vp] * 12),
+    "tn_field_fwd_train": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _i32] + [_vp] * 6),
+    "tn_field_bwd_fused_workspace_bytes": (_sz, []),
+    "tn_field_bwd_fused": (C.c_int, [C.POINTER(tn_thermal_field), _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_float,
+                                     _vp, _vp, C.POINTER(tn_field_grads), _vp, _sz, _vp]),
     "tn_composite_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "tn_color_input_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     "tn_color_input_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -689,6 +689,7 @@ struct TapedArgs {
     long long N;
     int n;                    // samples per ray
     float *enc, *sel, *h1, *bo, *density, *c1, *c2, *rgb, *t1, *t2, *thermal;
+    const float *ray_bias;    // [R,64]  (TAPE == false) mlp_head.0's bias + SH + appearance part of each ray
 };
 
 template <int ACT>  // 1 relu, 2 sigmoid (exact flavour: the tape is what the backward differentiates)
@@ -715,6 +716,9 @@ __device__ __forceinline__ void tape_store(float *dst, long long row0, long long
     }
 }
 
+// TAPE == false (tn_field_fwd_train): nothing but enc / selector / density / rgb / thermal leaves the kernel, and the per-ray
+// constant part of the colour layer (SH(direction), appearance embedding: 24 of its 32 k-steps) arrives as a per-ray bias.
+template <bool TAPE>
 __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -768,14 +772,16 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
                 MFMA32(h1[mt][1], aw, bt1[s]);
             }
         }
-        tape_store<1>(a.h1, row0, a.N, lane, h, h1);
+        if (TAPE) tape_store<1>(a.h1, row0, a.N, lane, h, h1);
         // ---- mlp_base layer 1: [N,16] = raw density | geo ------------------------------------------------------------
         f32x4 G[4];
         base2_tiles(A, lds + OFF_B_BASE2, lane, h1, G);
+        if (TAPE) {
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            const long long row = row0 + 16 * T + (lane & 15);
-            if (row < a.N) *reinterpret_cast<float4 *>(a.bo + row * 16 + 4 * (lane >> 4)) = float4{G[T][0], G[T][1], G[T][2], G[T][3]};
+            for (int T = 0; T < 4; ++T) {
+                const long long row = row0 + 16 * T + (lane & 15);
+                if (row < a.N) *reinterpret_cast<float4 *>(a.bo + row * 16 + 4 * (lane >> 4)) = float4{G[T][0], G[T][1], G[T][2], G[T][3]};
+            }
         }
         float g[2][8];
         geo_relayout(G, g);
@@ -785,48 +791,69 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         // ---- colour branch: [geo | SH(dir) | appearance[cam]] -> 64 -> 64 -> 3 ----------------------------------------
         {
             f32x16 x1[2][2], x2[2][2];
-            layer_geo(A, A_C1, lds + OFF_B_C1_RAW, lane, h, g, x1);
-            {   // SH of this lane's ray direction: 8 k-steps
-                float sx = a.dirs[ray * 3], sy = a.dirs[ray * 3 + 1], sz = a.dirs[ray * 3 + 2];
-                if (a.sh_shifted) {
-                    sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
+            if (TAPE) {
+                layer_geo(A, A_C1, lds + OFF_B_C1_RAW, lane, h, g, x1);
+                {   // SH of this lane's ray direction: 8 k-steps
+                    float sx = a.dirs[ray * 3], sy = a.dirs[ray * 3 + 1], sz = a.dirs[ray * 3 + 2];
+                    if (a.sh_shifted) {
+                        sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
+                    }
+                    float c[16];
+                    sh16(sx, sy, sz, c);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        float b0, b1;
+                        swap32(c[2 * s], c[2 * s + 1], b0, b1);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const float aw = A[(A_SH + mt * 8 + s) * 64 + lane];
+                            MFMA32(x1[mt][0], aw, b0);
+                            MFMA32(x1[mt][1], aw, b1);
+                        }
+                    }
                 }
-                float c[16];
-                sh16(sx, sy, sz, c);
+                {   // appearance embedding of this lane's camera: 16 k-steps; A read from the natural [k][f] layout of W_app
+                    const float4 *emb = reinterpret_cast<const float4 *>(a.appearance + (long long)a.cam[ray] * APP);
+#pragma unroll
+                    for (int s4 = 0; s4 < APP / 4; ++s4) {
+                        const float4 e = emb[s4];
+                        float b0, b1, b2, b3;
+                        swap32(e.x, e.y, b0, b1);
+                        swap32(e.z, e.w, b2, b3);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const float a0 = lds[OFF_W_APP + (4 * s4 + h) * 64 + 32 * mt + (lane & 31)];
+                            const float a1 = lds[OFF_W_APP + (4 * s4 + 2 + h) * 64 + 32 * mt + (lane & 31)];
+                            MFMA32(x1[mt][0], a0, b0);
+                            MFMA32(x1[mt][1], a0, b1);
+                            MFMA32(x1[mt][0], a1, b2);
+                            MFMA32(x1[mt][1], a1, b3);
+                        }
+                    }
+                }
+            } else {
+                // accumulators start from the ray's bias (both N tiles of this lane belong to samples row0 + (l & 31) and + 32)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    long long smp = row0 + 32 * nt + (lane & 31);
+                    if (smp >= a.N) smp = a.N - 1;
+                    const float *rb = a.ray_bias + (smp / a.n) * 64;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) x1[mt][nt] = bias_frag(rb, mt, h);
+                }
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    float b0, b1;
-                    swap32(c[2 * s], c[2 * s + 1], b0, b1);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        const float aw = A[(A_SH + mt * 8 + s) * 64 + lane];
-                        MFMA32(x1[mt][0], aw, b0);
-                        MFMA32(x1[mt][1], aw, b1);
+                        const float aw = A[(A_C1 + mt * 8 + s) * 64 + lane];
+                        MFMA32(x1[mt][0], aw, g[0][s]);
+                        MFMA32(x1[mt][1], aw, g[1][s]);
                     }
                 }
             }
-            {   // appearance embedding of this lane's camera: 16 k-steps; A read from the natural [k][f] layout of W_app
-                const float4 *emb = reinterpret_cast<const float4 *>(a.appearance + (long long)a.cam[ray] * APP);
-#pragma unroll
-                for (int s4 = 0; s4 < APP / 4; ++s4) {
-                    const float4 e = emb[s4];
-                    float b0, b1, b2, b3;
-                    swap32(e.x, e.y, b0, b1);
-                    swap32(e.z, e.w, b2, b3);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const float a0 = lds[OFF_W_APP + (4 * s4 + h) * 64 + 32 * mt + (lane & 31)];
-                        const float a1 = lds[OFF_W_APP + (4 * s4 + 2 + h) * 64 + 32 * mt + (lane & 31)];
-                        MFMA32(x1[mt][0], a0, b0);
-                        MFMA32(x1[mt][1], a0, b1);
-                        MFMA32(x1[mt][0], a1, b2);
-                        MFMA32(x1[mt][1], a1, b3);
-                    }
-                }
-            }
-            tape_store<1>(a.c1, row0, a.N, lane, h, x1);
+            if (TAPE) tape_store<1>(a.c1, row0, a.N, lane, h, x1);
             layer64(A, A_C2, lds + OFF_B_C2, lane, h, x1, x2);
-            tape_store<1>(a.c2, row0, a.N, lane, h, x2);
+            if (TAPE) tape_store<1>(a.c2, row0, a.N, lane, h, x2);
             const float *w3 = lds + OFF_W3;
             const float cr = sigmoidf(combine_halves(out_dot<0>(w3, h, x2)) + w3[192]);
             const float cg = sigmoidf(combine_halves(out_dot<0>(w3 + 64, h, x2)) + w3[193]);
@@ -841,9 +868,20 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         {
             f32x16 x1[2][2], x2[2][2];
             layer_geo(A, A_T1, lds + OFF_B_T1, lane, h, g, x1);
-            tape_store<1>(a.t1, row0, a.N, lane, h, x1);
+            if (TAPE) tape_store<1>(a.t1, row0, a.N, lane, h, x1);
             layer64(A, A_T2, lds + OFF_B_T2, lane, h, x1, x2);
-            tape_store<2>(a.t2, row0, a.N, lane, h, x2);
+            if (TAPE) {
+                tape_store<2>(a.t2, row0, a.N, lane, h, x2);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) x2[mt][nt][r] = sigmoidf(x2[mt][nt][r]);
+                    }
+                }
+            }
             // x2 now holds sigmoid(t2): the head is a plain dot product on it
             const float *wt = lds + OFF_WTH;
             float p0 = 0.0f, p1 = 0.0f;
@@ -943,13 +981,41 @@ int tn_field_fwd_taped(const tn_thermal_field *f, const float *positions, const 
     a.positions = positions; a.dirs = directions; a.cam = camera_indices;
     a.N = (long long)num_rays * n; a.n = n;
     a.enc = enc; a.sel = selector; a.h1 = h1; a.bo = bo; a.density = density; a.c1 = c1; a.c2 = c2; a.rgb = rgb;
-    a.t1 = t1; a.t2 = t2; a.thermal = thermal;
+    a.t1 = t1; a.t2 = t2; a.thermal = thermal; a.ray_bias = nullptr;
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
-    if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel>(smem)) return TN_ERR_LAUNCH;
+    if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel<true>>(smem)) return TN_ERR_LAUNCH;
     const long long passes = (a.N + 63) / 64;
     const long long need = (passes + kWaves - 1) / kWaves;
     const unsigned grid = (unsigned)(need < 512 ? (need < 1 ? 1 : need) : 512);
-    hipLaunchKernelGGL(field_fwd_taped_kernel, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(field_fwd_taped_kernel<true>, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
+int tn_field_fwd_train(const tn_thermal_field *f, const float *positions, const float *ray_bias, int64_t num_rays, int32_t n,
+                       float *enc, float *selector, float *density, float *rgb, float *thermal, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!f || !positions || !ray_bias || !enc || !selector || !density || !rgb || !thermal) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    TN_TRY(tn_check_thermal_field(f));
+    if (!mfma_supported(f) || !f->prepared) return TN_ERR_UNSUPPORTED;
+    TapedArgs a;
+    a.g = tn_make_grid(f->grid);
+    a.space = f->space;
+    a.blob = f->prepared;
+    a.appearance = f->appearance;
+    a.avg = f->average_init_density;
+    a.sh_shifted = f->sh_shifted;
+    a.positions = positions; a.dirs = nullptr; a.cam = nullptr;
+    a.N = (long long)num_rays * n; a.n = n;
+    a.enc = enc; a.sel = selector; a.h1 = nullptr; a.bo = nullptr; a.density = density; a.c1 = nullptr; a.c2 = nullptr; a.rgb = rgb;
+    a.t1 = nullptr; a.t2 = nullptr; a.thermal = thermal; a.ray_bias = ray_bias;
+    const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
+    if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel<false>>(smem)) return TN_ERR_LAUNCH;
+    const long long passes = (a.N + 63) / 64;
+    const long long need = (passes + kWaves - 1) / kWaves;
+    const unsigned grid = (unsigned)(need < 512 ? (need < 1 ? 1 : need) : 512);
+    hipLaunchKernelGGL(field_fwd_taped_kernel<false>, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
     return TN_OK;
 }

@@ -1136,10 +1136,10 @@ density_act_fwd_kernel(const float *__restrict__ raw, int ld, const float *__res
         density[i] = mul_rn(mul_rn(avg, expf(raw[i * ld])), sel[i]);
 }
 __global__ void __launch_bounds__(kBlock)
-density_act_bwd_kernel(const float *__restrict__ raw, int ld, const float *__restrict__ sel, float avg,
+density_act_bwd_kernel(const float *__restrict__ raw, int ld, const float *__restrict__ sel, float avg, float clamp_min,
                        const float *__restrict__ dd, long long n, float *__restrict__ d_raw, int ldd, int clear_cols) {
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-        const float g = dd[i] * sel[i] * avg * expf(fminf(raw[i * ld], 15.0f));
+        const float g = dd[i] * sel[i] * avg * expf(fminf(fmaxf(raw[i * ld], clamp_min), 15.0f));
         float *row = d_raw + i * ldd;
         if (clear_cols > 1 && (ldd & 3) == 0 && (clear_cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_raw) & 15) == 0) {
             // the row's other columns are the += targets of later stages: whole 16-byte pieces (a 16-float row = one line)
@@ -1920,12 +1920,13 @@ int tn_density_act_fwd(const float *raw, int32_t ld_raw, const float *selector, 
 }
 
 int tn_density_act_bwd(const float *raw, int32_t ld_raw, const float *selector, float average_init_density,
-                       const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw, int32_t clear_cols, void *stream) {
+                       float trunc_exp_min, const float *d_density, int64_t n, float *d_raw, int32_t ld_d_raw,
+                       int32_t clear_cols, void *stream) {
     if (n == 0) return TN_OK;
     if (!raw || !selector || !d_density || !d_raw) return TN_ERR_NULL;
     if (n < 0 || ld_raw < 1 || ld_d_raw < 1 || clear_cols < 0 || clear_cols > ld_d_raw) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(density_act_bwd_kernel, dim3(grid_for(n, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream, raw,
-                       ld_raw, selector, average_init_density, d_density, (long long)n, d_raw, ld_d_raw, clear_cols);
+                       ld_raw, selector, average_init_density, trunc_exp_min, d_density, (long long)n, d_raw, ld_d_raw, clear_cols);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

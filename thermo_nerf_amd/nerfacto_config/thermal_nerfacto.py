@@ -92,12 +92,20 @@ class NerfactoModelConfig:
     """Training: the final level's field forward (encode + mlp_base + heads, with its tape) as ONE MFMA kernel
     (tn_field_fwd_taped); False: the stage-by-stage entry points (one launch per nerfstudio module)."""
     fused_train_backward: bool = True
-    # hash-table gradient of the field: the fine levels (scaling >= 256) as bucketed records + LDS sums instead of global
-    # atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,
-    # 2.24 against 2.27 at S=48 (DESIGN §5.6)
-    bucketed_table_scatter: bool = True
     """Training: the backward of each MLP (mlp_head, mlp_thermal + head, mlp_base, the proposal MLPs) as ONE launch per MLP
     (tn_linear_chain_bwd: one tile read per layer); False: one tn_linear_bwd launch per layer."""
+    tape_free_training: bool = True
+    """Training: the final level's field without an activation tape.  The forward (tn_field_fwd_train) keeps 38 floats per
+    sample (hash features, selector, density, rgb, thermal) instead of ~380; the backward (tn_field_bwd_fused) recomputes the
+    five hidden layers from the hash features in registers and runs every adjoint next to them (DESIGN §5.6).  False: the
+    taped forward + chained / per-layer backward above, kept as the cross-check (same gradients, tests/test_gpu_training.py)."""
+    trunc_exp_clamp_min: float = -15.0
+    """Lower clamp of trunc_exp's backward, g * exp(clamp(x, min, 15)): -15 = nerfstudio's activations.trunc_exp (taken from
+    torch-ngp, two-sided); float("-inf") = upper clamp only (SURVEY A.3 [UNSURE])."""
+    bucketed_table_scatter: bool = True
+    """Training: hash-table gradient of the field's fine levels (scaling >= 256) as bucketed records + LDS sums instead of
+    global atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,
+    2.24 against 2.27 at S=48 (DESIGN §5.6)."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""

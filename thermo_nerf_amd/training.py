@@ -15,6 +15,7 @@ SH basis when a camera optimizer makes them depend on ``pose_adjustment``.  Not 
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -102,6 +103,24 @@ def linear_bwd(x: Tensor, x_off: int, ldx: int, y: Optional[Tensor], dy: Tensor,
 
 
 _CHAIN_WS: Dict = {}
+_FUSED_WS: Dict = {}
+_ZEROS: Dict = {}
+
+
+def _fused_bwd_workspace(dev) -> Tensor:
+    """per-device slab buffer of tn_field_bwd_fused (one slab of parameter gradients per persistent block)"""
+    ws = _FUSED_WS.get(dev)
+    if ws is None:
+        ws = _FUSED_WS[dev] = torch.empty(_hip.load().tn_field_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _zeros_like_cached(dev, n: int) -> Tensor:
+    """a read-only run of n zero floats on ``dev`` (the geo rows of the ray-level mlp_head input)"""
+    z = _ZEROS.get(dev)
+    if z is None or z.numel() < n:
+        z = _ZEROS[dev] = torch.zeros((max(n, 1 << 16),), dtype=torch.float32, device=dev)
+    return z
 
 
 def linear_chain_bwd(layers, y_top: Optional[Tensor], act_top: int, dy: Tensor, lddy: int, n: int, dx: Optional[Tensor],
@@ -215,12 +234,13 @@ def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, 
 
 
 def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict,
-                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True, bucketed: bool = False) -> None:
+                        ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True, bucketed: bool = False,
+                        exp_min: float = -15.0) -> None:
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
     g_raw = _f32((n, 1), g_w.device)
-    _hip.check(lib.tn_density_act_bwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density,
+    _hip.check(lib.tn_density_act_bwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density, exp_min,
                                       g_density.data_ptr(), n, g_raw.data_ptr(), 1, 0, _stream()), "tn_density_act_bwd")
     names = [f"{prefix}.mlp_base.encoder.hash_table", f"{prefix}.mlp_base.mlp.layers.0.weight",
              f"{prefix}.mlp_base.mlp.layers.0.bias", f"{prefix}.mlp_base.mlp.layers.1.weight",
@@ -326,11 +346,27 @@ class RenderTrain(torch.autograd.Function):
         f.pos, f.deltas = _frustum_positions(o, d, f)
         N = R * S
         fused = None
-        if cfg.fused_train_forward:
+        tape_free = bool(getattr(cfg, "tape_free_training", True))
+        if cfg.fused_train_forward or tape_free:
             fused = model.field.c_struct(prepare=True, dense=False)  # MFMA fragments of the CURRENT weights (rebuilt per step)
             if not fused.prepared:
                 fused = None  # geometry the MFMA chain does not cover: stage-by-stage entry points below
-        if fused is not None:
+        tape_free = tape_free and fused is not None
+        h1 = bo = cin = c1 = c2 = t1 = t2 = None
+        if tape_free:
+            # no activation tape: the per-ray constant inputs of mlp_head.0 (SH(direction), appearance embedding) become a
+            # per-ray bias [R,64]; the forward keeps enc / selector / density / rgb / thermal, tn_field_bwd_fused recomputes the rest
+            cin = _f32((R, 64), dev)   # ray rows of mlp_head's input: [SH | 0 (geo) | appearance | 0]
+            _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), _zeros_like_cached(dev, R * 16).data_ptr(), 16, cam.data_ptr(), 1, R, 1,
+                                              cin.data_ptr(), _stream()), "tn_color_input_fwd")
+            ray_bias = linear_fwd(cin, 0, 64, fld.head0, ACT_NONE, R)
+            f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
+            rgb_s, th_s = _f32((N, 3), dev), _f32((N, 1), dev)
+            _hip.check(lib.tn_field_fwd_train(fused, f.pos.data_ptr(), ray_bias.data_ptr(), R, S, f.enc.data_ptr(), f.sel.data_ptr(),
+                                              f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _stream()),
+                       "tn_field_fwd_train")
+            bo = ray_bias  # (slot reuse in ctx.acts: the tape-free backward reads (cin, ray_bias, rgb_s))
+        elif fused is not None and cfg.fused_train_forward:
             # the whole field forward of the level in one launch; every tensor of the tape in the layout the adjoints read
             f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
             h1, bo = _f32((N, 64), dev), _f32((N, 16), dev)
@@ -386,6 +422,7 @@ class RenderTrain(torch.autograd.Function):
         ctx.acts = (h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s)
         ctx.acc, ctx.o, ctx.d, ctx.cam = acc, o, d, cam
         ctx.updated = bool(updated)
+        ctx.tape_free = tape_free
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.params = {n: p for n, p in zip(ctx.param_names, params)}
         # ctx must not hold a tensor OBJECT that is also returned as a differentiable output (output -> grad_fn -> ctx ->
@@ -444,12 +481,52 @@ class RenderTrain(torch.autograd.Function):
             starts, ends = _starts_ends(f)
             _hip.check(lib.tn_gradient_scale_bwd(starts.data_ptr(), ends.data_ptr(), N, g_density.data_ptr(), _hip.ptr(g_rgb_s),
                                                  _hip.ptr(g_th_s), _stream()), "tn_gradient_scale_bwd")
-        ldb = bo.shape[1]
-        g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass
-        _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density,
-                                          g_density.data_ptr(), N, g_bo.data_ptr(), ldb, ldb, _stream()), "tn_density_act_bwd")
+        exp_min = float(getattr(cfg, "trunc_exp_clamp_min", -15.0))
         W = 64
         chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
+        bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
+        E = f.enc.shape[1]
+        g_enc = _f32((N, E), dev)
+        if ctx.tape_free:
+            self_bias = bo  # ray_bias [R,64]
+            gr = _hip.tn_field_grads()
+            names = {"base0": "field.mlp_base.mlp.layers.0", "base1": "field.mlp_base.mlp.layers.1",
+                     "head0": "field.mlp_head.layers.0", "head1": "field.mlp_head.layers.1", "head2": "field.mlp_head.layers.2",
+                     "th0": "field.mlp_thermal.layers.0", "th1": "field.mlp_thermal.layers.1", "thead": "field.field_head_thermal.net"}
+            for key, name in names.items():
+                if key.startswith("head") and g_rgb_s is None:
+                    continue
+                if key.startswith("th") and g_th_s is None:
+                    continue
+                setattr(gr, key + "_w", zeros(name + ".weight").data_ptr())
+                if key != "head0":
+                    setattr(gr, key + "_b", zeros(name + ".bias").data_ptr())
+            g_ray = torch.zeros((R, 64), dtype=torch.float32, device=dev) if g_rgb_s is not None else None
+            ws = _fused_bwd_workspace(dev)
+            _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), self_bias.data_ptr(), rgb_s.data_ptr(),
+                                              _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
+                                              1 if model.field.pass_thermal_gradients else 0, exp_min, g_enc.data_ptr(),
+                                              _hip.ptr(g_ray), C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
+                       "tn_field_bwd_fused")
+            if g_ray is not None:
+                # the ray-level Linear backward of mlp_head.0: bias, SH and appearance weight columns (the geo columns of the ray
+                # rows are zero), and d(ray row) -> embedding / direction gradients
+                g_cin = _f32((R, 64), dev)
+                linear_bwd(cin, 0, 64, None, g_ray, 64, fld.head0, ACT_NONE, R, g_cin, 0, 64, False,
+                           grads["field.mlp_head.layers.0.weight"], zeros("field.mlp_head.layers.0.bias"))
+                _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, 1, None, 0,
+                                                  zeros("field.embedding_appearance.embedding.weight").data_ptr(),
+                                                  ctx.d.data_ptr() if sh_grads else None,
+                                                  ray_grads[1].data_ptr() if sh_grads else None, _stream()),
+                           "tn_color_input_bwd")
+            hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
+            if ray_grads:
+                _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
+            return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
+        ldb = bo.shape[1]
+        g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass
+        _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density, exp_min,
+                                          g_density.data_ptr(), N, g_bo.data_ptr(), ldb, ldb, _stream()), "tn_density_act_bwd")
         if g_th_s is not None:  # thermal branch [REF thermal_field.py:170-179]
             into_geo = g_bo if model.field.pass_thermal_gradients else None  # REF :171-172 (.detach())
             th = [(fld.thead, t2, 0, W, ACT_SIGMOID, zeros("field.field_head_thermal.net.weight"),
@@ -480,8 +557,6 @@ class RenderTrain(torch.autograd.Function):
                                               ctx.d.data_ptr() if sh_grads else None,
                                               ray_grads[1].data_ptr() if sh_grads else None, _stream()),
                        "tn_color_input_bwd")
-        E = f.enc.shape[1]
-        g_enc = _f32((N, E), dev)
         bs = [(fld.base1, h1, 0, W, ACT_RELU, zeros("field.mlp_base.mlp.layers.1.weight"), zeros("field.mlp_base.mlp.layers.1.bias")),
               (fld.base0, f.enc, 0, E, ACT_NONE, zeros("field.mlp_base.mlp.layers.0.weight"), zeros("field.mlp_base.mlp.layers.0.bias"))]
         if chained:
@@ -490,21 +565,23 @@ class RenderTrain(torch.autograd.Function):
             g_h1 = _f32((N, W), dev)
             linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
             linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
-        bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
         hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
+        return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
 
-        # ---- proposal levels (only through their weights) --------------------------------------------------
+    @staticmethod
+    def _finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop):
+        """proposal levels (only through their weights), then the gradient tuple in parameter order"""
         if ctx.updated:
-            for lvl, g in enumerate((g_w0, g_w1)):
+            for lvl, g in enumerate(g_prop):
                 if g is None:
                     continue
                 t = ctx.tapes[lvl]
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
                 net = model.proposal_networks[which].c_struct(dense=False)
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
-                                    ray_grads, chained, bucketed)
+                                    ray_grads, chained, bucketed, exp_min)
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
         result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)
