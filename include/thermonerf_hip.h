@@ -399,7 +399,10 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * gradients of every other Linear of the field (+=; NULL entries skipped; head0_w receives its geo columns 16..30 only).
  * trunc_exp_min: lower clamp of trunc_exp's backward (g * exp(clamp(x, min, 15)); -15 = torch-ngp / nerfstudio's
  * two-sided clamp, -INFINITY = upper clamp only).  pass_thermal_gradients = 0 keeps the thermal branch from the geo
- * features [REF thermal_field.py:171-172].  The reference geometry only (16 levels, geo 15, appearance 32). */
+ * features [REF thermal_field.py:171-172].  split = 0: one launch for the whole field (one wave per SIMD: its ~210 gradient
+ * accumulators); 1: the colour head and (thermal head + mlp_base) as two launches of two waves per SIMD each, the colour
+ * head's adjoint of mlp_base's outputs passing through the workspace.  The reference geometry only (16 levels, geo 15,
+ * appearance 32). */
 typedef struct tn_field_grads {
     float *base0_w, *base0_b, *base1_w, *base1_b;
     float *head0_w, *head1_w, *head1_b, *head2_w, *head2_b;
@@ -407,11 +410,12 @@ typedef struct tn_field_grads {
 } tn_field_grads;
 int tn_field_fwd_train(const tn_thermal_field *field, const float *positions, const float *ray_bias, int64_t num_rays,
                        int32_t n, float *enc, float *selector, float *density, float *rgb, float *thermal, void *stream);
-size_t tn_field_bwd_fused_workspace_bytes(void);
+size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n);
 int tn_field_bwd_fused(const tn_thermal_field *field, int64_t num_rays, int32_t n, const float *enc, const float *selector,
                        const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
-                       const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, float *d_enc,
-                       float *d_ray_sum, const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+                       const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split,
+                       float *d_enc, float *d_ray_sum, const tn_field_grads *grads, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* NS scale_gradients_by_distance_squared [REF thermal_nerf_model.py:228-231, use_gradient_scaling]: the forward is the
  * identity; in the backward the gradient of EVERY field output of a sample (density [n], rgb [n,3], thermal [n]; any may

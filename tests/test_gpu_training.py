@@ -415,16 +415,17 @@ def test_fused_field_forward_writes_the_stage_chain_tape(hw):
     assert rel(dens, dens_s) <= 1e-5
 
 
-@pytest.mark.parametrize("hw", [(12, 12), (7, 5), (1, 1), (1, 3)])  # (7,5) x 48 = 1680 samples: a ragged last 32-sample tile
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("hw", [(12, 12), (7, 5), (1, 1), (1, 3)])  # (7,5) x 5 = 175 samples: a ragged last 16-sample tile
 @pytest.mark.parametrize("S", [48, 192, 5])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
-def test_tape_free_step_equals_the_taped_step(kind, S, hw):
+def test_tape_free_step_equals_the_taped_step(kind, S, hw, split):
     """tn_field_fwd_train + tn_field_bwd_fused (nothing but 38 floats per sample kept, the hidden layers recomputed in the
-    backward) against the taped forward + chained backward on the same batch: same outputs, losses and parameter gradients up
+    backward; split: three launches colour head | thermal head | mlp_base, or the whole field in one) against the taped forward + chained backward on the same batch: same outputs, losses and parameter gradients up
     to fp32 summation order (the oracle comparison of both is test_training_step_matches_autograd_oracle)."""
     got = {}
     for tape_free in (True, False):
-        gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, R_hw=hw, tape_free_training=tape_free)
+        gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, R_hw=hw, tape_free_training=tape_free, fused_backward_split=split)
         out, loss = _gpu_step(gm, o, d, jit, cam, batch)
         got[tape_free] = (out, loss, {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None})
     (o1, l1, g1), (o0, l0, g0) = got[True], got[False]

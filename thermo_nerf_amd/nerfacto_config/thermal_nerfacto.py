@@ -99,6 +99,9 @@ class NerfactoModelConfig:
     sample (hash features, selector, density, rgb, thermal) instead of ~380; the backward (tn_field_bwd_fused) recomputes the
     five hidden layers from the hash features in registers and runs every adjoint next to them (DESIGN §5.6).  False: the
     taped forward + chained / per-layer backward above, kept as the cross-check (same gradients, tests/test_gpu_training.py)."""
+    fused_backward_split: bool = True
+    """tn_field_bwd_fused as three launches (colour head | thermal head | mlp_base) of two waves per SIMD each instead of one
+    launch of one wave per SIMD holding all ~210 gradient accumulators (DESIGN §5.6)."""
     trunc_exp_clamp_min: float = -15.0
     """Lower clamp of trunc_exp's backward, g * exp(clamp(x, min, 15)): -15 = nerfstudio's activations.trunc_exp (taken from
     torch-ngp, two-sided); float("-inf") = upper clamp only (SURVEY A.3 [UNSURE])."""

@@ -107,11 +107,13 @@ _FUSED_WS: Dict = {}
 _ZEROS: Dict = {}
 
 
-def _fused_bwd_workspace(dev) -> Tensor:
-    """per-device slab buffer of tn_field_bwd_fused (one slab of parameter gradients per persistent block)"""
+def _fused_bwd_workspace(dev, R: int, S: int) -> Tensor:
+    """per-device workspace of tn_field_bwd_fused (a slab of parameter gradients per persistent block and launch + the heads'
+    adjoints of mlp_base's outputs), grown to the largest batch seen"""
+    need = _hip.load().tn_field_bwd_fused_workspace_bytes(R, S)
     ws = _FUSED_WS.get(dev)
-    if ws is None:
-        ws = _FUSED_WS[dev] = torch.empty(_hip.load().tn_field_bwd_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+    if ws is None or ws.numel() < need:
+        ws = _FUSED_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -502,10 +504,11 @@ class RenderTrain(torch.autograd.Function):
                 if key != "head0":
                     setattr(gr, key + "_b", zeros(name + ".bias").data_ptr())
             g_ray = torch.zeros((R, 64), dtype=torch.float32, device=dev) if g_rgb_s is not None else None
-            ws = _fused_bwd_workspace(dev)
+            ws = _fused_bwd_workspace(dev, R, S)
             _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), self_bias.data_ptr(), rgb_s.data_ptr(),
                                               _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
-                                              1 if model.field.pass_thermal_gradients else 0, exp_min, g_enc.data_ptr(),
+                                              1 if model.field.pass_thermal_gradients else 0, exp_min,
+                                              1 if getattr(cfg, "fused_backward_split", True) else 0, g_enc.data_ptr(),
                                               _hip.ptr(g_ray), C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
                        "tn_field_bwd_fused")
             if g_ray is not None:
