@@ -386,7 +386,9 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
 
 /* The tape-free pair of the final level's training pass [REF thermal_field.py:108-201 differentiated; the modules
  * constructed at thermal_field.py:62-102].  tn_field_fwd_train is tn_field_fwd_taped keeping only what compositing, the
- * losses and the backward read: enc [N,32], selector [N], density [N], rgb [N,3], thermal [N].  `ray_bias` [R,64] = mlp_head.0's
+ * losses and the backward read: selector [N], density [N], rgb [N,3], thermal [N] and the hash features `enc`, the latter
+ * in tiles of 64 consecutive samples, [ceil(N/64)][16 levels][64 samples][2] floats (the layout tn_field_bwd_fused reads;
+ * allocate 32 * 64 * ceil(N/64) floats).  `ray_bias` [R,64] = mlp_head.0's
  * bias plus its SH(direction) and appearance-embedding columns applied to each ray's constants (tn_color_input_fwd with n = 1
  * and zero geo rows, then tn_linear_fwd with mlp_head.0): the colour layer sees them as a per-ray bias.
  *

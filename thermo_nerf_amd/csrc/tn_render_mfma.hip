@@ -742,7 +742,15 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         const float sel = normalize_position(sp, a.positions[ic * 3], a.positions[ic * 3 + 1], a.positions[ic * 3 + 2], px, py, pz);
         // ---- hash encoding (lane = sample): features to the tape and, through 16 permlane swaps, to the B operands ----
         float bt0[16], bt1[16];
-        if (a.g.num_dense == 0) {
+        if (!TAPE) {
+            // the hash features in pass tiles [pass][level][64 samples][2]: every store instruction writes 512 contiguous bytes
+            // (row-major [N,32] rows put 8 bytes of each of 64 lines on a store); tn_field_bwd_fused reads the same tiling
+            float2 *et = reinterpret_cast<float2 *>(a.enc) + ps * (16 * 64) + lane;
+            hash_encode_pipelined<L16, LG>(a.g, px, py, pz, [&](int l, float2 f) {
+                et[l * 64] = f;
+                swap32(f.x, f.y, bt0[l], bt1[l]);
+            });
+        } else if (a.g.num_dense == 0) {
             hash_encode_pipelined<L16, 2>(a.g, px, py, pz, [&](int l, float2 f) {
                 if (live) *reinterpret_cast<float2 *>(a.enc + ic * 32 + 2 * l) = f;
                 swap32(f.x, f.y, bt0[l], bt1[l]);
@@ -787,7 +795,7 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         geo_relayout(G, g);
         float raw, unused;
         swap32(g[0][0], g[1][0], raw, unused);
-        if (live) a.density[ic] = mul_rn(mul_rn(a.avg, expf(raw)), sel);
+        if (live) a.density[ic] = mul_rn(mul_rn(a.avg, TAPE ? expf(raw) : __expf(raw)), sel);
         // ---- colour branch: [geo | SH(dir) | appearance[cam]] -> 64 -> 64 -> 3 ----------------------------------------
         {
             f32x16 x1[2][2], x2[2][2];
@@ -855,9 +863,11 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
             layer64(A, A_C2, lds + OFF_B_C2, lane, h, x1, x2);
             if (TAPE) tape_store<1>(a.c2, row0, a.N, lane, h, x2);
             const float *w3 = lds + OFF_W3;
-            const float cr = sigmoidf(combine_halves(out_dot<0>(w3, h, x2)) + w3[192]);
-            const float cg = sigmoidf(combine_halves(out_dot<0>(w3 + 64, h, x2)) + w3[193]);
-            const float cb = sigmoidf(combine_halves(out_dot<0>(w3 + 128, h, x2)) + w3[194]);
+            const float o0 = combine_halves(out_dot<0>(w3, h, x2)) + w3[192], o1 = combine_halves(out_dot<0>(w3 + 64, h, x2)) + w3[193],
+                        o2 = combine_halves(out_dot<0>(w3 + 128, h, x2)) + w3[194];
+            // (untaped: v_exp_f32 / v_rcp_f32 sigmoids, |error| < 3e-7; the backward differentiates its own recomputation)
+            const float cr = TAPE ? sigmoidf(o0) : fast_sigmoid(o0), cg = TAPE ? sigmoidf(o1) : fast_sigmoid(o1),
+                        cb = TAPE ? sigmoidf(o2) : fast_sigmoid(o2);
             if (live) {
                 a.rgb[ic * 3 + 0] = cr;
                 a.rgb[ic * 3 + 1] = cg;
@@ -878,7 +888,7 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) x2[mt][nt][r] = sigmoidf(x2[mt][nt][r]);
+                        for (int r = 0; r < 16; ++r) x2[mt][nt][r] = fast_sigmoid(x2[mt][nt][r]);
                     }
                 }
             }

@@ -188,7 +188,7 @@ struct FusedBwdArgs {
     float avg, exp_clamp_min;
     long long N;
     int S, pass_thermal;
-    const float *enc;       // [N,32]  hash features of the forward
+    const float *enc;       // hash features of the forward in its pass tiles [ceil(N/64)][16 levels][64][2]
     const float *sel;       // [N]
     const float *ray_bias;  // [R,64]  mlp_head.0 bias + its SH and appearance columns applied to the ray's constants
     const float *rgb;       // [N,3]   forward output (sigmoid)
@@ -212,8 +212,12 @@ __device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long
     const long long i = tile * TS + n;
     const bool live = i < a.N;
     const long long ic = live ? i : a.N - 1;
-    t.e[0] = ld4(a.enc + ic * 32 + 4 * sl);
-    t.e[1] = ld4(a.enc + ic * 32 + 16 + 4 * sl);
+    {   // pass tiles of tn_field_fwd_train: [pass of 64 samples][level][sample][2]; features 4 sl .. = levels 2 sl, 2 sl + 1
+        const float2 *et = reinterpret_cast<const float2 *>(a.enc) + (ic >> 6) * (16 * 64) + (ic & 63);
+        const float2 f0 = et[(2 * sl) * 64], f1 = et[(2 * sl + 1) * 64], f2 = et[(8 + 2 * sl) * 64], f3 = et[(9 + 2 * sl) * 64];
+        t.e[0] = f32x4{f0.x, f0.y, f1.x, f1.y};
+        t.e[1] = f32x4{f2.x, f2.y, f3.x, f3.y};
+    }
     t.ray = (unsigned)ic / (unsigned)a.S;
     if (MODE & 4) {
         t.sel = a.sel[ic];
@@ -376,7 +380,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             dw<4, 4, true>(D, X, n, sl, aw_c1, ab_c1);
             wave_sync();
             // ---- mlp_head.0: columns of bo's rows here, the per-ray columns through gsum ----------------------------------------
-            if (MODE == 1 && tile + stride < tiles) tile_load<MODE>(nxt, a, tile + stride, n, sl);  // in flight during this phase
             rows_store<4, false>(D, n, sl, d1);
             rows_store<1, false>(X, n, sl, G);
             mm_t_from_r<1, 4, LD_G>(lds + O_C0R, n, sl, d1, dG);
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t2[ob][q] = sigmoid_exact(t2[ob][q]);
+                for (int q = 0; q < 4; ++q) t2[ob][q] = __builtin_amdgcn_rcpf(1.0f + __expf(-t2[ob][q]));  // |error| < 3e-7
             }
             const float dth = cur.g_th;
             // ---- thermal head (1 output row): dW on the vector unit, x = sigmoid(t2) -----------------------------------------
@@ -453,7 +456,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             dw<4, 4, true>(D, X, n, sl, aw_t1, ab_t1);
             wave_sync();
             // ---- mlp_thermal.0 ---------------------------------------------------------------------------------------------
-            if (MODE == 2 && tile + stride < tiles) tile_load<MODE>(nxt, a, tile + stride, n, sl);
             rows_store<4, false>(D, n, sl, d1);
             rows_store<1, false>(X, n, sl, G);
             if (a.pass_thermal) mm_t_from_r<1, 4, LD_G>(lds + O_T0R, n, sl, d1, dG);  // REF thermal_field.py:171-172: .detach() otherwise
@@ -494,7 +496,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             wave_sync();
             dw<4, 2, true>(D, X, n, sl, aw_b0, ab_b0);
             wave_sync();
-        } else if ((MODE == 1 && !has_rgb) || (MODE == 2 && !has_th)) {
+        } else {
+            // (the head launches hold 80 accumulators + their working set in 256 registers: no room to keep the next tile's
+            // inputs in flight across a phase; the SIMD's other wave covers the latency)
             if (tile + stride < tiles) tile_load<MODE>(nxt, a, tile + stride, n, sl);
         }
         cur = nxt;
@@ -574,7 +578,8 @@ struct RedArgs {
     const float *slabs;
     int blocks;
 };
-constexpr int kRedSplit = 4;
+constexpr int kRedSplit = 8;   // slices of the block range (one atomic per entry and slice)
+constexpr int kRedUnroll = 8;  // independent slab reads in flight per thread: the kernel is bound by load latency, not bytes
 constexpr int kBlock = 256;
 
 __global__ void __launch_bounds__(kBlock) field_bwd_reduce_kernel(RedArgs a) {
@@ -586,14 +591,15 @@ __global__ void __launch_bounds__(kBlock) field_bwd_reduce_kernel(RedArgs a) {
     for (int e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
         const int r = e / sg.cols, c = e - r * sg.cols;
         const float *p = a.slabs + sg.off + r * sg.src_ld + sg.src_col0 + c;
-        float s0 = 0.0f, s1 = 0.0f;
-        int b = b0;
-        for (; b + 1 < b1; b += 2) {
-            s0 += p[(size_t)b * SLAB_FLOATS];
-            s1 += p[(size_t)(b + 1) * SLAB_FLOATS];
+        float s = 0.0f;
+        for (int b = b0; b < b1; b += kRedUnroll) {
+            float v[kRedUnroll];
+#pragma unroll
+            for (int u = 0; u < kRedUnroll; ++u) v[u] = b + u < b1 ? p[(size_t)(b + u) * SLAB_FLOATS] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < kRedUnroll; ++u) s += v[u];
         }
-        if (b < b1) s0 += p[(size_t)b * SLAB_FLOATS];
-        unsafeAtomicAdd(sg.dst + r * sg.dst_ld + sg.dst_col0 + c, s0 + s1);
+        unsafeAtomicAdd(sg.dst + r * sg.dst_ld + sg.dst_col0 + c, s);
     }
 }
 
@@ -664,7 +670,7 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
         seg(12, S_BT1, 1, 64, 64, 0, tt ? grads->th1_b : nullptr, 64, 0);
         seg(13, S_WTH, 1, 64, 64, 0, tt ? grads->thead_w : nullptr, 64, 0);
         seg(14, S_BTH, 1, 1, 4, 0, tt ? grads->thead_b : nullptr, 1, 0);
-        hipLaunchKernelGGL(field_bwd_reduce_kernel, dim3(4, kRedSegs, kRedSplit), dim3(kBlock), 0, st, r);
+        hipLaunchKernelGGL(field_bwd_reduce_kernel, dim3(16, kRedSegs, kRedSplit), dim3(kBlock), 0, st, r);
         if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
         return TN_OK;
     };

@@ -362,7 +362,7 @@ class RenderTrain(torch.autograd.Function):
             _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), _zeros_like_cached(dev, R * 16).data_ptr(), 16, cam.data_ptr(), 1, R, 1,
                                               cin.data_ptr(), _stream()), "tn_color_input_fwd")
             ray_bias = linear_fwd(cin, 0, 64, fld.head0, ACT_NONE, R)
-            f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
+            f.enc, f.sel, f.density = _f32(((N + 63) // 64 * 64, 32), dev), _f32((N,), dev), _f32((N,), dev)  # enc: 64-sample tiles
             rgb_s, th_s = _f32((N, 3), dev), _f32((N, 1), dev)
             _hip.check(lib.tn_field_fwd_train(fused, f.pos.data_ptr(), ray_bias.data_ptr(), R, S, f.enc.data_ptr(), f.sel.data_ptr(),
                                               f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _stream()),
@@ -488,7 +488,7 @@ class RenderTrain(torch.autograd.Function):
         chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
         bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
         E = f.enc.shape[1]
-        g_enc = _f32((N, E), dev)
+        g_enc = _f32((N, E), dev)  # row-major [N,32] in both forms (what the table scatter reads)
         if ctx.tape_free:
             self_bias = bo  # ray_bias [R,64]
             gr = _hip.tn_field_grads()
