@@ -547,13 +547,15 @@ def get_outputs(
         "depth": render_depth_median(weights, s.starts, s.ends),  # [REF :238-239]
         "expected_depth": render_depth_expected(weights, s.starts, s.ends),  # [REF :240-242]
     }
+    if training:  # [REF :262-265] (key order as in the reference's dict: pinned by fixture G7)
+        out["weights_list"] = weights_list
+        out["ray_samples_list"] = samples_list
     for i in range(len(cfg.num_proposal_samples_per_ray)):  # [REF :267-270]
         out[f"prop_depth_{i}"] = render_depth_median(weights_list[i], samples_list[i].starts, samples_list[i].ends)
     out["thermal"] = render_thermal(thermal_s, weights, training)  # [REF :271-273]
-    if training or return_intermediates:
-        out["weights_list"] = weights_list
-        out["ray_samples_list"] = samples_list
     if return_intermediates:
+        out.setdefault("weights_list", weights_list)
+        out.setdefault("ray_samples_list", samples_list)
         out["density"] = density
         out["geo"] = geo
         out["rgb_samples"] = rgb_s

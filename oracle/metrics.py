@@ -48,3 +48,21 @@ def ssim(preds: Tensor, target: Tensor, sigma: float = 1.5, k1: float = 0.01, k2
 def psnr(preds: Tensor, target: Tensor, data_range: float = 1.0) -> Tensor:
     """torchmetrics PeakSignalNoiseRatio(data_range=1.0) [REF thermal_nerf_model.py:200]."""
     return 10.0 * torch.log10(data_range ** 2 / torch.mean((preds - target) ** 2))
+
+
+def thermal_image_metrics(gt_thermal: Tensor, pred_thermal: Tensor, cold: bool, max_temperature: float, min_temperature: float,
+                          threshold=None) -> dict:
+    """What ThermalNerfModel.get_image_metrics_and_images adds for the thermal modality [REF thermal_nerf_model.py:354-391]:
+    [H,W,1] images moved to [1,1,H,W], PSNR / SSIM on them, the two MAE figures in degrees (threshold only on the foreground
+    one).  Key names and values pinned by the reference's own method (fixture G7, ``metrics.*``); LPIPS (a pretrained network)
+    is outside the oracle."""
+    from .hotpath import mae_thermal
+
+    gt = torch.moveaxis(gt_thermal, -1, 0)[None, ...]
+    pr = torch.moveaxis(pred_thermal, -1, 0)[None, ...]
+    return {
+        "psnr_thermal": float(psnr(gt, pr)),
+        "ssim_thermal": float(ssim(gt, pr)),
+        "mae_thermal_foreground": float(mae_thermal(gt, pr, cold, max_temperature, min_temperature, threshold)),
+        "mae_thermal": float(mae_thermal(gt, pr, cold, max_temperature, min_temperature, None)),
+    }

@@ -87,16 +87,21 @@ def get_metrics_dict(outputs: Dict, batch: Dict, training: bool) -> Dict[str, Te
 
 
 def get_loss_dict(outputs: Dict, batch: Dict, metrics_dict: Optional[Dict], training: bool,
-                  interlevel_loss_mult: float = 1.0, distortion_loss_mult: float = 0.002) -> Dict[str, Tensor]:
-    """[REF thermal_nerf_model.py:277-326] with pass_rgb_gradients = pass_thermal_gradients = True, no predicted
-    normals.  background "last_sample" leaves 3-channel ground truth untouched (NS blend_background_for_loss_computation).
-    ``thermal_loss_weight`` exists in the reference config [REF :53-54] but is never applied [REF :319-323]."""
-    loss = {"rgb_loss": torch.nn.functional.mse_loss(batch["image"], outputs["rgb"])}  # [REF :294-295]
+                  interlevel_loss_mult: float = 1.0, distortion_loss_mult: float = 0.002,
+                  pass_rgb_gradients: bool = True, pass_thermal_gradients: bool = True) -> Dict[str, Tensor]:
+    """[REF thermal_nerf_model.py:277-326], no predicted normals.  background "last_sample" leaves 3-channel ground truth
+    untouched (NS blend_background_for_loss_computation).  ``thermal_loss_weight`` exists in the reference config
+    [REF :53-54] but is never applied [REF :319-323]; the field's pass_rgb_gradients / pass_thermal_gradients flags gate the
+    two image losses [REF :295, :321].  Key order and values are pinned by the reference's own method (fixture G7)."""
+    loss = {}
+    if pass_rgb_gradients:
+        loss["rgb_loss"] = torch.nn.functional.mse_loss(batch["image"], outputs["rgb"])  # [REF :294-295]
     if training:
         loss["interlevel_loss"] = interlevel_loss_mult * interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
         assert metrics_dict is not None and "distortion" in metrics_dict  # [REF :301]
         loss["distortion_loss"] = distortion_loss_mult * metrics_dict["distortion"]
-    loss["thermal"] = torch.nn.functional.mse_loss(outputs["thermal"], batch["thermal"])  # [REF :319-323]
+    if pass_thermal_gradients:
+        loss["thermal"] = torch.nn.functional.mse_loss(outputs["thermal"], batch["thermal"])  # [REF :319-323]
     return loss
 
 

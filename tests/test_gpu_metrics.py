@@ -91,3 +91,33 @@ def test_get_image_metrics_and_images():
     rgba = torch.cat([gt_rgb, torch.full((36, 64, 1), 0.5)], dim=-1)
     m2, _ = gm.get_image_metrics_and_images(out, {"image": rgba, RM.THERMAL.value: gt_th})
     assert m2["psnr"] == pytest.approx(float(OM.psnr(gt_rgb * 0.5, rgb)), abs=1e-3)
+
+
+def test_thermal_image_metrics_golden_g7(golden_dir):
+    """ThermalNerfModel.get_image_metrics_and_images against what the reference's own method returned for the thermal modality
+    (tests/golden/model_wiring.npz ``metrics.*``, tools/make_golden.py G7)."""
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(golden_dir, "model_wiring.npz"))
+    gt, pr = torch.from_numpy(g["metrics.gt_thermal"]).to(DEV), torch.from_numpy(g["metrics.pred_thermal"]).to(DEV)
+    cm, _, _ = helpers.build("scene", 48)
+    gm = copy.deepcopy(cm).to(DEV).eval()
+    gm.config = copy.deepcopy(gm.config)
+    gm.max_temperature, gm.min_temperature = (float(x) for x in g["metrics.bounds"])
+    Hh, Ww = gt.shape[:2]
+    out = {"rgb": torch.rand(Hh, Ww, 3, device=DEV), "accumulation": torch.rand(Hh, Ww, 1, device=DEV),
+           "depth": torch.rand(Hh, Ww, 1, device=DEV) + 1, "thermal": pr}
+    batch = {"image": torch.rand(Hh, Ww, 3, device=DEV), "thermal": gt}
+    for cold in (False, True):
+        gm.config.cold = cold
+        for thr in (None, 0.6):
+            want = dict(zip(g[f"metrics.cold{int(cold)}_thr{thr}.keys"].tolist(), g[f"metrics.cold{int(cold)}_thr{thr}.values"].tolist()))
+            m, im = gm.get_image_metrics_and_images(out, batch, threshold=thr)
+            assert list(m.keys()) == list(want.keys())
+            for k in ("psnr_thermal", "ssim_thermal", "mae_thermal_foreground", "mae_thermal"):
+                assert abs(m[k] - want[k]) <= 2e-5 * abs(want[k]) + 1e-6, (k, m[k], want[k])
+    assert [k for k in im if not k.startswith("prop_depth")] == g["metrics.image_keys"].tolist()
+    np.testing.assert_array_equal(im["thermal"].cpu().numpy(), g["metrics.thermal_image"])
+    np.testing.assert_array_equal(im["thermal_combined"].cpu().numpy(), g["metrics.thermal_combined_image"])

@@ -5,6 +5,7 @@ Tolerances (written per test): the kernels are fp32 with a different summation o
 so gradients are compared in relative L2 norm per tensor; values pointwise."""
 import copy
 
+import numpy as np
 import pytest
 import torch
 
@@ -952,3 +953,63 @@ def test_eval_follows_fused_optimizer_updates(dense_mb):
     assert (after["rgb"] - before).abs().max().item() > 1e-2, "the render did not move: stale prepared weights"
     assert (after["rgb"].cpu() - want["rgb"]).abs().max().item() <= 2e-3
     assert (after["thermal"].cpu() - want["thermal"]).abs().max().item() <= 2e-3
+
+
+# --------------------------------------------------------------------------------------------------
+# G7: the reference's own get_outputs / get_loss_dict (run over oracle-built components) against the HIP model
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["eval", "train", "train_scaled", "train_no_thermal"])
+def test_model_wiring_golden_g7(golden_dir, monkeypatch, tag):
+    """tests/golden/model_wiring.npz holds what the REAL ThermalNerfModel.get_outputs / get_loss_dict
+    [REF thermal_nerf_model.py:210-326] returned (tools/make_golden.py G7): the HIP model's forward, loss dictionary and
+    gradients reproduce the keys, their order, the values and the gates (camera optimizer in training only, pass_thermal_gradients,
+    use_gradient_scaling, the never-applied thermal_loss_weight)."""
+    from tests.test_oracle_golden import G7_CASES, G7_GRADS, g7_problem
+
+    g, cm, sd, ocfg, o, d, cam, jit, batch = g7_problem(golden_dir)
+    kw = G7_CASES[tag]
+    training = kw["training"]
+    gm = copy.deepcopy(cm).to(DEV)
+    gm.config = copy.deepcopy(gm.config)
+    with torch.no_grad():
+        gm.camera_optimizer.pose_adjustment.copy_(sd["camera_optimizer.pose_adjustment"].to(DEV))
+    gm.config.use_gradient_scaling = bool(kw.get("gradient_scaling", False))
+    gm.field.pass_thermal_gradients = bool(kw.get("pass_thermal", True))
+    gm.config.thermal_loss_weight = 123.0  # never applied [REF :319-323]
+    gm.train(training)
+    if training:
+        orig = TR.get_outputs_train
+        J = torch.cat(jit, dim=1).T.contiguous().to(DEV)
+        monkeypatch.setattr(TR, "get_outputs_train", lambda m, rb: orig(m, rb, jitter=J))
+    rb = RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV))
+    out = gm(rb) if training else gm(RayBundle(origins=o.to(DEV), directions=d.to(DEV)))
+    assert list(out.keys()) == g[f"{tag}.output_keys"].tolist()
+    for k in ("rgb", "thermal", "accumulation"):
+        assert (out[k].detach().cpu().numpy() - g[f"{tag}.out.{k}"]).__abs__().max() <= 2e-5, k
+    want_e = g[f"{tag}.out.expected_depth"]
+    assert (np.abs(out["expected_depth"].detach().cpu().numpy() - want_e) <= 1e-4 * np.abs(want_e) + 1e-6).all()
+    for k in ("depth", "prop_depth_0", "prop_depth_1"):  # medians: at most one ray may sit on a 0.5 tie
+        bad = np.abs(out[k].detach().cpu().numpy() - g[f"{tag}.out.{k}"]) > 1e-4 * np.abs(g[f"{tag}.out.{k}"]) + 1e-6
+        assert bad.sum() <= 1, k
+    if training:
+        for i in range(3):
+            assert np.abs(out["weights_list"][i].detach().cpu().numpy() - g[f"{tag}.out.weights_list.{i}"]).max() <= 2e-5
+            assert np.abs(out["ray_samples_list"][i].spacing_bins.cpu().numpy() - g[f"{tag}.out.spacing_bins.{i}"]).max() <= 2e-5
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    loss = gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b))
+    assert list(loss.keys()) == g[f"{tag}.loss_keys"].tolist()
+    for k, v in loss.items():
+        want = float(g[f"{tag}.loss.{k}"])
+        assert abs(v.item() - want) <= 5e-5 * abs(want) + 1e-8, (k, v.item(), want)
+    if training:
+        gm.zero_grad(set_to_none=True)
+        sum(loss.values()).backward()
+        named = dict(gm.named_parameters())
+        for name in G7_GRADS:
+            want = torch.from_numpy(g[f"{tag}.grad.{name}"])
+            got = named[name].grad
+            if want.abs().max().item() == 0.0:
+                assert got is None or got.abs().max().item() == 0.0, name
+                continue
+            tol = 2e-2 if name.startswith("camera_optimizer") else 2e-3
+            assert rel(got, want) <= tol, f"{name}: {rel(got, want):.2e}"

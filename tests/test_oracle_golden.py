@@ -132,3 +132,105 @@ def test_g6_state_dict_names_match_reference_module(golden_dir):
     assert ref_keys <= mine, sorted(ref_keys - mine)
     for k in ref_keys:
         assert tuple(f.state_dict()[k].shape) == tuple(g["sd." + k].shape), k
+
+
+# ---- G7: the reference's own get_outputs / get_loss_dict on oracle-built components ----------------------------------------------
+def g7_problem(golden_dir):
+    """(fixture, cpu model, state dict incl. the fixture's pose adjustment, oracle config, rays, cameras, jitter, batch)"""
+    import json
+
+    from tests import helpers
+
+    g = np.load(os.path.join(golden_dir, "model_wiring.npz"))
+    cfg = json.loads(str(g["config"]))
+    cm, sd, ocfg = helpers.build(cfg["kind"], cfg["S"], small=cfg["small"], num_images=cfg["num_images"],
+                                 camera_optimizer_mode=cfg["camera_optimizer_mode"], log2_hashmap_size=cfg["log2_hashmap_size"],
+                                 num_proposal_samples_per_ray=tuple(cfg["num_proposal_samples_per_ray"]))
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["camera_optimizer.pose_adjustment"] = torch.from_numpy(g["pose_adjustment"])
+    # the weights are regenerated, not stored: they must be the tensors the fixture was made from
+    assert sorted(sd.keys()) == g["sd_keys"].tolist()
+    sums = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in sorted(sd.keys())])
+    np.testing.assert_allclose(sums, g["sd_sums"], rtol=1e-12, atol=0)
+    o, d = torch.from_numpy(g["origins"]), torch.from_numpy(g["directions"])
+    cam = torch.from_numpy(g["camera_indices"])
+    jit = [j for j in torch.from_numpy(g["jitter"])]
+    batch = {"image": torch.from_numpy(g["image"]), "thermal": torch.from_numpy(g["thermal"])}
+    return g, cm, sd, ocfg, o, d, cam, jit, batch
+
+
+G7_CASES = {"eval": dict(training=False), "train": dict(training=True), "train_scaled": dict(training=True, gradient_scaling=True),
+            "train_no_thermal": dict(training=True, pass_thermal=False)}
+G7_GRADS = ["field.mlp_base.mlp.layers.1.weight", "field.mlp_thermal.layers.0.weight", "field.mlp_head.layers.0.weight",
+            "proposal_networks.0.mlp_base.mlp.layers.0.weight", "camera_optimizer.pose_adjustment"]
+
+
+def test_g7_get_outputs_and_get_loss_dict_follow_the_reference_methods(golden_dir):
+    """oracle.hotpath.get_outputs + oracle.training.get_loss_dict against what the reference's OWN ThermalNerfModel.get_outputs /
+    get_loss_dict [REF thermal_nerf_model.py:210-326] returned when run over oracle-built components (tools/make_golden.py G7):
+    output keys and their order, train-only lists, prop_depth_i, camera optimizer in training only, loss keys / multipliers /
+    gates, gradient scaling.  Pins the wiring of the two methods, not nerfstudio's arithmetic."""
+    import dataclasses
+
+    from oracle import training as T
+
+    g, cm, sd, ocfg0, o, d, cam, jit, batch = g7_problem(golden_dir)
+    assert g["train.call_log"].tolist() == ["camera_optimizer", "proposal_sampler", "field", "renderer_rgb"]
+    assert g["eval.call_log"].tolist() == ["proposal_sampler", "field", "renderer_rgb"]  # REF :218: training only
+    for tag, kw in G7_CASES.items():
+        training = kw["training"]
+        ocfg = dataclasses.replace(ocfg0, use_gradient_scaling=bool(kw.get("gradient_scaling", False)))
+        leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith((".aabb", ".scalings")) else v)
+                  for k, v in sd.items()}
+        oo, dd = (T.apply_pose_adjustment(leaves["camera_optimizer.pose_adjustment"], cam, o, d) if training else (o, d))
+        out = H.get_outputs(leaves, oo, dd, cam if training else None, ocfg, training=training, jitter=jit if training else None)
+        assert list(out.keys()) == g[f"{tag}.output_keys"].tolist(), tag
+        for k, v in out.items():
+            if isinstance(v, torch.Tensor):
+                np.testing.assert_allclose(v.detach().numpy(), g[f"{tag}.out.{k}"], rtol=0, atol=1e-6, err_msg=f"{tag} {k}")
+        metrics = T.get_metrics_dict(out, batch, training)
+        loss = T.get_loss_dict(out, batch, metrics, training, pass_thermal_gradients=kw.get("pass_thermal", True))
+        assert list(loss.keys()) == g[f"{tag}.loss_keys"].tolist(), tag
+        for k, v in loss.items():
+            assert abs(v.item() - float(g[f"{tag}.loss.{k}"])) <= 1e-6 * abs(v.item()) + 1e-9, (tag, k)
+        assert g[f"{tag}.calls"].tolist() == [1 if training else 0, 1 if kw.get("gradient_scaling") else 0]
+        if training:
+            for i in range(3):
+                np.testing.assert_allclose(out["weights_list"][i].detach().numpy(), g[f"{tag}.out.weights_list.{i}"], atol=1e-6)
+                np.testing.assert_allclose(T.ray_samples_to_sdist(out["ray_samples_list"][i]).numpy(), g[f"{tag}.out.spacing_bins.{i}"],
+                                           atol=1e-6)
+            sum(loss.values()).backward()
+            for name in G7_GRADS:
+                want = g[f"{tag}.grad.{name}"]
+                got = leaves[name].grad
+                got = np.zeros_like(want) if got is None else got.numpy()
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-9 + 1e-5 * np.abs(want).max(), err_msg=f"{tag} {name}")
+    # the gates do what the reference's method did: no thermal loss -> the thermal MLP receives nothing; scaling changes gradients
+    assert np.abs(g["train_no_thermal.grad.field.mlp_thermal.layers.0.weight"]).max() == 0.0
+    assert np.abs(g["train.grad.field.mlp_thermal.layers.0.weight"]).max() > 0.0
+    assert not np.allclose(g["train_scaled.grad.field.mlp_base.mlp.layers.1.weight"], g["train.grad.field.mlp_base.mlp.layers.1.weight"])
+
+
+def test_g7_thermal_image_metrics_follow_the_reference_method(golden_dir):
+    """oracle.metrics.thermal_image_metrics against the reference's own get_image_metrics_and_images [REF :328-393] (run with
+    the oracle's PSNR / SSIM as the torchmetrics stand-ins and the reference's own mae_thermal): metric keys and their order,
+    [1,C,H,W] layout, which MAE takes the threshold, the "gray" thermal images."""
+    from oracle import metrics as OM
+
+    g = np.load(os.path.join(golden_dir, "model_wiring.npz"))
+    gt, pr = torch.from_numpy(g["metrics.gt_thermal"]), torch.from_numpy(g["metrics.pred_thermal"])
+    tmax, tmin = (float(x) for x in g["metrics.bounds"])
+    for cold in (False, True):
+        for thr in (None, 0.6):
+            keys = g[f"metrics.cold{int(cold)}_thr{thr}.keys"].tolist()
+            vals = dict(zip(keys, g[f"metrics.cold{int(cold)}_thr{thr}.values"].tolist()))
+            assert keys == ["psnr", "ssim", "lpips", "psnr_thermal", "ssim_thermal", "lpips_thermal", "mae_thermal_foreground",
+                            "mae_thermal"]
+            got = OM.thermal_image_metrics(gt, pr, cold, tmax, tmin, thr)
+            for k, v in got.items():
+                assert abs(v - vals[k]) <= 1e-6 * abs(vals[k]) + 1e-7, (k, v, vals[k])
+    assert g["metrics.image_keys"].tolist() == ["img", "accumulation", "depth", "thermal", "thermal_combined"]
+    np.testing.assert_array_equal(g["metrics.thermal_image"], np.repeat(g["metrics.pred_thermal"], 3, axis=-1))
+    np.testing.assert_array_equal(g["metrics.thermal_combined_image"],
+                                  np.concatenate([np.repeat(g["metrics.gt_thermal"], 3, -1), np.repeat(g["metrics.pred_thermal"], 3, -1)], axis=1))
+    assert g["metrics.lpips_input_shape"].tolist() == [1, 3, 24, 20]  # the thermal channel repeated to three for LPIPS [REF :381-383]
