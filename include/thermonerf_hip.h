@@ -389,15 +389,14 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * losses and the backward read: selector [N], density [N], rgb [N,3], thermal [N] and the hash features `enc`, the latter
  * in tiles of 64 consecutive samples, [ceil(N/64)][16 levels][64 samples][2] floats (the layout tn_field_bwd_fused reads;
  * allocate 32 * 64 * ceil(N/64) floats).  `ray_bias` [R,64] = mlp_head.0's
- * bias plus its SH(direction) and appearance-embedding columns applied to each ray's constants (tn_color_input_fwd with n = 1
- * and zero geo rows, then tn_linear_fwd with mlp_head.0): the colour layer sees them as a per-ray bias.
+ * bias plus its SH(direction) and appearance-embedding columns applied to each ray's constants (tn_ray_head_fwd): the colour
+ * layer sees them as a per-ray bias.
  *
  * tn_field_bwd_fused recomputes the five hidden layers from `enc` in registers and runs their adjoints next to them (no
  * [N,64] activation ever touches HBM).  Inputs: enc / selector / rgb of the forward, ray_bias, the per-sample output
  * gradients d_rgb [N,3], d_thermal [N] (either may be NULL: that branch is skipped), d_density [N].  Outputs: d_enc [N,32]
- * (=), d_ray_sum [R,64] (+=, zero it first) = per-ray sums of mlp_head.0's pre-activation gradient — the ray-level
- * tn_linear_bwd(x = the ray rows of tn_color_input_fwd, dy = d_ray_sum) then yields mlp_head.0's bias gradient, its SH and
- * appearance weight columns and, through tn_color_input_bwd with n = 1, the embedding / direction gradients — and the
+ * (=), d_ray_sum [R,64] (+=, zero it first) = per-ray sums of mlp_head.0's pre-activation gradient — tn_ray_head_bwd then
+ * yields mlp_head.0's bias gradient, its SH and appearance weight columns and the embedding / direction gradients — and the
  * gradients of every other Linear of the field (+=; NULL entries skipped; head0_w receives its geo columns 16..30 only).
  * trunc_exp_min: lower clamp of trunc_exp's backward (g * exp(clamp(x, min, 15)); -15 = torch-ngp / nerfstudio's
  * two-sided clamp, -INFINITY = upper clamp only).  pass_thermal_gradients = 0 keeps the thermal branch from the geo
@@ -405,6 +404,16 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * accumulators); 1: the colour head and (thermal head + mlp_base) as two launches of two waves per SIMD each, the colour
  * head's adjoint of mlp_base's outputs passing through the workspace.  The reference geometry only (16 levels, geo 15,
  * appearance 32). */
+/* mlp_head.0's ray-constant part [REF thermal_field.py:117-126,160-168]: ray_bias [R,64] = bias + W[:, 0:16] . SH(direction) +
+ * W[:, 31:63] . embedding[camera] (training-mode appearance), and its adjoint on the per-ray sums d_ray_sum [R,64] of the layer's
+ * pre-activation gradient: d_head0_weight (+=, the SH and appearance columns only), d_head0_bias (+=), d_appearance
+ * [num_images, 32] (+=), and optionally d_ray_inputs [R,64] (=; columns 0..15 = gradient w.r.t. the SH basis values, which
+ * tn_color_input_bwd with n = 1 carries on to the directions). */
+int tn_ray_head_fwd(const tn_thermal_field *field, const float *directions, const int32_t *camera_indices, int64_t num_rays,
+                    float *ray_bias, void *stream);
+int tn_ray_head_bwd(const tn_thermal_field *field, const float *directions, const int32_t *camera_indices, int64_t num_rays,
+                    const float *d_ray_sum, float *d_head0_weight, float *d_head0_bias, float *d_appearance, float *d_ray_inputs,
+                    void *stream);
 typedef struct tn_field_grads {
     float *base0_w, *base0_b, *base1_w, *base1_b;
     float *head0_w, *head1_w, *head1_b, *head2_w, *head2_b;
@@ -456,6 +465,12 @@ int tn_color_input_fwd(const tn_thermal_field *field, const float *directions, c
 int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const int32_t *camera_indices,
                        int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
                        float *d_appearance, const float *directions, float *d_directions, void *stream);
+
+/* The two image losses of get_loss_dict [REF thermal_nerf_model.py:294-295, 319-323: MSELoss means] and the PSNR of NS
+ * get_metrics_dict in one launch: rgb / gt_rgb [R,3], thermal / gt_thermal [R] (thermal may be NULL) -> out[0] = rgb MSE,
+ * out[1] = thermal MSE, out[2] = 10 log10(1 / out[0]); d_rgb [R,3] (=) and d_thermal [R] (=) = the gradients of the two means. */
+int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal, const float *gt_thermal, int64_t num_rays,
+                    float *out, float *d_rgb, float *d_thermal, void *stream);
 
 /* NS losses.distortion_loss on one level: spacing bins [R,n+1], weights [R,n] -> loss_sum[0] (+=) = scale * sum over rays
  * of lossfun_distortion (scale = 1/R for nerfstudio's mean), d_weights [R,n] (=) = scale * d(sum)/dw.  O(n) per ray. */

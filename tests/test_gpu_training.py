@@ -917,7 +917,10 @@ def test_thermoscenes_style_tree_to_training_steps(tmp_path):
         assert len(res[key]) == 2 and all(-1.0 <= v <= 1.0 for v in res[key])
     assert all(v != v for v in res["lpips"]) and all(v != v for v in res["lpips_thermal"])  # NaN: no pretrained network offline
     ev.save_metrics(tmp_path / "eval")
-    saved = json.loads((tmp_path / "eval" / "metrics.json").read_text())
+    text = (tmp_path / "eval" / "metrics.json").read_text()
+    assert "NaN" not in text  # strict JSON: the LPIPS entries are null
+    saved = json.loads(text)
+    assert saved["results"]["lpips_mean"] is None
     assert saved["method_name"] == "thermal-nerf" and saved["job_param_identifier"] == "t" and "psnr_mean" in saved["results"]
     ev.save_images([M.RGB, M.THERMAL_COMBINED], tmp_path / "eval" / "images")
     names = sorted(p.name for p in (tmp_path / "eval" / "images").glob("*.jpg"))

@@ -202,6 +202,8 @@ SIGNATURES = {
     "tn_linear_chain_bwd_workspace_bytes": (_sz, []),
     "tn_linear_chain_bwd": (C.c_int, [C.POINTER(tn_chain_layer), _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
     "tn_field_fwd_taped": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32] + [_vp] * 12),
+    "tn_ray_head_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _vp, _vp]),
+    "tn_ray_head_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tn_field_fwd_train": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _i32] + [_vp] * 6),
     "tn_field_bwd_fused_workspace_bytes": (_sz, [_i64, _i32]),
     "tn_field_bwd_fused": (C.c_int, [C.POINTER(tn_thermal_field), _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_float,
@@ -211,6 +213,7 @@ SIGNATURES = {
     "tn_color_input_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "tn_hash_encode_bwd_input": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),
     "tn_frustum_positions_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_image_losses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_version": (C.c_char_p, []),

@@ -1631,6 +1631,56 @@ interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, cons
     if (threadIdx.x == 0) atomic_add_f32(loss_sum, scale * ((red[0] + red[1]) + (red[2] + red[3])));
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// the two image losses of get_loss_dict [REF thermal_nerf_model.py:294-295, 319-323] and the PSNR metric of get_metrics_dict in
+// ONE launch (as torch ops: two MSE kernels, two mean reductions, six elementwise launches for the PSNR and two more kernels
+// in the backward — a tenth of a 2 ms step in launches alone).  One block: a training batch is a few thousand pixels.
+// out[0] = mean((gt_rgb - rgb)^2), out[1] = mean((thermal - gt_thermal)^2), out[2] = 10 log10(1 / out[0]);
+// d_rgb = 2 (rgb - gt_rgb) / (3 R), d_thermal = 2 (thermal - gt_thermal) / R  (the gradients of the two means).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLossBlock = 1024;
+__global__ void __launch_bounds__(kLossBlock)
+image_losses_kernel(const float *__restrict__ rgb, const float *__restrict__ gt_rgb, const float *__restrict__ th,
+                    const float *__restrict__ gt_th, long long R, float *__restrict__ out, float *__restrict__ d_rgb,
+                    float *__restrict__ d_th) {
+    __shared__ float red[2][kLossBlock / 64];
+    const long long n3 = R * 3;
+    const float k3 = 2.0f / (float)n3, k1 = 2.0f / (float)R;
+    float s3 = 0.0f, s1 = 0.0f;
+    for (long long i = threadIdx.x; i < n3; i += kLossBlock) {
+        const float e = rgb[i] - gt_rgb[i];
+        s3 = fmaf(e, e, s3);
+        d_rgb[i] = k3 * e;
+    }
+    if (th) {
+        for (long long i = threadIdx.x; i < R; i += kLossBlock) {
+            const float e = th[i] - gt_th[i];
+            s1 = fmaf(e, e, s1);
+            d_th[i] = k1 * e;
+        }
+    }
+    s3 = wave_sum(s3);
+    s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = s3;
+        red[1][wave] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f, b = 0.0f;
+        for (int w = 0; w < kLossBlock / 64; ++w) {
+            a += red[0][w];
+            b += red[1][w];
+        }
+        const float mse = a / (float)n3;
+        out[0] = mse;
+        out[1] = b / (float)R;
+        out[2] = 10.0f * log10f(1.0f / mse);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2076,4 +2126,16 @@ int tn_interlevel_loss(const float *c, const float *w, const float *cp, const fl
     return TN_OK;
 }
 
+int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal, const float *gt_thermal, int64_t num_rays,
+                    float *out, float *d_rgb, float *d_thermal, void *stream) {
+    if (!rgb || !gt_rgb || !out || !d_rgb) return TN_ERR_NULL;
+    if (thermal && (!gt_thermal || !d_thermal)) return TN_ERR_NULL;
+    if (num_rays < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(image_losses_kernel, dim3(1), dim3(kLossBlock), 0, (hipStream_t)stream, rgb, gt_rgb, thermal, gt_thermal,
+                       (long long)num_rays, out, d_rgb, d_thermal);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 }  // extern "C"
+

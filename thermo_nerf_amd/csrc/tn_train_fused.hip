@@ -603,6 +603,122 @@ __global__ void __launch_bounds__(kBlock) field_bwd_reduce_kernel(RedArgs a) {
     }
 }
 
+
+// ---- mlp_head.0's per-ray part ---------------------------------------------------------------------------------------------------
+// 48 of the layer's 63 inputs — SH(direction) [REF thermal_field.py:117-119] and the appearance embedding of the ray's camera
+// [REF :121-126] — are constant along a ray: the forward folds them into a per-ray bias, the backward works on per-ray sums.
+constexpr int RH_IN = 16 + APP;  // the ray-constant inputs: SH 0..15, appearance 16..47
+__device__ __forceinline__ int rh_col(int k) { return k < 16 ? k : GF + k; }  // column of mlp_head.0's weight
+
+__global__ void __launch_bounds__(256) ray_head_fwd_kernel(const float *__restrict__ w, const float *__restrict__ b,
+                                                           const float *__restrict__ emb, const float *__restrict__ dirs,
+                                                           const int *__restrict__ cam, long long R, int sh_shifted,
+                                                           float *__restrict__ ray_bias) {
+    __shared__ float Wt[RH_IN][64];  // [k][f]
+    for (int e = threadIdx.x; e < RH_IN * 64; e += 256) Wt[e >> 6][e & 63] = w[(e & 63) * IN0 + rh_col(e >> 6)];
+    __syncthreads();
+    const int f = threadIdx.x & 63;
+    const float bf = b[f];
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (long long)gridDim.x * 4) {
+        float x = dirs[r * 3], y = dirs[r * 3 + 1], z = dirs[r * 3 + 2];
+        if (sh_shifted) {
+            x = add_rn(x, 1.0f) / 2.0f; y = add_rn(y, 1.0f) / 2.0f; z = add_rn(z, 1.0f) / 2.0f;
+        }
+        float c[16];
+        sh16(x, y, z, c);
+        float v = bf;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v = fmaf(Wt[k][f], c[k], v);
+        const float4 *e4 = reinterpret_cast<const float4 *>(emb + (size_t)cam[r] * APP);
+#pragma unroll
+        for (int k4 = 0; k4 < APP / 4; ++k4) {
+            const float4 e = e4[k4];
+            v = fmaf(Wt[16 + 4 * k4][f], e.x, v);
+            v = fmaf(Wt[17 + 4 * k4][f], e.y, v);
+            v = fmaf(Wt[18 + 4 * k4][f], e.z, v);
+            v = fmaf(Wt[19 + 4 * k4][f], e.w, v);
+        }
+        ray_bias[r * 64 + f] = v;
+    }
+}
+
+// backward on the per-ray sums g[r][f] of the layer's pre-activation gradient (tn_field_bwd_fused's d_ray_sum):
+//   d_w[f][col k] += sum_r g[r][f] x[r][k],  d_b[f] += sum_r g[r][f],  d_emb[cam_r][k] += (W^T g[r])[16 + k],
+//   d_x [R,64] (optional; columns 0..15 = the SH part, what tn_color_input_bwd turns into the direction gradient)
+constexpr int RH_BATCH = 64;
+__global__ void __launch_bounds__(256) ray_head_bwd_kernel(const float *__restrict__ w, const float *__restrict__ emb,
+                                                           const float *__restrict__ dirs, const int *__restrict__ cam, long long R,
+                                                           int sh_shifted, const float *__restrict__ g, float *__restrict__ d_w,
+                                                           float *__restrict__ d_b, float *__restrict__ d_emb,
+                                                           float *__restrict__ d_x) {
+    __shared__ float Wt[RH_IN][64];        // [k][f]
+    __shared__ float G[RH_BATCH][65];      // [ray][f]
+    __shared__ float X[RH_BATCH][RH_IN];   // [ray][k]
+    for (int e = threadIdx.x; e < RH_IN * 64; e += 256) Wt[e >> 6][e & 63] = w[(e & 63) * IN0 + rh_col(e >> 6)];
+    const int lo = threadIdx.x & 63, part = threadIdx.x >> 6;
+    float aw[RH_IN / 4], ab = 0.0f;  // thread (f = lo, part): d_w[f][col(part + 4 j)]
+#pragma unroll
+    for (int j = 0; j < RH_IN / 4; ++j) aw[j] = 0.0f;
+    for (long long r0 = (long long)blockIdx.x * RH_BATCH; r0 < R; r0 += (long long)gridDim.x * RH_BATCH) {
+        __syncthreads();
+        const long long r = r0 + lo;  // staging: thread (ray lo, part)
+        const bool live = r < R;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) G[lo][part * 16 + q] = live ? g[r * 64 + part * 16 + q] : 0.0f;
+        if (part == 0) {
+            float x = live ? dirs[r * 3] : 0.0f, y = live ? dirs[r * 3 + 1] : 0.0f, z = live ? dirs[r * 3 + 2] : 1.0f;
+            if (sh_shifted) {
+                x = add_rn(x, 1.0f) / 2.0f; y = add_rn(y, 1.0f) / 2.0f; z = add_rn(z, 1.0f) / 2.0f;
+            }
+            float c[16];
+            sh16(x, y, z, c);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) X[lo][k] = c[k];
+        } else if (part <= 2) {
+            const float *e = emb + (size_t)(live ? cam[r] : 0) * APP + (part - 1) * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) X[lo][16 + (part - 1) * 16 + k] = e[k];
+        }
+        __syncthreads();
+        // weight / bias gradient partials: thread (f = lo, part)
+        for (int rr = 0; rr < RH_BATCH; ++rr) {
+            const float gv = G[rr][lo];
+#pragma unroll
+            for (int j = 0; j < RH_IN / 4; ++j) aw[j] = fmaf(gv, X[rr][part + 4 * j], aw[j]);
+            if (part == 0) ab += gv;
+        }
+        // d_x of ray lo, inputs part + 4 j
+        float dx[RH_IN / 4];
+#pragma unroll
+        for (int j = 0; j < RH_IN / 4; ++j) dx[j] = 0.0f;
+        for (int f = 0; f < 64; ++f) {
+            const float gv = G[lo][f];
+#pragma unroll
+            for (int j = 0; j < RH_IN / 4; ++j) dx[j] = fmaf(Wt[part + 4 * j][f], gv, dx[j]);
+        }
+        __syncthreads();  // every reader of X is done: it now carries d_x to the lanes that issue the atomics
+#pragma unroll
+        for (int j = 0; j < RH_IN / 4; ++j) X[lo][part + 4 * j] = dx[j];
+        __syncthreads();
+        // embedding gradient: a wave covers two rays x 32 entries per instruction — up to 64 distinct addresses in flight (with
+        // lane = ray and one entry per instruction a wave hits only as many addresses as it has cameras, and same-address
+        // atomics retire one at a time: 240 us instead of 15 for 4096 rays on 8 cameras)
+        if (d_emb) {
+            const int k = threadIdx.x & 31;
+            for (int rr = threadIdx.x >> 5; rr < RH_BATCH; rr += 8) {
+                if (r0 + rr < R) unsafeAtomicAdd(d_emb + (size_t)cam[r0 + rr] * APP + k, X[rr][16 + k]);
+            }
+        }
+        if (d_x && live && part == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d_x[r * 64 + k] = X[lo][k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RH_IN / 4; ++j) unsafeAtomicAdd(d_w + lo * IN0 + rh_col(part + 4 * j), aw[j]);
+    if (part == 0 && d_b) unsafeAtomicAdd(d_b + lo, ab);
+}
+
 }  // namespace
 
 extern "C" {
@@ -697,4 +813,36 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     return launch(field_bwd_fused_kernel<4, 8>, 4, 8, smem4);
 }
 
+int tn_ray_head_fwd(const tn_thermal_field *f, const float *directions, const int32_t *camera_indices, int64_t num_rays,
+                    float *ray_bias, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!f || !directions || !camera_indices || !ray_bias) return TN_ERR_NULL;
+    if (num_rays < 0) return TN_ERR_SHAPE;
+    TN_TRY(tn_check_thermal_field(f));
+    if (f->geo_feat_dim != GF || f->app_dim != APP) return TN_ERR_UNSUPPORTED;
+    const long long blocks = (num_rays + 3) / 4;
+    hipLaunchKernelGGL(ray_head_fwd_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream,
+                       f->head0.weight, f->head0.bias, f->appearance, directions, camera_indices, (long long)num_rays, f->sh_shifted,
+                       ray_bias);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_ray_head_bwd(const tn_thermal_field *f, const float *directions, const int32_t *camera_indices, int64_t num_rays,
+                    const float *d_ray_sum, float *d_head0_weight, float *d_head0_bias, float *d_appearance, float *d_ray_inputs,
+                    void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!f || !directions || !camera_indices || !d_ray_sum || !d_head0_weight) return TN_ERR_NULL;
+    if (num_rays < 0) return TN_ERR_SHAPE;
+    TN_TRY(tn_check_thermal_field(f));
+    if (f->geo_feat_dim != GF || f->app_dim != APP) return TN_ERR_UNSUPPORTED;
+    const long long blocks = (num_rays + RH_BATCH - 1) / RH_BATCH;
+    hipLaunchKernelGGL(ray_head_bwd_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream,
+                       f->head0.weight, f->appearance, directions, camera_indices, (long long)num_rays, f->sh_shifted, d_ray_sum,
+                       d_head0_weight, d_head0_bias, d_appearance, d_ray_inputs);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 }  // extern "C"
+

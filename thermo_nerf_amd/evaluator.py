@@ -88,5 +88,14 @@ class Evaluator:
         """[REF evaluator.py:126-133]"""
         output_file = Path(output_folder, "metrics.json")
         output_file.parent.mkdir(parents=True, exist_ok=True)
-        output_file.write_text(json.dumps(self._benchmark_info, indent=2), "utf8")
+        def strict(v):  # NaN (LPIPS without its pretrained weights, the std of a single image) is not JSON: write null
+            if isinstance(v, float) and v != v:
+                return None
+            if isinstance(v, dict):
+                return {k: strict(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return [strict(x) for x in v]
+            return v
+
+        output_file.write_text(json.dumps(strict(self._benchmark_info), indent=2, allow_nan=False), "utf8")
         return output_file

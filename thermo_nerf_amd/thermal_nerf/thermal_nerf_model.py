@@ -202,10 +202,33 @@ class ThermalNerfModel(ThermalNerfactoModel):
         from ..training import distortion_loss
 
         gt_rgb = batch["image"].to(self.device)[..., :3]
-        metrics = {"psnr": 10.0 * torch.log10(1.0 / torch.mean((outputs["rgb"].detach() - gt_rgb) ** 2))}
+        fused = self._fused_image_losses(outputs, batch)
+        if fused is not None:
+            metrics = {"psnr": fused[2]}
+        else:
+            metrics = {"psnr": 10.0 * torch.log10(1.0 / torch.mean((outputs["rgb"].detach() - gt_rgb) ** 2))}
         if self.training:
             metrics["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
         return metrics
+
+    def _fused_image_losses(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
+        """(rgb MSE, thermal MSE, PSNR) of a training batch from ONE kernel (tn_image_losses), shared by get_metrics_dict and
+        get_loss_dict of the same outputs; None when the batch is not the plain training case (then torch's ops run)."""
+        rgb, th = outputs.get("rgb"), outputs.get(RenderedImageModality.THERMAL.value)
+        img, tgt = batch.get("image"), batch.get(RenderedImageModality.THERMAL.value)
+        if not (self.training and torch.is_grad_enabled() and isinstance(rgb, Tensor) and rgb.is_cuda and rgb.dim() == 2
+                and isinstance(th, Tensor) and isinstance(img, Tensor) and isinstance(tgt, Tensor) and img.shape == rgb.shape
+                and tgt.numel() == th.numel() and rgb.dtype == torch.float32 and img.dtype == torch.float32
+                and tgt.dtype == torch.float32):
+            return None
+        hit = self.__dict__.get("_image_loss_cache")
+        if hit is not None and hit[0] is rgb and hit[1] is img and hit[2] is tgt:
+            return hit[3]
+        from ..training import image_losses
+
+        res = image_losses(rgb, th, img.to(rgb.device), tgt.to(rgb.device))
+        self.__dict__["_image_loss_cache"] = (rgb, img, tgt, res)
+        return res
 
     def get_loss_dict(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor],
                       metrics_dict: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
@@ -216,8 +239,9 @@ class ThermalNerfModel(ThermalNerfactoModel):
         image = batch["image"].to(self.device)
         pred_rgb, gt_rgb = self.renderer_rgb.blend_background_for_loss_computation(
             pred_image=outputs["rgb"], pred_accumulation=outputs[RenderedImageModality.ACCUMULATION.value], gt_image=image)
+        fused = self._fused_image_losses(outputs, batch) if pred_rgb is outputs["rgb"] and image.shape[-1] == 3 else None
         if self.field.pass_rgb_gradients:
-            loss_dict["rgb_loss"] = torch.nn.functional.mse_loss(gt_rgb, pred_rgb)  # REF :294-295
+            loss_dict["rgb_loss"] = fused[0] if fused is not None else torch.nn.functional.mse_loss(gt_rgb, pred_rgb)  # REF :294-295
         if self.training:
             loss_dict["interlevel_loss"] = self.config.interlevel_loss_mult * interlevel_loss(
                 outputs["weights_list"], outputs["ray_samples_list"])  # REF :296-300
@@ -228,8 +252,9 @@ class ThermalNerfModel(ThermalNerfactoModel):
         thermal_batch = batch[RenderedImageModality.THERMAL.value].to(self.device)
         if self.field.pass_thermal_gradients:
             # the reference gates the thermal LOSS (not only the geo gradient) on this flag [REF :319-323]
-            loss_dict[RenderedImageModality.THERMAL.value] = torch.nn.functional.mse_loss(
+            loss_dict[RenderedImageModality.THERMAL.value] = fused[1] if fused is not None else torch.nn.functional.mse_loss(
                 outputs[RenderedImageModality.THERMAL.value], thermal_batch)
+        self.__dict__.pop("_image_loss_cache", None)  # one (metrics, losses) pair per forward
         return loss_dict
 
     def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor],

@@ -181,14 +181,27 @@ class _GradArena:
     parameter was ~50 fill launches per step).  A fresh arena per backward: the views become the parameters' .grad and must
     not alias the next step's."""
 
-    def __init__(self, like: Dict[str, Tensor], dev) -> None:
+    def __init__(self, like: Dict[str, Tensor], dev, extra: int = 0) -> None:
         self.like, self.dev = like, dev
         self.offsets: Dict[str, int] = {}
         total = 0
         for name, p in like.items():
             self.offsets[name] = total
             total += (p.numel() + 63) // 64 * 64  # 256-byte aligned views
-        self.flat = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self._extra = total  # `extra` more zero floats for the step's other zero-initialised buffers (ray gradients, per-ray sums)
+        self.flat = torch.zeros((total + extra,), dtype=torch.float32, device=dev)
+
+    def zeros(self, shape) -> Tensor:
+        """a zero tensor carved from the arena's tail (falls back to a fresh allocation when the tail is used up)"""
+        n = 1
+        for k in shape:
+            n *= k
+        n_al = (n + 63) // 64 * 64
+        if self._extra + n_al > self.flat.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+        out = self.flat[self._extra:self._extra + n].view(shape)
+        self._extra += n_al
+        return out
 
     def get(self, name: str) -> Tensor:
         p = self.like[name]
@@ -358,16 +371,14 @@ class RenderTrain(torch.autograd.Function):
         if tape_free:
             # no activation tape: the per-ray constant inputs of mlp_head.0 (SH(direction), appearance embedding) become a
             # per-ray bias [R,64]; the forward keeps enc / selector / density / rgb / thermal, tn_field_bwd_fused recomputes the rest
-            cin = _f32((R, 64), dev)   # ray rows of mlp_head's input: [SH | 0 (geo) | appearance | 0]
-            _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), _zeros_like_cached(dev, R * 16).data_ptr(), 16, cam.data_ptr(), 1, R, 1,
-                                              cin.data_ptr(), _stream()), "tn_color_input_fwd")
-            ray_bias = linear_fwd(cin, 0, 64, fld.head0, ACT_NONE, R)
+            ray_bias = _f32((R, 64), dev)
+            _hip.check(lib.tn_ray_head_fwd(fld, d.data_ptr(), cam.data_ptr(), R, ray_bias.data_ptr(), _stream()), "tn_ray_head_fwd")
             f.enc, f.sel, f.density = _f32(((N + 63) // 64 * 64, 32), dev), _f32((N,), dev), _f32((N,), dev)  # enc: 64-sample tiles
             rgb_s, th_s = _f32((N, 3), dev), _f32((N, 1), dev)
             _hip.check(lib.tn_field_fwd_train(fused, f.pos.data_ptr(), ray_bias.data_ptr(), R, S, f.enc.data_ptr(), f.sel.data_ptr(),
                                               f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _stream()),
                        "tn_field_fwd_train")
-            bo = ray_bias  # (slot reuse in ctx.acts: the tape-free backward reads (cin, ray_bias, rgb_s))
+            bo = ray_bias  # (slot reuse in ctx.acts: the tape-free backward reads (ray_bias, rgb_s))
         elif fused is not None and cfg.fused_train_forward:
             # the whole field forward of the level in one launch; every tensor of the tape in the layout the adjoints read
             f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
@@ -451,20 +462,20 @@ class RenderTrain(torch.autograd.Function):
         grads: Dict[str, Tensor] = {}
         # camera-pose optimisation: the ray origins / directions carry gradient (NS CameraOptimizer.apply_to_raybundle)
         ray_grads = None
+        R_, S_ = f.weights.shape
+        arena = _GradArena(like, dev, extra=R_ * (64 + 2 * 64 + S_) + 1024)  # every gradient buffer of this step: one allocation, one fill
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            ray_grads = (torch.zeros_like(ctx.o), torch.zeros_like(ctx.d))
+            ray_grads = (arena.zeros(tuple(ctx.o.shape)), arena.zeros(tuple(ctx.d.shape)))
         # NS SHEncoding.pytorch_fwd is @torch.no_grad(): by default the SH basis passes no gradient to the
         # directions; config.sh_direction_gradient=True adds that term (a differentiable SH encoding)
         sh_grads = ray_grads is not None and bool(cfg.sh_direction_gradient)
-
-        arena = _GradArena(like, dev)  # every parameter gradient of this step: one allocation, one fill
 
         def zeros(name: str) -> Tensor:
             grads[name] = arena.get(name)
             return grads[name]
 
         # ---- final level ------------------------------------------------------------------------------------
-        g_w = torch.zeros((R, S), dtype=torch.float32, device=dev) if g_w2 is None else g_w2.reshape(R, S).contiguous().clone()
+        g_w = arena.zeros((R, S)) if g_w2 is None else g_w2.reshape(R, S).contiguous().clone()
         if g_acc is not None:
             g_w += g_acc.reshape(R, 1)
         g_rgb_s, g_th_s = None, None
@@ -503,7 +514,7 @@ class RenderTrain(torch.autograd.Function):
                 setattr(gr, key + "_w", zeros(name + ".weight").data_ptr())
                 if key != "head0":
                     setattr(gr, key + "_b", zeros(name + ".bias").data_ptr())
-            g_ray = torch.zeros((R, 64), dtype=torch.float32, device=dev) if g_rgb_s is not None else None
+            g_ray = arena.zeros((R, 64)) if g_rgb_s is not None else None
             ws = _fused_bwd_workspace(dev, R, S)
             _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), self_bias.data_ptr(), rgb_s.data_ptr(),
                                               _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
@@ -512,16 +523,16 @@ class RenderTrain(torch.autograd.Function):
                                               _hip.ptr(g_ray), C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
                        "tn_field_bwd_fused")
             if g_ray is not None:
-                # the ray-level Linear backward of mlp_head.0: bias, SH and appearance weight columns (the geo columns of the ray
-                # rows are zero), and d(ray row) -> embedding / direction gradients
-                g_cin = _f32((R, 64), dev)
-                linear_bwd(cin, 0, 64, None, g_ray, 64, fld.head0, ACT_NONE, R, g_cin, 0, 64, False,
-                           grads["field.mlp_head.layers.0.weight"], zeros("field.mlp_head.layers.0.bias"))
-                _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, 1, None, 0,
-                                                  zeros("field.embedding_appearance.embedding.weight").data_ptr(),
-                                                  ctx.d.data_ptr() if sh_grads else None,
-                                                  ray_grads[1].data_ptr() if sh_grads else None, _stream()),
-                           "tn_color_input_bwd")
+                # mlp_head.0's ray-level part: bias, SH and appearance weight columns, the embedding gradient
+                g_cin = _f32((R, 64), dev) if sh_grads else None
+                _hip.check(lib.tn_ray_head_bwd(fld, ctx.d.data_ptr(), ctx.cam.data_ptr(), R, g_ray.data_ptr(),
+                                               grads["field.mlp_head.layers.0.weight"].data_ptr(),
+                                               zeros("field.mlp_head.layers.0.bias").data_ptr(),
+                                               zeros("field.embedding_appearance.embedding.weight").data_ptr(), _hip.ptr(g_cin),
+                                               _stream()), "tn_ray_head_bwd")
+                if sh_grads:  # ... and on through the SH basis to the directions (camera-pose optimisation, differentiable-SH switch)
+                    _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, 1, None, 0, None,
+                                                      ctx.d.data_ptr(), ray_grads[1].data_ptr(), _stream()), "tn_color_input_bwd")
             hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
             if ray_grads:
                 _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
@@ -643,6 +654,33 @@ class _Interlevel(torch.autograd.Function):
         for g, shape in zip(ctx.g, ctx.shapes):
             out += [(go * g).view(shape), None]
         return tuple(out)
+
+
+class _ImageLosses(torch.autograd.Function):
+    """rgb MSE, thermal MSE [REF thermal_nerf_model.py:294-295, 319-323] and the PSNR metric in one launch
+    (tn_image_losses); apply(rgb [R,3], thermal [R,1], gt_rgb, gt_thermal) -> (rgb_loss, thermal_loss, psnr)."""
+
+    @staticmethod
+    def forward(ctx, rgb: Tensor, thermal: Tensor, gt_rgb: Tensor, gt_thermal: Tensor):
+        R = rgb.shape[0]
+        rgb_c, th_c = _hip.require_device_tensor(rgb, "rgb"), _hip.require_device_tensor(thermal.reshape(R), "thermal")
+        g3, g1 = _hip.require_device_tensor(gt_rgb, "image"), _hip.require_device_tensor(gt_thermal.reshape(R), "thermal image")
+        out, d_rgb, d_th = _f32((4,), rgb.device), _f32((R, 3), rgb.device), _f32((R, 1), rgb.device)
+        _hip.check(_hip.load().tn_image_losses(rgb_c.data_ptr(), g3.data_ptr(), th_c.data_ptr(), g1.data_ptr(), R, out.data_ptr(),
+                                               d_rgb.data_ptr(), d_th.data_ptr(), _stream()), "tn_image_losses")
+        ctx.d_rgb, ctx.d_th = d_rgb, d_th
+        ctx.set_materialize_grads(False)
+        psnr = out[2]
+        ctx.mark_non_differentiable(psnr)
+        return out[0], out[1], psnr
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_th, _g_psnr):
+        return (None if g_rgb is None else g_rgb * ctx.d_rgb, None if g_th is None else g_th * ctx.d_th, None, None)
+
+
+def image_losses(rgb: Tensor, thermal: Tensor, gt_rgb: Tensor, gt_thermal: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    return _ImageLosses.apply(rgb, thermal, gt_rgb, gt_thermal)
 
 
 def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) -> Tensor:

@@ -33,10 +33,8 @@ def main():
     fld = model.field.c_struct(prepare=True, dense=False)
     f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     st = _hip.current_stream()
-    cin = f32(R, 64)
-    _hip.check(lib.tn_color_input_fwd(fld, d.data_ptr(), torch.zeros(R * 16, device=dev).data_ptr(), 16, cam.data_ptr(), 1, R, 1,
-                                      cin.data_ptr(), st), "cin")
-    ray_bias = TR.linear_fwd(cin, 0, 64, fld.head0, TR.ACT_NONE, R)
+    ray_bias = f32(R, 64)
+    _hip.check(lib.tn_ray_head_fwd(fld, d.data_ptr(), cam.data_ptr(), R, ray_bias.data_ptr(), st), "tn_ray_head_fwd")
     enc, sel, dens, rgb, th = f32((N + 63) // 64 * 64, 32), f32(N), f32(N), f32(N, 3), f32(N, 1)
 
     def fwd():
