@@ -766,15 +766,16 @@ def test_degenerate_rays(family):
     check_outputs(got, want, f"degenerate rays {family}")
 
 
-def test_full_frame_properties():
-    """BASELINE config 2 at full size (800x800 = 640 000 rays, S=64, full-size tables): size-independent properties of the
-    path — idempotence, independence from chunking / stream scheduling, equivariance under a permutation of the rays —
-    plus the oracle on a strided sample of the same frame."""
+@pytest.mark.parametrize("S", [64, 192])  # BASELINE config 2, and the metric's own frame (800x800 at 192 samples per ray)
+def test_full_frame_properties(S):
+    """BASELINE's frames at full size (800x800 = 640 000 rays, full-size tables; S = 64: config 2, S = 192: the configuration
+    the headline metric is quoted on): size-independent properties of the path — idempotence, independence from chunking /
+    stream scheduling, equivariance under a permutation of the rays — plus the oracle on a strided sample of the same frame."""
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.engine import RayRenderEngine
 
     # config.kernel_family stays "auto": every call picks its kernel family by size, as in production
-    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=64)
+    cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, "scene")
     sd = synthetic.model_state_dict_cpu(model)

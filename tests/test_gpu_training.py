@@ -294,7 +294,8 @@ def test_interlevel_loss_and_gradient(ns):
 # the whole step
 # --------------------------------------------------------------------------------------------------
 def _train_setup(kind, S, R_hw=(12, 12), seed=11, **over):
-    cm, sd, ocfg = helpers.build(kind, S, camera_optimizer_mode="off", **over)
+    over.setdefault("camera_optimizer_mode", "off")
+    cm, sd, ocfg = helpers.build(kind, S, **over)
     gm = copy.deepcopy(cm).to(DEV)
     gm.train()
     o, d = helpers.rays(*R_hw, view=3)
@@ -1016,3 +1017,18 @@ def test_model_wiring_golden_g7(golden_dir, monkeypatch, tag):
                 continue
             tol = 2e-2 if name.startswith("camera_optimizer") else 2e-3
             assert rel(got, want) <= tol, f"{name}: {rel(got, want):.2e}"
+
+
+def test_out_of_range_camera_index_poisons_the_ray_instead_of_reading_elsewhere():
+    """the camera-optimizer and appearance-embedding look-ups index tables with the batch's camera ids; torch's
+    index_select / nn.Embedding would raise on a stale or eval-split id.  The kernels never read outside the tables: such a ray
+    comes out NaN (the step's loss turns NaN — loud), and the backward skips it."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", 48, camera_optimizer_mode="SO3xR3")
+    cam = cam.clone()
+    cam[5] = 8      # num_train_data = 8: one past the tables
+    cam[9] = -1
+    out, loss = _gpu_step(gm, o, d, jit, cam, batch)
+    rgb = out["rgb"].detach().cpu()
+    bad = torch.isnan(rgb).any(dim=-1)
+    assert bad[5] and bad[9] and int(bad.sum()) == 2
+    assert torch.isnan(loss["rgb_loss"]).item()

@@ -1203,10 +1203,19 @@ __device__ __forceinline__ void cross3(const float *u, const float *v, float *o)
 }
 
 __global__ void __launch_bounds__(kBlock)
-camera_opt_fwd_kernel(const float *__restrict__ pose, const long long *__restrict__ cam, const float *__restrict__ origins,
-                      const float *__restrict__ dirs, long long n, float *__restrict__ out_o, float *__restrict__ out_d) {
+camera_opt_fwd_kernel(const float *__restrict__ pose, const long long *__restrict__ cam, int num_cameras,
+                      const float *__restrict__ origins, const float *__restrict__ dirs, long long n, float *__restrict__ out_o,
+                      float *__restrict__ out_d) {
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-        const Pose p = pose_load(pose, cam[i]);
+        const long long c = cam[i];
+        if (c < 0 || c >= num_cameras) {
+            // a stale / eval-split index: torch's index_select would raise; no table row is read and the ray is poisoned so that the
+            // step's loss turns NaN instead of training silently on another memory location
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out_o[i * 3 + k] = out_d[i * 3 + k] = __int_as_float(0x7fc00000);
+            continue;
+        }
+        const Pose p = pose_load(pose, c);
         const float d[3] = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
         float u[3], v[3];
         cross3(p.w, d, u);
@@ -1224,18 +1233,24 @@ camera_opt_fwd_kernel(const float *__restrict__ pose, const long long *__restric
 //   d/dt = g_o;   d/dw = a (d x g) + b (g (w.d) + d (g.w) - 2 (g.d) w) + (a'(theta) g.(w x d) + b'(theta) g.(w x (w x d))) w / theta
 // with the last term only where |w|^2 >= 1e-4 (inside the clamp theta is a constant).  Optional d_dirs_in = R^T g.
 __global__ void __launch_bounds__(kBlock)
-camera_opt_bwd_kernel(const float *__restrict__ pose, const long long *__restrict__ cam, const float *__restrict__ dirs,
-                      const float *__restrict__ g_o, const float *__restrict__ g_d, long long n, float *__restrict__ d_pose,
-                      float *__restrict__ d_dirs_in) {
+camera_opt_bwd_kernel(const float *__restrict__ pose, const long long *__restrict__ cam, int num_cameras,
+                      const float *__restrict__ dirs, const float *__restrict__ g_o, const float *__restrict__ g_d, long long n,
+                      float *__restrict__ d_pose, float *__restrict__ d_dirs_in) {
     const long long stride = (long long)gridDim.x * kBlock;
     const long long rounds = (n + stride - 1) / stride;
     for (long long rd = 0; rd < rounds; ++rd) {
         const long long i = rd * stride + (long long)blockIdx.x * kBlock + threadIdx.x;
-        const bool live = i < n;
+        bool live = i < n;
         long long c = -1;
         float q[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (live) {
             c = cam[i];
+            if (c < 0 || c >= num_cameras) {  // out of the table (the forward poisoned this ray): no read, no atomic
+                live = false;
+                c = -1;
+            }
+        }
+        if (live) {
             const Pose p = pose_load(pose, c);
             const float d[3] = {dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]};
             float g[3] = {0.0f, 0.0f, 0.0f};
@@ -1999,7 +2014,7 @@ int tn_camera_opt_fwd(const float *pose_adjustment, const int64_t *camera_indice
     if (!pose_adjustment || !camera_indices || !origins || !directions || !out_origins || !out_directions) return TN_ERR_NULL;
     if (num_rays < 0 || num_cameras < 1) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(camera_opt_fwd_kernel, dim3(grid_for(num_rays, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
-                       pose_adjustment, reinterpret_cast<const long long *>(camera_indices), origins, directions,
+                       pose_adjustment, reinterpret_cast<const long long *>(camera_indices), num_cameras, origins, directions,
                        (long long)num_rays, out_origins, out_directions);
     TN_LAUNCH_CHECK();
     return TN_OK;
@@ -2012,7 +2027,7 @@ int tn_camera_opt_bwd(const float *pose_adjustment, const int64_t *camera_indice
     if (!pose_adjustment || !camera_indices || !directions || !d_pose_adjustment) return TN_ERR_NULL;
     if (num_rays < 0 || num_cameras < 1) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(camera_opt_bwd_kernel, dim3(grid_for(num_rays, kBlock, 1 << 16)), dim3(kBlock), 0, (hipStream_t)stream,
-                       pose_adjustment, reinterpret_cast<const long long *>(camera_indices), directions, d_out_origins,
+                       pose_adjustment, reinterpret_cast<const long long *>(camera_indices), num_cameras, directions, d_out_origins,
                        d_out_directions, (long long)num_rays, d_pose_adjustment, d_directions);
     TN_LAUNCH_CHECK();
     return TN_OK;

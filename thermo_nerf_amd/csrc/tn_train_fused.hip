@@ -612,7 +612,7 @@ __device__ __forceinline__ int rh_col(int k) { return k < 16 ? k : GF + k; }  //
 
 __global__ void __launch_bounds__(256) ray_head_fwd_kernel(const float *__restrict__ w, const float *__restrict__ b,
                                                            const float *__restrict__ emb, const float *__restrict__ dirs,
-                                                           const int *__restrict__ cam, long long R, int sh_shifted,
+                                                           const int *__restrict__ cam, int num_images, long long R, int sh_shifted,
                                                            float *__restrict__ ray_bias) {
     __shared__ float Wt[RH_IN][64];  // [k][f]
     for (int e = threadIdx.x; e < RH_IN * 64; e += 256) Wt[e >> 6][e & 63] = w[(e & 63) * IN0 + rh_col(e >> 6)];
@@ -629,7 +629,12 @@ __global__ void __launch_bounds__(256) ray_head_fwd_kernel(const float *__restri
         float v = bf;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v = fmaf(Wt[k][f], c[k], v);
-        const float4 *e4 = reinterpret_cast<const float4 *>(emb + (size_t)cam[r] * APP);
+        const int ci = cam[r];
+        if (ci < 0 || ci >= num_images) {  // no embedding row: poison the ray (nn.Embedding would raise) instead of reading elsewhere
+            ray_bias[r * 64 + f] = __int_as_float(0x7fc00000);
+            continue;
+        }
+        const float4 *e4 = reinterpret_cast<const float4 *>(emb + (size_t)ci * APP);
 #pragma unroll
         for (int k4 = 0; k4 < APP / 4; ++k4) {
             const float4 e = e4[k4];
@@ -647,8 +652,8 @@ __global__ void __launch_bounds__(256) ray_head_fwd_kernel(const float *__restri
 //   d_x [R,64] (optional; columns 0..15 = the SH part, what tn_color_input_bwd turns into the direction gradient)
 constexpr int RH_BATCH = 64;
 __global__ void __launch_bounds__(256) ray_head_bwd_kernel(const float *__restrict__ w, const float *__restrict__ emb,
-                                                           const float *__restrict__ dirs, const int *__restrict__ cam, long long R,
-                                                           int sh_shifted, const float *__restrict__ g, float *__restrict__ d_w,
+                                                           const float *__restrict__ dirs, const int *__restrict__ cam, int num_images,
+                                                           long long R, int sh_shifted, const float *__restrict__ g, float *__restrict__ d_w,
                                                            float *__restrict__ d_b, float *__restrict__ d_emb,
                                                            float *__restrict__ d_x) {
     __shared__ float Wt[RH_IN][64];        // [k][f]
@@ -662,7 +667,7 @@ __global__ void __launch_bounds__(256) ray_head_bwd_kernel(const float *__restri
     for (long long r0 = (long long)blockIdx.x * RH_BATCH; r0 < R; r0 += (long long)gridDim.x * RH_BATCH) {
         __syncthreads();
         const long long r = r0 + lo;  // staging: thread (ray lo, part)
-        const bool live = r < R;
+        const bool live = r < R && cam[r < R ? r : 0] >= 0 && cam[r < R ? r : 0] < num_images;  // (rays without an embedding row: skipped)
 #pragma unroll
         for (int q = 0; q < 16; ++q) G[lo][part * 16 + q] = live ? g[r * 64 + part * 16 + q] : 0.0f;
         if (part == 0) {
@@ -706,7 +711,10 @@ __global__ void __launch_bounds__(256) ray_head_bwd_kernel(const float *__restri
         if (d_emb) {
             const int k = threadIdx.x & 31;
             for (int rr = threadIdx.x >> 5; rr < RH_BATCH; rr += 8) {
-                if (r0 + rr < R) unsafeAtomicAdd(d_emb + (size_t)cam[r0 + rr] * APP + k, X[rr][16 + k]);
+                if (r0 + rr < R) {
+                    const int ci = cam[r0 + rr];
+                    if (ci >= 0 && ci < num_images) unsafeAtomicAdd(d_emb + (size_t)ci * APP + k, X[rr][16 + k]);
+                }
             }
         }
         if (d_x && live && part == 0) {
@@ -822,8 +830,8 @@ int tn_ray_head_fwd(const tn_thermal_field *f, const float *directions, const in
     if (f->geo_feat_dim != GF || f->app_dim != APP) return TN_ERR_UNSUPPORTED;
     const long long blocks = (num_rays + 3) / 4;
     hipLaunchKernelGGL(ray_head_fwd_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream,
-                       f->head0.weight, f->head0.bias, f->appearance, directions, camera_indices, (long long)num_rays, f->sh_shifted,
-                       ray_bias);
+                       f->head0.weight, f->head0.bias, f->appearance, directions, camera_indices, f->num_images, (long long)num_rays,
+                       f->sh_shifted, ray_bias);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -838,7 +846,7 @@ int tn_ray_head_bwd(const tn_thermal_field *f, const float *directions, const in
     if (f->geo_feat_dim != GF || f->app_dim != APP) return TN_ERR_UNSUPPORTED;
     const long long blocks = (num_rays + RH_BATCH - 1) / RH_BATCH;
     hipLaunchKernelGGL(ray_head_bwd_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream,
-                       f->head0.weight, f->appearance, directions, camera_indices, (long long)num_rays, f->sh_shifted, d_ray_sum,
+                       f->head0.weight, f->appearance, directions, camera_indices, f->num_images, (long long)num_rays, f->sh_shifted, d_ray_sum,
                        d_head0_weight, d_head0_bias, d_appearance, d_ray_inputs);
     TN_LAUNCH_CHECK();
     return TN_OK;
