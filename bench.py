@@ -162,10 +162,10 @@ def load_profile_json(name: str):
     return json.load(open(p)) if os.path.exists(p) else {}
 
 
-def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, warmup: int = 6, start_step: int = 5000,
+def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, warmup: int = 24, start_step: int = 5000,
                        cpu: bool = True):
-    """Secondary measurement (BASELINE configs 3/5): one optimisation step = train-mode forward with a
-    tape + get_metrics_dict/get_loss_dict + backward + Adam(lr 1e-2, eps 1e-15) [REF config_thermal_nerf.py:32-45] on
+    """Secondary measurement (BASELINE configs 3/5): one optimisation step = train-mode forward (tape-free
+    final level, config.tape_free_training) + get_metrics_dict/get_loss_dict + backward + Adam(lr 1e-2, eps 1e-15) [REF config_thermal_nerf.py:32-45] on
     `rays` random-target rays, full-size tables, starting at `start_step` (>= proposal_warmup: the proposal networks take
     gradient every 6th step, as in nerfstudio's schedule)."""
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
@@ -214,7 +214,7 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 30, war
     # trace of tools/train_bench.py) is named beside it.
     hbm = 3 * b_all * R / dt / 1e9
     tfl = 3 * f_all * R / dt / 1e12
-    res = {"what": "train step: taped forward + losses + backward + Adam, %d rays/step, P=(256,96)+%d samples/ray, "
+    res = {"what": "train step: forward + losses + backward + Adam, %d rays/step, P=(256,96)+%d samples/ray, "
                    "steps %d.. (proposal nets updated every 6th step), camera optimizer SO3xR3" % (R, samples, start_step),
            "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps,
            "roofline": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
@@ -325,6 +325,87 @@ def roofline_of(S, n_rays, steps, prop_ms, main_ms, precision, no_mfma, value_pe
     return r
 
 
+def rccl_info(dist, world, dev):
+    """What the line says about the transport: the backend torch.distributed reports, the world size it sees, every rank's device."""
+    name = torch.cuda.get_device_name(dev)
+    if world == 1:
+        return {"backend": None, "world_size": 1, "devices": [name]}
+    names = [None] * world
+    dist.all_gather_object(names, "%s (cuda:%d)" % (name, dev.index))
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": names}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # pragma: no cover - informational only
+        pass
+    return info
+
+
+def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None):
+    """BASELINE config 4: ONE 1920x1080 camera-path frame, ray-sharded on the reference's chunk boundaries over the ranks and
+    all-gathered inside every step (strong scaling).  Returns the JSON fields on rank 0, None elsewhere."""
+    from thermo_nerf_amd import distributed as D
+    from thermo_nerf_amd import synthetic
+
+    S = S or args.samples or 48
+    H_, W_ = args.height or 1080, args.width or 1920
+    chunk = args.chunk or REF_CHUNK
+    model, cfg, _, engine = build_render(dev, S, chunk, args)
+    o3, d3, _ = synthetic.orbit_camera_rays(H_, W_, view=3)
+    n_rays = H_ * W_
+    if world > 1:
+        r0, r1 = D.chunk_block(n_rays, chunk, rank, world)
+        counts = [D.chunk_block(n_rays, chunk, r, world)[1] - D.chunk_block(n_rays, chunk, r, world)[0] for r in range(world)]
+    else:
+        r0, r1, counts = 0, n_rays, [n_rays]
+    o = o3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
+    d = d3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
+    out = engine.allocate_outputs(max(r1 - r0, 1), dev)
+    frame = [None]
+
+    def step():
+        if r1 > r0:
+            engine.render(o, d, out=out)
+        local = {k: v[: r1 - r0] for k, v in out.items()}
+        # the frame exists (on every rank) once the gather is done: it is inside the step, not pipelined away
+        frame[0] = D.gather_frame(local, H_, W_, counts=counts) if world > 1 else local
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    del model, engine, out
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    _, _, b_all = algorithmic_bytes_per_ray(S)
+    value = n_rays * steps / elapsed
+    return {
+        "metric": "rays/sec (forward-only render, ONE frame ray-sharded over the GPUs) @ %dx%d, %d samples/ray" % (W_, H_, S),
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "frame_latency_ms": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config 4: synthetic %dx%d camera-path frame, P=(256,96)+%d samples/ray, chunk %d, shards = "
+                               "contiguous runs of whole chunks per rank (rays per rank: %s), all-gather of 36 B/ray in "
+                               "the timed step" % (W_, H_, S, chunk, counts),
+                   "rays_per_step": n_rays, "parallelism": "one frame ray-sharded x%d + all_gather" % world},
+        "roofline": {"bound": "hbm", "achieved": value * b_all / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": value * b_all / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                     "kernel": "whole path, all ranks", "path_bytes_per_ray": b_all}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,9 +440,11 @@ def main():
         t = torch.tensor([res["ms_per_step"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        info = rccl_info(dist, world, dev)
         if rank == 0:
             ms = float(t.item())
             line = {"metric": "rays/sec (train step: forward + losses + backward + Adam) @ 4096 rays/step", "value": world * 4096 / (ms * 1e-3),
+                    "rccl": info,
                     "unit": "rays/s", "n_gpus": world, "steps": res["steps"], "warmup": max(args.warmup, 1), "ms_per_step": ms,
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                     "config": {"workload": res["what"], "parallelism": "scene replica per rank x%d, no collective" % world},
@@ -376,64 +459,11 @@ def main():
     from thermo_nerf_amd import synthetic
 
     if args.shard == "frame":
-        # BASELINE config 4: one 1920x1080 camera-path frame, ray-sharded on the reference's chunk boundaries
-        from thermo_nerf_amd import distributed as D
-
-        S = args.samples or 48
-        H_, W_ = args.height or 1080, args.width or 1920
-        chunk = args.chunk or REF_CHUNK
-        model, cfg, _, engine = build_render(dev, S, chunk, args)
-        o3, d3, _ = synthetic.orbit_camera_rays(H_, W_, view=3)
-        n_rays = H_ * W_
-        if world > 1:
-            r0, r1 = D.chunk_block(n_rays, chunk, rank, world)
-            counts = [D.chunk_block(n_rays, chunk, r, world)[1] - D.chunk_block(n_rays, chunk, r, world)[0] for r in range(world)]
-        else:
-            r0, r1, counts = 0, n_rays, [n_rays]
-        o = o3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
-        d = d3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
-        out = engine.allocate_outputs(max(r1 - r0, 1), dev)
-        frame = [None]
-
-        def step():
-            if r1 > r0:
-                engine.render(o, d, out=out)
-            local = {k: v[: r1 - r0] for k, v in out.items()}
-            # the frame exists (on every rank) once the gather is done: it is inside the step, not pipelined away
-            frame[0] = D.gather_frame(local, H_, W_, counts=counts) if world > 1 else local
-
-        def sync():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        line = measure_sharded_frame(dev, args, world, rank, dist, args.steps, args.warmup)
+        info = rccl_info(dist, world, dev)
         if rank == 0:
-            _, _, b_all = algorithmic_bytes_per_ray(S)
-            value = n_rays * args.steps / elapsed
-            print(json.dumps({
-                "metric": "rays/sec (forward-only render, ONE frame ray-sharded over the GPUs) @ %dx%d, %d samples/ray" % (W_, H_, S),
-                "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": elapsed / args.steps * 1e3, "frame_latency_ms": elapsed / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "config 4: synthetic %dx%d camera-path frame, P=(256,96)+%d samples/ray, chunk %d, shards = "
-                                       "contiguous runs of whole chunks per rank (rays per rank: %s), all-gather of 36 B/ray in "
-                                       "the timed step" % (W_, H_, S, chunk, counts),
-                           "rays_per_step": n_rays, "parallelism": "one frame ray-sharded x%d + all_gather" % world},
-                "roofline": {"bound": "hbm", "achieved": value * b_all / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                             "frac": value * b_all / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                             "kernel": "whole path, all ranks", "path_bytes_per_ray": b_all}}), flush=True)
+            line["rccl"] = info
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -467,6 +497,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    info = rccl_info(dist, world, dev)
+    strong = None
+    if world > 1 and not args.no_variants:
+        # the same ranks on ONE frame (BASELINE config 4, strong scaling): a driver that runs `bench.py --gpus N` sees both curves
+        saved = (args.height, args.width, args.chunk)
+        args.height = args.width = None
+        args.chunk = 0
+        strong = measure_sharded_frame(dev, args, world, rank, dist, max(3, args.steps // 2), 1, S=48)
+        args.height, args.width, args.chunk = saved
 
     if rank == 0:
         value = world * n_rays * args.steps / elapsed
@@ -484,7 +523,10 @@ def main():
                                        "" if args.early_eps <= 0 else ", early ray termination eps=%g" % args.early_eps),
                        "rays_per_step_per_gpu": n_rays, "parallelism": "ray-shard x%d (one frame per rank)" % world},
             "roofline": roofline_of(S, n_rays, args.steps, prop_ms, main_ms, args.precision, args.no_mfma, value / world),
+            "rccl": info,
         }
+        if strong is not None:
+            line["variants"] = {"strong_frame_1080p_S48": strong}
         if sd_cpu is not None:
             from tests import helpers  # oracle-side plumbing: only imported on the cpu_baseline leg
 

@@ -300,6 +300,15 @@ int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const flo
 /* tn_hash_encode_bwd restricted to the levels [level_begin, level_end) (d_enc keeps all num_levels columns). */
 int tn_hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
                               int64_t n, float *d_table, int32_t level_begin, int32_t level_end, void *stream);
+/* tn_hash_encode_bwd_levels with the COARSE levels (dense vertex grid of at most 48^3: scalings up to 46, the first four
+ * levels of the reference grids) accumulated in 16 private dense copies of their vertex grids and summed into d_table by
+ * a second launch: at those levels the samples of a trained scene hit the same few thousand entries, and same-address atomics
+ * retire one at a time in the memory-side atomic unit.  Same sums (other order).  The workspace is cleared by the call;
+ * levels outside the coarse set, or a call that does not start at level 0, run exactly as tn_hash_encode_bwd_levels. */
+size_t tn_hash_encode_bwd_spread_workspace_bytes(const tn_hashgrid *grid);
+int tn_hash_encode_bwd_spread(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, int32_t level_begin, int32_t level_end, void *workspace,
+                              size_t workspace_bytes, void *stream);
 
 /* The same adjoint without global atomics for the levels [level_begin, num_levels): contributions are written out as records
  * bucketed by the table slice (2^14 entries) that owns them and summed per slice in LDS, then added to d_table (+=) with plain

@@ -147,10 +147,13 @@ def test_hash_encode_fwd_bwd(contraction):
     e, s = TR.hash_encode_fwd(grid, space, pos.to(DEV))
     assert torch.equal(s.cpu(), sel.float())
     assert (e.cpu() - enc.detach()).abs().max().item() <= 1e-6
-    for bucketed in (0, 5, False):  # records bucketed by owning slice + LDS sums | global atomics
+    # records bucketed by owning slice + LDS sums | global atomics; the coarsest levels through private dense copies or not
+    for bucketed, spread in ((0, True), (5, True), (5, False), (False, True), (False, False)):
         d_table = torch.zeros_like(td)
-        TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), d_table, bucketed=bucketed)
-        assert rel(d_table, table.grad) <= 1e-5, bucketed
+        for _ in range(2):  # twice: the spread workspace is cleared by every call
+            d_table.zero_()
+            TR.hash_encode_bwd(grid, space, pos.to(DEV), d_enc.to(DEV), d_table, bucketed=bucketed, spread=spread)
+        assert rel(d_table, table.grad) <= 1e-5, (bucketed, spread)
         # untouched entries stay exactly zero
         assert torch.all(d_table.cpu()[table.grad == 0] == 0)
 

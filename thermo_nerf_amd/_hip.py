@@ -188,6 +188,8 @@ SIGNATURES = {
     "tn_hash_encode_fwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _i64, _vp, _vp, _vp]),
     "tn_hash_encode_bwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),
     "tn_hash_encode_bwd_levels": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "tn_hash_encode_bwd_spread_workspace_bytes": (_sz, [C.POINTER(tn_hashgrid)]),
+    "tn_hash_encode_bwd_spread": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
     "tn_hash_encode_bwd_sorted_workspace_bytes": (_sz, [C.POINTER(tn_hashgrid), _i64, _i32]),
     "tn_hash_encode_bwd_sorted_first_level": (C.c_int, [C.POINTER(tn_hashgrid), _i64]),
     "tn_hash_encode_bwd_sorted": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),

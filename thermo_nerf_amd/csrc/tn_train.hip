@@ -57,9 +57,22 @@ hash_encode_fwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
 // a wave takes 64 CONSECUTIVE samples (neighbours along a ray) at ONE level; samples in the same grid cell form
 // contiguous runs of lanes, a segmented wave scan adds each run's 8 corner contributions, and only the last lane of a
 // run issues the atomics (x3.9 / x1.8 / x1.3 fewer on the 256- / 96- / 48-sample levels of the reference config).
+// Coarse levels, "spread": at a level with a few thousand vertices the samples of a trained scene crowd onto the same entries
+// (level 0 of the field: 4 913 vertices for 196 k samples), and same-address atomics retire one at a time in the memory-side
+// atomic unit (~10 ns each): launched alone, level 0 costs 200 us against 49 for level 15 (tools/scatter_levels.py).  Such
+// levels accumulate into `copies` private DENSE vertex grids instead (copy = block % copies; side^3 vertices of two floats,
+// x fastest, so the x-neighbour pairing below still holds), which spread_reduce_kernel sums and hashes into d_table.
+struct Spread {
+    float *buf;            // [copies][per_copy][2]
+    int levels, copies;    // levels [0, levels) are spread
+    unsigned per_copy;     // vertices of all spread levels
+    unsigned off[TN_MAX_LEVELS];
+    int side[TN_MAX_LEVELS];
+};
+
 __global__ void __launch_bounds__(kBlock)
 hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positions, const float *__restrict__ d_enc,
-                       long long n, float *__restrict__ d_table, int level_begin, int level_end) {
+                       long long n, float *__restrict__ d_table, int level_begin, int level_end, Spread spr) {
     const Space sp = make_space(space);
     const int L = g.num_levels, LS = level_end - level_begin;  // levels [level_begin, level_end) of the L in d_enc
     const int lane = threadIdx.x & 63;
@@ -124,10 +137,18 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
         const unsigned cx = (unsigned)cxi, cy = (unsigned)cyi, cz = (unsigned)czi;
         const unsigned fx = (unsigned)fxi, fy = (unsigned)fyi, fz = (unsigned)fzi;
         const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
-        float *tb = d_table + ((size_t)l * g.tsize) * 2;
+        const bool spread = l < spr.levels;  // wave-uniform
+        float *tb = spread ? spr.buf + ((size_t)(blockIdx.x % spr.copies) * spr.per_copy + spr.off[l]) * 2
+                           : d_table + ((size_t)l * g.tsize) * 2;
         const unsigned m = g.mask;
-        const unsigned idx[8] = {(cx ^ hcy ^ hcz) & m, (cx ^ hfy ^ hcz) & m, (fx ^ hfy ^ hcz) & m, (fx ^ hcy ^ hcz) & m,
-                                 (cx ^ hcy ^ hfz) & m, (cx ^ hfy ^ hfz) & m, (fx ^ hfy ^ hfz) & m, (fx ^ hcy ^ hfz) & m};
+        unsigned idx[8] = {(cx ^ hcy ^ hcz) & m, (cx ^ hfy ^ hcz) & m, (fx ^ hfy ^ hcz) & m, (fx ^ hcy ^ hcz) & m,
+                           (cx ^ hcy ^ hfz) & m, (cx ^ hfy ^ hfz) & m, (fx ^ hfy ^ hfz) & m, (fx ^ hcy ^ hfz) & m};
+        if (spread) {
+            const unsigned sd = (unsigned)spr.side[l];
+            const unsigned ycz = sd * (cy + sd * cz), yfz = sd * (fy + sd * cz), ycf = sd * (cy + sd * fz), yff = sd * (fy + sd * fz);
+            idx[0] = cx + ycz; idx[1] = cx + yfz; idx[2] = fx + yfz; idx[3] = fx + ycz;
+            idx[4] = cx + ycf; idx[5] = cx + yff; idx[6] = fx + yff; idx[7] = fx + ycf;
+        }
         // The memory side retires ~21 G atomic transactions/s on this part, one per 64-byte line an instruction touches,
         // whatever the line carries (tools/micro/atomics.hip: 4, 8, 16 ... 64 contiguous bytes of adds cost the same).  So an
         // instruction should put as much of a line as possible on its lanes: the hash's first prime is 1, hence the two
@@ -151,6 +172,27 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
                 if (st && val != 0.0f) atomic_add_f32(tb + (size_t)id * 2 + feat, val);
             }
         }
+    }
+}
+
+// d_table[l][hash(x, y, z)] += sum over the copies of the spread grid of level l (one thread per vertex)
+__global__ void __launch_bounds__(kBlock) spread_reduce_kernel(Grid g, Spread spr, float *__restrict__ d_table) {
+    for (unsigned v = blockIdx.x * kBlock + threadIdx.x; v < spr.per_copy; v += gridDim.x * kBlock) {
+        int l = 0;
+        while (l + 1 < spr.levels && v >= spr.off[l + 1]) ++l;
+        const float2 *src = reinterpret_cast<const float2 *>(spr.buf) + v;
+        float sx = 0.0f, sy = 0.0f;
+        for (int c = 0; c < spr.copies; ++c) {
+            const float2 t = src[(size_t)c * spr.per_copy];
+            sx += t.x;
+            sy += t.y;
+        }
+        if (sx == 0.0f && sy == 0.0f) continue;
+        const unsigned r = v - spr.off[l], sd = (unsigned)spr.side[l];
+        const unsigned x = r % sd, y = (r / sd) % sd, z = r / (sd * sd);
+        float *dst = d_table + ((size_t)l * g.tsize + ((x ^ (y * TN_P1) ^ (z * TN_P2)) & g.mask)) * 2;
+        if (sx != 0.0f) atomic_add_f32(dst, sx);
+        if (sy != 0.0f) atomic_add_f32(dst + 1, sy);
     }
 }
 
@@ -1713,18 +1755,55 @@ int tn_hash_encode_fwd(const tn_hashgrid *grid, const tn_space *space, const flo
     return TN_OK;
 }
 
+// the spread layout of a grid: the leading levels whose dense vertex grid is small (<= kSpreadMaxSide per axis)
+constexpr int kSpreadCopies = 16, kSpreadMaxSide = 48;
+static Spread spread_layout(const tn_hashgrid &h, int level_begin, int level_end) {
+    Spread s{};
+    s.copies = kSpreadCopies;
+    if (level_begin != 0) return s;  // only when the call starts at the coarsest level
+    unsigned off = 0;
+    for (int l = 0; l < level_end && l < TN_MAX_LEVELS; ++l) {
+        const int side = (int)h.scalings[l] + 2;  // coordinates 0 .. ceil(scaling)
+        if (side > kSpreadMaxSide) break;
+        s.off[l] = off;
+        s.side[l] = side;
+        off += (unsigned)side * side * side;
+        s.levels = l + 1;
+    }
+    s.per_copy = off;
+    return s;
+}
+
 static int hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
-                                  int64_t n, float *d_table, int level_begin, int level_end, void *stream) {
+                                  int64_t n, float *d_table, int level_begin, int level_end, void *stream, void *spread_ws = nullptr,
+                                  size_t spread_bytes = 0) {
     if (!grid || !space) return TN_ERR_NULL;
     TN_TRY(tn_check_grid(*grid));
     if (level_begin < 0 || level_end > grid->num_levels || level_begin > level_end) return TN_ERR_SHAPE;
     if (n == 0 || level_begin == level_end) return TN_OK;
     if (!positions || !d_enc || !d_table) return TN_ERR_NULL;
     if (n < 0) return TN_ERR_SHAPE;
+    Spread spr{};
+    spr.copies = 1;
+    if (spread_ws) {
+        spr = spread_layout(*grid, level_begin, level_end);
+        const size_t need = (size_t)spr.copies * spr.per_copy * 2 * sizeof(float);
+        if (spr.levels > 0 && spread_bytes < need) return TN_ERR_WORKSPACE;
+        if (spr.levels > 0) {
+            spr.buf = reinterpret_cast<float *>(spread_ws);
+            if (hipMemsetAsync(spread_ws, 0, need, (hipStream_t)stream) != hipSuccess) return TN_ERR_LAUNCH;
+        }
+    }
+    const Grid g = tn_make_grid(*grid);
     hipLaunchKernelGGL(hash_encode_bwd_kernel, dim3(grid_for(((n + 63) / 64) * (level_end - level_begin), kBlock / 64, 1 << 16)),
-                       dim3(kBlock), 0, (hipStream_t)stream, tn_make_grid(*grid), *space, positions, d_enc, (long long)n, d_table,
-                       level_begin, level_end);
+                       dim3(kBlock), 0, (hipStream_t)stream, g, *space, positions, d_enc, (long long)n, d_table, level_begin,
+                       level_end, spr);
     TN_LAUNCH_CHECK();
+    if (spr.levels > 0) {
+        hipLaunchKernelGGL(spread_reduce_kernel, dim3(grid_for(spr.per_copy, kBlock, 1024)), dim3(kBlock), 0, (hipStream_t)stream, g,
+                           spr, d_table);
+        TN_LAUNCH_CHECK();
+    }
     return TN_OK;
 }
 
@@ -1737,6 +1816,19 @@ int tn_hash_encode_bwd(const tn_hashgrid *grid, const tn_space *space, const flo
 int tn_hash_encode_bwd_levels(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
                               int64_t n, float *d_table, int32_t level_begin, int32_t level_end, void *stream) {
     return hash_encode_bwd_levels(grid, space, positions, d_enc, n, d_table, level_begin, level_end, stream);
+}
+
+size_t tn_hash_encode_bwd_spread_workspace_bytes(const tn_hashgrid *grid) {
+    if (!grid || tn_check_grid(*grid) != TN_OK) return 0;
+    const Spread s = spread_layout(*grid, 0, grid->num_levels);
+    return (size_t)s.copies * s.per_copy * 2 * sizeof(float);
+}
+
+int tn_hash_encode_bwd_spread(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, int32_t level_begin, int32_t level_end, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    return hash_encode_bwd_levels(grid, space, positions, d_enc, n, d_table, level_begin, level_end, stream, workspace,
+                                  workspace_bytes);
 }
 
 size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n, int32_t level_begin) {

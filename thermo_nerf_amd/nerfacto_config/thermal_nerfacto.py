@@ -109,6 +109,11 @@ class NerfactoModelConfig:
     """Training: hash-table gradient of the field's fine levels (scaling >= 256) as bucketed records + LDS sums instead of
     global atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,
     2.24 against 2.27 at S=48 (DESIGN §5.6)."""
+    spread_coarse_scatter: bool = True
+    """Training: the coarsest levels of the table-gradient scatter (dense vertex grid <= 48^3: the first four levels of the
+    reference grids) accumulate into 16 private dense copies that a second launch sums and hashes into the gradient
+    (tn_hash_encode_bwd_spread): same-address atomics retire one at a time, and at those levels a trained scene's samples
+    share a few thousand entries (DESIGN §5.6)."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""

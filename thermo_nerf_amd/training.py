@@ -48,15 +48,33 @@ def hash_encode_fwd(grid, space, pos: Tensor) -> Tuple[Tensor, Tensor]:
     return enc, sel
 
 
-def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False) -> None:
+_SPREAD_WS: Dict = {}
+
+
+def _atomic_levels(lib, grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, lo: int, hi: int, spread: bool) -> None:
+    """levels [lo, hi) with global atomics; ``spread``: the coarsest levels through private dense copies (tn_hash_encode_bwd_spread)"""
+    n = pos.shape[0]
+    args = (grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), lo, hi)
+    need = lib.tn_hash_encode_bwd_spread_workspace_bytes(grid) if spread and lo == 0 else 0
+    if need:
+        key = (pos.device, need)
+        ws = _SPREAD_WS.get(key)
+        if ws is None:
+            ws = _SPREAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=pos.device)
+        _hip.check(lib.tn_hash_encode_bwd_spread(*args, ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_spread")
+    else:
+        _hip.check(lib.tn_hash_encode_bwd_levels(*args, _stream()), "tn_hash_encode_bwd_levels")
+
+
+def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True) -> None:
     """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
     ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 256, enough table slices: the
     field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
     summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 25 B of scratch per (sample, level, corner pair)), the
-    coarser levels keep the atomics.  An int (tests): bucketed from that level on, whatever the library advises."""
+    coarser levels keep the atomics.  An int (tests): bucketed from that level on, whatever the library advises.
+    ``spread`` (config.spread_coarse_scatter): the coarsest levels of the atomic part accumulate in private dense copies."""
     lib = _hip.load()
     n = pos.shape[0]
-    args = (grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr())
     first = -1
     if bucketed is True:
         first = lib.tn_hash_encode_bwd_sorted_first_level(grid, n)
@@ -64,12 +82,13 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
         first = int(bucketed)
     need = lib.tn_hash_encode_bwd_sorted_workspace_bytes(grid, n, first) if first >= 0 else 0
     if not need:
-        _hip.check(lib.tn_hash_encode_bwd(*args, _stream()), "tn_hash_encode_bwd")
+        _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, grid.num_levels, spread)
         return
     if first > 0:
-        _hip.check(lib.tn_hash_encode_bwd_levels(*args, 0, first, _stream()), "tn_hash_encode_bwd_levels")
+        _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
     ws = torch.empty(need, dtype=torch.uint8, device=pos.device)
-    _hip.check(lib.tn_hash_encode_bwd_sorted(*args, first, ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
+    _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first, ws.data_ptr(),
+                                             need, _stream()), "tn_hash_encode_bwd_sorted")
 
 
 def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor:
@@ -250,7 +269,7 @@ def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, 
 
 def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict,
                         ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True, bucketed: bool = False,
-                        exp_min: float = -15.0) -> None:
+                        exp_min: float = -15.0, spread: bool = True) -> None:
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
@@ -274,7 +293,7 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
         g_hid = _f32((n, H), g_w.device)
         linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
         linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
-    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed)
+    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed, spread)
     if ray_grads is not None:
         _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads)
 
@@ -498,6 +517,7 @@ class RenderTrain(torch.autograd.Function):
         W = 64
         chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
         bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
+        spread = bool(getattr(cfg, "spread_coarse_scatter", True))
         E = f.enc.shape[1]
         g_enc = _f32((N, E), dev)  # row-major [N,32] in both forms (what the table scatter reads)
         if ctx.tape_free:
@@ -533,7 +553,7 @@ class RenderTrain(torch.autograd.Function):
                 if sh_grads:  # ... and on through the SH basis to the directions (camera-pose optimisation, differentiable-SH switch)
                     _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, 1, None, 0, None,
                                                       ctx.d.data_ptr(), ray_grads[1].data_ptr(), _stream()), "tn_color_input_bwd")
-            hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
+            hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread)
             if ray_grads:
                 _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
             return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
@@ -579,7 +599,7 @@ class RenderTrain(torch.autograd.Function):
             g_h1 = _f32((N, W), dev)
             linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
             linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
-        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed)
+        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread)
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
         return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
@@ -595,7 +615,7 @@ class RenderTrain(torch.autograd.Function):
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
                 net = model.proposal_networks[which].c_struct(dense=False)
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
-                                    ray_grads, chained, bucketed, exp_min)
+                                    ray_grads, chained, bucketed, exp_min, bool(getattr(model.config, "spread_coarse_scatter", True)))
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
         result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)

@@ -1,5 +1,7 @@
-"""Time the training step (taped forward + losses + backward + Adam) on the GPU.
-usage: python tools/train_bench.py [--rays 4096] [--samples 48] [--steps 20] [--small]"""
+"""Time the training step (forward + losses + backward + Adam) on the GPU.
+usage: python tools/train_bench.py [--rays 4096] [--samples 48] [--steps 20 | --seconds 20] [--taped]
+--seconds T: run consecutive steps for T seconds (BASELINE config 3 is 30 000 consecutive steps: the sustained figure is the
+honest one), report the mean over the first and the second half and the GPU's sclk / power (rocm-smi) before and after."""
 import argparse
 import os
 import sys
@@ -19,6 +21,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--weights", default="scene")
+    ap.add_argument("--seconds", type=float, default=0.0, help="sustained run: consecutive steps for this long (overrides --steps)")
+    ap.add_argument("--taped", action="store_true", help="config.tape_free_training = False (the round-2 taped forward + chained backward)")
+    ap.add_argument("--one-launch", action="store_true", help="config.fused_backward_split = False")
+    ap.add_argument("--no-spread", action="store_true", help="config.spread_coarse_scatter = False")
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
@@ -27,7 +33,8 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt,
-                                 bucketed_table_scatter=not a.atomic_scatter)
+                                 bucketed_table_scatter=not a.atomic_scatter, tape_free_training=not a.taped,
+                                 fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
@@ -56,9 +63,42 @@ def main():
             opt.step()
         return loss
 
+    def smi():
+        """sclk (MHz) and socket power (W) as rocm-smi reports them; None when the tool is not there"""
+        import json
+        import subprocess
+
+        try:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+            card = next(iter(json.loads(r.stdout).values()))
+            sclk = next((v for k, v in card.items() if "sclk" in k.lower()), None)
+            power = next((v for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+            return f"sclk {sclk}, power {power} W"
+        except Exception as e:  # pragma: no cover - informational
+            return f"rocm-smi unavailable ({type(e).__name__})"
+
     for i in range(a.warmup):
         step(a.start_step + i)
     torch.cuda.synchronize()
+    if a.seconds > 0:
+        print("before:", smi(), flush=True)
+        marks, i, t0 = [], 0, time.perf_counter()
+        while True:
+            for _ in range(100):
+                step(a.start_step + a.warmup + i)
+                i += 1
+            torch.cuda.synchronize()
+            marks.append((i, time.perf_counter() - t0))
+            if marks[-1][1] >= a.seconds:
+                break
+        print("after: ", smi(), flush=True)
+        half = next(k for k, m in enumerate(marks) if m[1] >= marks[-1][1] / 2)
+        n1, t1 = marks[half]
+        n2, t2 = marks[-1]
+        first, second = t1 / n1, (t2 - t1) / max(n2 - n1, 1)
+        print(f"rays {R} S {a.samples}: sustained {n2} consecutive steps in {t2:.1f} s: first half {first * 1e3:.3f} ms/step, "
+              f"second half {second * 1e3:.3f} ms/step ({R / second / 1e6:.3f} M rays/s)")
+        return
     t = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.start_step + a.warmup + i)
