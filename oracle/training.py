@@ -139,9 +139,36 @@ def exp_map_SO3xR3(tangent_vector: Tensor) -> Tensor:
     return ret
 
 
-def apply_pose_adjustment(pose_adjustment: Tensor, camera_indices: Tensor, origins: Tensor, directions: Tensor):
-    """NS CameraOptimizer.forward (mode "SO3xR3": gather the rays' rows, exponentiate) + apply_to_raybundle."""
-    m = exp_map_SO3xR3(pose_adjustment[camera_indices.reshape(-1).long(), :])
+def exp_map_SE3(tangent_vector: Tensor) -> Tensor:
+    """NS cameras/lie_groups.exp_map_SE3: [N,6] = (translation part u, log-rotation w) -> [N,3,4] = [R(w) | V(w) u] with
+    theta^2 clamped at 1e-4 as in exp_map_SO3xR3; V = I + fac2 K + fac3 K^2, fac3 = (theta - sin theta) / theta^3."""
+    log_rot = tangent_vector[:, 3:]
+    nrms = (log_rot * log_rot).sum(1)
+    rot_angles = torch.clamp(nrms, 1e-4).sqrt()
+    rot_angles_inv = 1.0 / rot_angles
+    fac1 = rot_angles_inv * rot_angles.sin()
+    fac2 = rot_angles_inv * rot_angles_inv * (1.0 - rot_angles.cos())
+    fac3 = rot_angles_inv * rot_angles_inv * rot_angles_inv * (rot_angles - rot_angles.sin())
+    skews = torch.zeros((log_rot.shape[0], 3, 3), dtype=log_rot.dtype)
+    skews[:, 0, 1] = -log_rot[:, 2]
+    skews[:, 0, 2] = log_rot[:, 1]
+    skews[:, 1, 0] = log_rot[:, 2]
+    skews[:, 1, 2] = -log_rot[:, 0]
+    skews[:, 2, 0] = -log_rot[:, 1]
+    skews[:, 2, 1] = log_rot[:, 0]
+    skews_square = torch.bmm(skews, skews)
+    eye = torch.eye(3, dtype=log_rot.dtype)[None]
+    ret = torch.zeros(tangent_vector.shape[0], 3, 4, dtype=tangent_vector.dtype)
+    ret[:, :3, :3] = fac1[:, None, None] * skews + fac2[:, None, None] * skews_square + eye
+    v = fac2[:, None, None] * skews + fac3[:, None, None] * skews_square + eye
+    ret[:, :3, 3] = torch.bmm(v, tangent_vector[:, :3, None])[:, :, 0]
+    return ret
+
+
+def apply_pose_adjustment(pose_adjustment: Tensor, camera_indices: Tensor, origins: Tensor, directions: Tensor, mode: str = "SO3xR3"):
+    """NS CameraOptimizer.forward (gather the rays' rows, exponentiate: mode "SO3xR3" or "SE3") + apply_to_raybundle."""
+    exp = exp_map_SE3 if mode == "SE3" else exp_map_SO3xR3
+    m = exp(pose_adjustment[camera_indices.reshape(-1).long(), :])
     return origins + m[:, :3, 3], torch.bmm(m[:, :3, :3], directions[..., None]).squeeze(-1)
 
 

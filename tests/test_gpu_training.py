@@ -729,11 +729,13 @@ def test_camera_opt_apply_and_its_adjoint(n, cams, scale):
     assert (m - T.exp_map_SO3xR3(pose[cam.reshape(-1)])).abs().max().item() <= 1e-6
 
 
-def test_camera_optimizer_receives_the_pose_gradient():
-    """Reference default camera_optimizer_mode="SO3xR3" [REF nerfacto_config/thermal_nerfacto.py:24]: pose_adjustment gets
-    its gradient through apply_to_raybundle (torch) from the HIP ray gradients."""
-    cm, sd, ocfg = helpers.build("stress", 48)
-    assert cm.config.camera_optimizer.mode == "SO3xR3"
+@pytest.mark.parametrize("mode", ["SO3xR3", "SE3"])
+def test_camera_optimizer_receives_the_pose_gradient(mode):
+    """camera_optimizer_mode [REF nerfacto_config/thermal_nerfacto.py:24: "off" | "SO3xR3" (the default) | "SE3"]:
+    pose_adjustment gets its gradient through apply_to_raybundle from the HIP ray gradients (SE3: exp_map_SE3's translation
+    V(w) u on the camera table, then the same per-ray kernels)."""
+    cm, sd, ocfg = helpers.build("stress", 48, camera_optimizer_mode=mode)
+    assert cm.config.camera_optimizer.mode == mode
     gm = copy.deepcopy(cm).to(DEV).train()
     o, d = helpers.rays(12, 12, view=3)
     R = o.shape[0]
@@ -741,6 +743,8 @@ def test_camera_optimizer_receives_the_pose_gradient():
     cam = torch.randint(0, 8, (R, 1), generator=g)
     batch = {"image": torch.rand(R, 3, generator=g), "thermal": torch.rand(R, 1, generator=g)}
     pose = 0.02 * torch.randn(8, 6, generator=g)
+    pose[3, 3:] *= 30.0  # one camera with a large rotation: the closed forms, not their small-angle limits
+    pose[5, 3:] = 0.0    # and one inside the theta^2 clamp
     with torch.no_grad():
         gm.camera_optimizer.pose_adjustment.copy_(pose)
     jit = [torch.rand(R, 1, generator=g) for _ in range(3)]
@@ -757,12 +761,16 @@ def test_camera_optimizer_receives_the_pose_gradient():
 
     # expected: the same chain on the CPU — the oracle's camera optimizer in front of the autograd oracle
     pose_cpu = pose.clone().requires_grad_(True)
-    o_adj, d_adj = T.apply_pose_adjustment(pose_cpu, cam, o, d)
+    o_adj, d_adj = T.apply_pose_adjustment(pose_cpu, cam, o, d, mode=mode)
     assert (rb.origins.detach().cpu() - o_adj.detach()).abs().max().item() <= 1e-6
     assert (rb.directions.detach().cpu() - d_adj.detach()).abs().max().item() <= 1e-6
     _, _, want = T.loss_and_grads(sd, o_adj.detach(), d_adj.detach(), cam, batch, ocfg, jit)
     ((o_adj * want["__origins__"]).sum() + (d_adj * want["__directions__"]).sum()).backward()
     assert rel(got, pose_cpu.grad) <= 2e-2, rel(got, pose_cpu.grad)
+    # CameraOptimizer.forward: the [N,3,4] correction matrices of the mode
+    idx = torch.tensor([3, 5, 0])
+    want_m = (T.exp_map_SE3 if mode == "SE3" else T.exp_map_SO3xR3)(pose[idx])
+    assert (gm.camera_optimizer(idx.to(DEV)).detach().cpu() - want_m).abs().max().item() <= 1e-6
     # used cameras only
     used = torch.zeros(8, dtype=torch.bool)
     used[cam.reshape(-1)] = True

@@ -26,3 +26,30 @@ def test_exponential_decay_schedule():
     assert math.isclose(exponential_decay_multiplier(w, 50) * 1e-2, 1e-8 + (1e-2 - 1e-8) * math.sin(math.pi / 4), rel_tol=1e-12)
     assert math.isclose(exponential_decay_multiplier(w, 100), 1.0, rel_tol=1e-12)
     assert math.isclose(exponential_decay_multiplier(w, 900), 1.0, rel_tol=1e-12)  # lr_final None: constant
+
+
+def test_exp_map_se3_is_the_matrix_exponential_of_the_twist():
+    """oracle.training.exp_map_SE3 (restating nerfstudio's lie_groups.exp_map_SE3) and the product's SE3 table transform against
+    an independent computation: exp of the 4x4 twist matrix [[K(w), u], [0, 0]] = [[R(w), V(w) u], [0, 1]] (outside the
+    theta^2 >= 1e-4 clamp, where the closed forms are exact)."""
+    import torch
+
+    from oracle import training as T
+    from thermo_nerf_amd.camera_optimizer import _se3_exp, _so3xr3_exp
+
+    g = torch.Generator().manual_seed(4)
+    tangent = torch.randn(64, 6, generator=g, dtype=torch.float64) * torch.tensor([0.3, 0.3, 0.3, 1.2, 1.2, 1.2], dtype=torch.float64)
+    tangent = tangent[(tangent[:, 3:] ** 2).sum(1) >= 1e-3]
+    u, w = tangent[:, :3], tangent[:, 3:]
+    twist = torch.zeros(tangent.shape[0], 4, 4, dtype=torch.float64)
+    twist[:, 0, 1], twist[:, 0, 2] = -w[:, 2], w[:, 1]
+    twist[:, 1, 0], twist[:, 1, 2] = w[:, 2], -w[:, 0]
+    twist[:, 2, 0], twist[:, 2, 1] = -w[:, 1], w[:, 0]
+    twist[:, :3, 3] = u
+    want = torch.linalg.matrix_exp(twist)[:, :3, :4]
+    assert (T.exp_map_SE3(tangent) - want).abs().max().item() <= 1e-12
+    assert (_se3_exp(tangent) - want).abs().max().item() <= 1e-12
+    # SO3xR3: the same rotation, the translation taken as is
+    so3 = T.exp_map_SO3xR3(tangent)
+    assert (so3[:, :, :3] - want[:, :, :3]).abs().max().item() <= 1e-12 and torch.equal(so3[:, :, 3], u)
+    assert (_so3xr3_exp(tangent) - so3).abs().max().item() <= 1e-12

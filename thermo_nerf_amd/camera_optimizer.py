@@ -37,6 +37,22 @@ def _so3xr3_exp(tangent: Tensor) -> Tensor:
     return torch.cat([rot, t[:, :, None]], dim=2)
 
 
+def _se3_translation(tangent: Tensor) -> Tensor:
+    """NS cameras/lie_groups.exp_map_SE3: the translation of exp([u | w]) is V(w) u, V = I + b K + c K^2 with
+    b = (1 - cos t) / t^2, c = (t - sin t) / t^3, t^2 = max(|w|^2, 1e-4) — written with cross products (K u = w x u).
+    Returns the [N,6] table [V(w) u | w]: the SO3xR3 form of the same rigid motions, which the HIP kernel applies per ray."""
+    u, w = tangent[:, :3], tangent[:, 3:]
+    theta = torch.clamp((w * w).sum(dim=1), min=1e-4).sqrt()
+    b = ((1.0 - torch.cos(theta)) / (theta * theta))[:, None]
+    c = ((theta - torch.sin(theta)) / (theta * theta * theta))[:, None]
+    wu = torch.cross(w, u, dim=1)
+    return torch.cat([u + b * wu + c * torch.cross(w, wu, dim=1), w], dim=1)
+
+
+def _se3_exp(tangent: Tensor) -> Tensor:
+    return _so3xr3_exp(_se3_translation(tangent))
+
+
 class _ApplyPoseAdjustment(torch.autograd.Function):
     """origins + t_c, R(w_c) directions with c = the ray's camera (NS exp_map_SO3xR3 + apply_to_raybundle) on the device."""
 
@@ -76,8 +92,8 @@ class CameraOptimizer(nn.Module):
         super().__init__()
         self.config = config
         self.num_cameras = num_cameras
-        if config.mode == "SE3":
-            raise NotImplementedError('camera_optimizer_mode "SE3" is not implemented (reference recommends SO3xR3)')
+        if config.mode not in ("off", "SO3xR3", "SE3"):
+            raise ValueError(f"unknown camera optimizer mode {config.mode!r}")
         if config.mode != "off":
             self.pose_adjustment = nn.Parameter(torch.zeros((num_cameras, 6), device=device))
 
@@ -87,7 +103,8 @@ class CameraOptimizer(nn.Module):
             return eye.repeat(indices.shape[0], 1, 1)
         # exponentiate once per CAMERA, then gather per ray (index_select: its backward is an index_add, not the
         # serial indexing_backward kernel of advanced indexing)
-        return _so3xr3_exp(self.pose_adjustment).index_select(0, indices)
+        exp = _se3_exp if self.config.mode == "SE3" else _so3xr3_exp
+        return exp(self.pose_adjustment).index_select(0, indices)
 
     def apply_to_raybundle(self, raybundle: RayBundle) -> None:
         if self.config.mode == "off":
@@ -95,5 +112,7 @@ class CameraOptimizer(nn.Module):
         cam = raybundle.camera_indices.reshape(-1)
         if cam.dtype != torch.int64:
             cam = cam.long()
-        raybundle.origins, raybundle.directions = _ApplyPoseAdjustment.apply(self.pose_adjustment, cam, raybundle.origins,
-                                                                             raybundle.directions)
+        # SE3 (REF nerfacto_config/thermal_nerfacto.py:24 lists it): the same rotation, translation V(w) u — a dozen torch ops on
+        # the [num_cameras, 6] table (autograd carries d(V u) back to u and w), then the SO3xR3 kernels per ray
+        pose = _se3_translation(self.pose_adjustment) if self.config.mode == "SE3" else self.pose_adjustment
+        raybundle.origins, raybundle.directions = _ApplyPoseAdjustment.apply(pose, cam, raybundle.origins, raybundle.directions)

@@ -65,7 +65,10 @@ class TrainerConfig:
     steps_per_save: int = 2000
     train_num_rays_per_batch: int = 4096
     optimizers: Dict[str, OptimizerConfig] = field(default_factory=default_optimizers)
-    mixed_precision: bool = False  # the reference asks for fp16 autocast; this path computes in fp32
+    mixed_precision: bool = False
+    """REF config_thermal_nerf.py:22 sets True (fp16 autocast + GradScaler in nerfstudio's Trainer, which force-disables it on
+    CPU).  This path computes in fp32 throughout — the parity target is the fp32 torch path (SURVEY §8f row 2) — so True is
+    accepted for config compatibility, changes nothing, and says so once (a warning) instead of silently."""
     seed: int = 0
 
 
@@ -104,6 +107,11 @@ class Trainer:
     def __init__(self, model, dataset: RayDataset, config: Optional[TrainerConfig] = None) -> None:
         self.model, self.dataset = model, dataset
         self.config = config or TrainerConfig()
+        if self.config.mixed_precision:
+            import warnings
+
+            warnings.warn("TrainerConfig.mixed_precision=True is accepted but not applied: the HIP training step computes in fp32 "
+                          "(the reference's fp32 torch path is the parity target; INTEGRATION.md 4b)", stacklevel=2)
         self.step = 0
         self.optimizers: Dict[str, torch.optim.Optimizer] = {}
         self.schedulers: Dict[str, torch.optim.lr_scheduler.LambdaLR] = {}
