@@ -475,6 +475,19 @@ int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const 
                        int32_t training, int64_t num_rays, int32_t n, float *d_geo, int32_t ld_d_geo,
                        float *d_appearance, const float *directions, float *d_directions, void *stream);
 
+/* The final level's per-ray renderers of a training step in one launch, and their adjoints in one launch: weights =
+ * RaySamples.get_weights(density) [REF thermal_nerf_model.py:233] [R,n], rgb [R,3] / thermal [R] = "last_sample" compositing
+ * [REF :237, :271-273; thermal_renderer.py:55-79], accumulation [R] (what tn_weights_fwd + 2 x tn_composite_fwd compute).
+ * Backward: d_rgb [R,3], d_thermal [R], d_accumulation [R], d_weights [R,n] (the regularisers' gradient) — each may be NULL
+ * — to d_rgb_samples [R n,3], d_thermal_samples [R n], d_densities [R n] (=); starts / ends [R n] non-NULL apply
+ * scale_gradients_by_distance_squared [REF :228-231] to the three.  n <= 1024. */
+int tn_ray_render_fwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
+                      int64_t num_rays, int32_t n, float *weights, float *rgb, float *thermal, float *accumulation, void *stream);
+int tn_ray_render_bwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
+                      const float *accumulation, const float *d_rgb, const float *d_thermal, const float *d_accumulation,
+                      const float *d_weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
+                      float *d_rgb_samples, float *d_thermal_samples, float *d_densities, void *stream);
+
 /* The two image losses of get_loss_dict [REF thermal_nerf_model.py:294-295, 319-323: MSELoss means] and the PSNR of NS
  * get_metrics_dict in one launch: rgb / gt_rgb [R,3], thermal / gt_thermal [R] (thermal may be NULL) -> out[0] = rgb MSE,
  * out[1] = thermal MSE, out[2] = 10 log10(1 / out[0]); d_rgb [R,3] (=) and d_thermal [R] (=) = the gradients of the two means. */

@@ -215,6 +215,8 @@ SIGNATURES = {
     "tn_color_input_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "tn_hash_encode_bwd_input": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),
     "tn_frustum_positions_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "tn_ray_render_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "tn_ray_render_bwd": (C.c_int, [_vp] * 11 + [_i64, _i32, _vp, _vp, _vp, _vp]),
     "tn_image_losses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),

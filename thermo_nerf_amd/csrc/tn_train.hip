@@ -1413,6 +1413,125 @@ weights_bwd_kernel(const float *__restrict__ deltas, const float *__restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The final level's per-ray renderers of a training step and their adjoints, one launch each way (round 3: they were
+// tn_weights_fwd + 2 x tn_composite_fwd, and g_w clone / += + 2 x tn_composite_bwd + tn_weights_bwd + tn_gradient_scale_bwd).
+// One wave per ray.  forward: w = get_weights(deltas, density) [REF thermal_nerf_model.py:233], rgb / thermal = sum w v + v_last
+// (1 - sum w) [REF :237, :271-273; thermal_renderer.py:55-79 with "last_sample"], accumulation = sum w.
+// backward: d_w[i] = d_w_ext[i] + d_acc + sum_c d_rgb[c] (rgb_i[c] - rgb_last[c]) + d_th (th_i - th_last);
+//           d_rgb_s[i] = d_rgb (w_i + [i = last] (1 - acc)), likewise thermal;  d_density = adjoint of get_weights applied to d_w;
+//           optional scale_gradients_by_distance_squared [REF :228-231] on the three per-sample gradients.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+ray_render_fwd_kernel(const float *__restrict__ deltas, const float *__restrict__ dens, const float *__restrict__ rgb_s,
+                      const float *__restrict__ th_s, long long R, int n, float *__restrict__ weights, float *__restrict__ rgb,
+                      float *__restrict__ thermal, float *__restrict__ acc) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float *dl = deltas + ray * n, *dn = dens + ray * n;
+    float carry = 0.0f, sw = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, st = 0.0f;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool live = i < n;
+        const float a = live ? mul_rn(dl[i], dn[i]) : 0.0f;
+        const float incl = wave_incl_scan(a, lane);
+        const float excl = wave_excl_from_incl(incl, lane) + carry;
+        carry += __shfl(incl, 63, 64);
+        const float w = live ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-a)), expf(-excl))) : 0.0f;
+        if (live) {
+            const long long t = ray * n + i;
+            weights[t] = w;
+            sw += w;
+            s0 += mul_rn(w, rgb_s[t * 3]);
+            s1 += mul_rn(w, rgb_s[t * 3 + 1]);
+            s2 += mul_rn(w, rgb_s[t * 3 + 2]);
+            st += mul_rn(w, th_s[t]);
+        }
+    }
+    sw = wave_sum(sw); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); st = wave_sum(st);
+    if (lane == 0) {
+        const long long last = ray * n + n - 1;
+        const float bg = sub_rn(1.0f, sw);
+        rgb[ray * 3] = add_rn(s0, mul_rn(rgb_s[last * 3], bg));
+        rgb[ray * 3 + 1] = add_rn(s1, mul_rn(rgb_s[last * 3 + 1], bg));
+        rgb[ray * 3 + 2] = add_rn(s2, mul_rn(rgb_s[last * 3 + 2], bg));
+        thermal[ray] = add_rn(st, mul_rn(th_s[last], bg));
+        acc[ray] = sw;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+ray_render_bwd_kernel(const float *__restrict__ deltas, const float *__restrict__ dens, const float *__restrict__ rgb_s,
+                      const float *__restrict__ th_s, const float *__restrict__ acc, const float *__restrict__ g_rgb,
+                      const float *__restrict__ g_th, const float *__restrict__ g_acc, const float *__restrict__ g_w_ext,
+                      const float *__restrict__ starts, const float *__restrict__ ends, long long R, int n,
+                      float *__restrict__ d_rgb_s, float *__restrict__ d_th_s, float *__restrict__ d_dens) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float *dl = deltas + ray * n, *dn = dens + ray * n;
+    const long long last = ray * n + n - 1;
+    const float gr0 = g_rgb ? g_rgb[ray * 3] : 0.0f, gr1 = g_rgb ? g_rgb[ray * 3 + 1] : 0.0f, gr2 = g_rgb ? g_rgb[ray * 3 + 2] : 0.0f;
+    const float gt = g_th ? g_th[ray] : 0.0f, ga = g_acc ? g_acc[ray] : 0.0f;
+    const float l0 = g_rgb ? rgb_s[last * 3] : 0.0f, l1 = g_rgb ? rgb_s[last * 3 + 1] : 0.0f, l2 = g_rgb ? rgb_s[last * 3 + 2] : 0.0f;
+    const float lt = g_th ? th_s[last] : 0.0f;
+    const float bg = 1.0f - acc[ray];
+    const int chunks = (n + 63) / 64;
+    float csum[kMaxChunks];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; ++c) {
+        csum[c] = 0.0f;
+        if (c < chunks) {
+            const int i = c * 64 + lane;
+            csum[c] = wave_sum(i < n ? mul_rn(dl[i], dn[i]) : 0.0f);
+        }
+    }
+    float suffix = 0.0f;  // sum of d_w_i w_i over the chunks behind this one
+#pragma unroll
+    for (int c = kMaxChunks - 1; c >= 0; --c) {
+        if (c >= chunks) continue;
+        float before = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kMaxChunks; ++q)
+            if (q < c) before += csum[q];
+        const int i = c * 64 + lane;
+        const bool live = i < n;
+        const long long t = ray * n + (live ? i : n - 1);
+        const float a = live ? mul_rn(dl[i], dn[i]) : 0.0f;
+        const float incl = wave_incl_scan(a, lane);
+        const float excl = wave_excl_from_incl(incl, lane) + before;
+        const float T = expf(-excl), ea = expf(-a);
+        const float w = (1.0f - ea) * T;
+        float scale = 1.0f;
+        if (starts) {
+            const float dist = (starts[t] + ends[t]) / 2.0f;
+            scale = fminf(fmaxf(dist * dist, 0.0f), 1.0f);
+        }
+        float dwi = (g_w_ext ? g_w_ext[t] : 0.0f) + ga;
+        const float wv = w + (i == n - 1 ? bg : 0.0f);
+        if (g_rgb) {
+            const float v0 = rgb_s[t * 3], v1 = rgb_s[t * 3 + 1], v2 = rgb_s[t * 3 + 2];
+            dwi += gr0 * (v0 - l0) + gr1 * (v1 - l1) + gr2 * (v2 - l2);
+            if (live) {
+                d_rgb_s[t * 3] = gr0 * wv * scale;
+                d_rgb_s[t * 3 + 1] = gr1 * wv * scale;
+                d_rgb_s[t * 3 + 2] = gr2 * wv * scale;
+            }
+        }
+        if (g_th) {
+            dwi += gt * (th_s[t] - lt);
+            if (live) d_th_s[t] = gt * wv * scale;
+        }
+        const float gi = live ? dwi : 0.0f;
+        const float gwv = live ? gi * w : 0.0f;
+        const float rincl = wave_incl_scan_rev(gwv, lane);
+        const float behind = rincl - gwv + suffix;  // sum_{k > i}
+        if (live) d_dens[t] = dl[i] * (gi * ea * T - behind) * scale;
+        suffix += __shfl(rincl, 0, 64);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // compositing backward (training mode):  out_c = sum_i w_i v_ic + v_last,c (1 - acc)
 // ------------------------------------------------------------------------------------------------------
 template <int C>
@@ -2244,5 +2363,34 @@ int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal,
     return TN_OK;
 }
 
+int tn_ray_render_fwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
+                      int64_t num_rays, int32_t n, float *weights, float *rgb, float *thermal, float *accumulation, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!deltas || !densities || !rgb_samples || !thermal_samples || !weights || !rgb || !thermal || !accumulation) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(ray_render_fwd_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, deltas,
+                       densities, rgb_samples, thermal_samples, (long long)num_rays, n, weights, rgb, thermal, accumulation);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_ray_render_bwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
+                      const float *accumulation, const float *d_rgb, const float *d_thermal, const float *d_accumulation,
+                      const float *d_weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
+                      float *d_rgb_samples, float *d_thermal_samples, float *d_densities, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!deltas || !densities || !accumulation || !d_densities) return TN_ERR_NULL;
+    if (d_rgb && (!rgb_samples || !d_rgb_samples)) return TN_ERR_NULL;
+    if (d_thermal && (!thermal_samples || !d_thermal_samples)) return TN_ERR_NULL;
+    if ((starts == nullptr) != (ends == nullptr)) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1 || n > 64 * kMaxChunks) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(ray_render_bwd_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, deltas,
+                       densities, rgb_samples, thermal_samples, accumulation, d_rgb, d_thermal, d_accumulation, d_weights, starts,
+                       ends, (long long)num_rays, n, d_rgb_samples, d_thermal_samples, d_densities);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 }  // extern "C"
+
 

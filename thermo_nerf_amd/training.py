@@ -430,17 +430,16 @@ class RenderTrain(torch.autograd.Function):
             t1 = linear_fwd(bo, 1, ldb, fld.th0, ACT_RELU, N)
             t2 = linear_fwd(t1, 0, t1.shape[1], fld.th1, ACT_SIGMOID, N)
             th_s = linear_fwd(t2, 0, t2.shape[1], fld.thead, ACT_NONE, N)
-        f.weights = weights_fwd(f.deltas, f.density.view(R, S))
-
-        rgb, thermal = _f32((R, 3), dev), _f32((R, 1), dev)
-        _hip.check(lib.tn_composite_fwd(rgb_s.data_ptr(), f.weights.data_ptr(), R, S, 3, 1, rgb.data_ptr(), _stream()),
-                   "tn_composite_fwd")
-        _hip.check(lib.tn_composite_fwd(th_s.data_ptr(), f.weights.data_ptr(), R, S, 1, 1, thermal.data_ptr(), _stream()),
-                   "tn_composite_fwd")
-        acc, depth, expected = _f32((R, 1), dev), _f32((R, 1), dev), _f32((R, 1), dev)
+        # get_weights + the RGB / thermal / accumulation renderers of the level: one launch (tn_ray_render_fwd)
+        f.weights = _f32((R, S), dev)
+        rgb, thermal, acc = _f32((R, 3), dev), _f32((R, 1), dev), _f32((R, 1), dev)
+        _hip.check(lib.tn_ray_render_fwd(f.deltas.data_ptr(), f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), R, S,
+                                         f.weights.data_ptr(), rgb.data_ptr(), thermal.data_ptr(), acc.data_ptr(), _stream()),
+                   "tn_ray_render_fwd")
+        depth, expected = _f32((R, 1), dev), _f32((R, 1), dev)
         scratch = _f32((2,), dev)
         starts, ends = _starts_ends(f)
-        _hip.check(lib.tn_depth_fwd(f.weights.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S, acc.data_ptr(),
+        _hip.check(lib.tn_depth_fwd(f.weights.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S, None,
                                     depth.data_ptr(), expected.data_ptr(), scratch.data_ptr(), _stream()), "tn_depth_fwd")
         for t in (tapes if not prop_depths else []):
             pd = _f32((R, 1), dev)
@@ -494,25 +493,18 @@ class RenderTrain(torch.autograd.Function):
             return grads[name]
 
         # ---- final level ------------------------------------------------------------------------------------
-        g_w = arena.zeros((R, S)) if g_w2 is None else g_w2.reshape(R, S).contiguous().clone()
-        if g_acc is not None:
-            g_w += g_acc.reshape(R, 1)
-        g_rgb_s, g_th_s = None, None
-        if g_rgb is not None:
-            g_rgb_s = _f32((N, 3), dev)
-            _hip.check(lib.tn_composite_bwd(rgb_s.data_ptr(), f.weights.data_ptr(), ctx.acc.data_ptr(),
-                                            g_rgb.contiguous().data_ptr(), R, S, 3, g_rgb_s.data_ptr(), g_w.data_ptr(),
-                                            _stream()), "tn_composite_bwd")
-        if g_th is not None:
-            g_th_s = _f32((N, 1), dev)
-            _hip.check(lib.tn_composite_bwd(th_s.data_ptr(), f.weights.data_ptr(), ctx.acc.data_ptr(),
-                                            g_th.contiguous().data_ptr(), R, S, 1, g_th_s.data_ptr(), g_w.data_ptr(),
-                                            _stream()), "tn_composite_bwd")
-        g_density = weights_bwd(f.deltas, f.density.view(R, S), g_w)
-        if cfg.use_gradient_scaling:  # REF :228-231: field_outputs = scale_gradients_by_distance_squared(field_outputs, ray_samples)
-            starts, ends = _starts_ends(f)
-            _hip.check(lib.tn_gradient_scale_bwd(starts.data_ptr(), ends.data_ptr(), N, g_density.data_ptr(), _hip.ptr(g_rgb_s),
-                                                 _hip.ptr(g_th_s), _stream()), "tn_gradient_scale_bwd")
+        # adjoints of the level's renderers and of get_weights (+ use_gradient_scaling, REF :228-231): one launch
+        g_rgb_s = _f32((N, 3), dev) if g_rgb is not None else None
+        g_th_s = _f32((N, 1), dev) if g_th is not None else None
+        g_density = _f32((R, S), dev)
+        g_wx = None if g_w2 is None else _hip.require_device_tensor(g_w2.reshape(R, S), "d weights")
+        st_en = _starts_ends(f) if cfg.use_gradient_scaling else (None, None)
+        _hip.check(lib.tn_ray_render_bwd(f.deltas.data_ptr(), f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(),
+                                         ctx.acc.data_ptr(), _hip.ptr(None if g_rgb is None else g_rgb.contiguous()),
+                                         _hip.ptr(None if g_th is None else g_th.contiguous()),
+                                         _hip.ptr(None if g_acc is None else g_acc.contiguous()), _hip.ptr(g_wx),
+                                         _hip.ptr(st_en[0]), _hip.ptr(st_en[1]), R, S, _hip.ptr(g_rgb_s), _hip.ptr(g_th_s),
+                                         g_density.data_ptr(), _stream()), "tn_ray_render_bwd")
         exp_min = float(getattr(cfg, "trunc_exp_clamp_min", -15.0))
         W = 64
         chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
