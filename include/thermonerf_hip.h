@@ -413,6 +413,17 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * accumulators); 1: the colour head and (thermal head + mlp_base) as two launches of two waves per SIMD each, the colour
  * head's adjoint of mlp_base's outputs passing through the workspace.  The reference geometry only (16 levels, geo 15,
  * appearance 32). */
+/* One proposal level of a step on which the proposal networks take gradient, forward and backward in one launch each
+ * [HashMLPDensityField built at REF thermal_nerf_model.py:127-149: 5 levels -> Linear(10,16)+ReLU -> Linear(16,1) -> trunc_exp]:
+ * forward writes what tn_hash_encode_fwd + 2 x tn_linear_fwd + tn_density_act_fwd write (enc [n,10], selector, raw, density
+ * [n]); backward takes d_density [n] to d_enc [n,10] (=) and the four parameter gradients (+=), the hidden layer recomputed
+ * from enc.  The reference geometry only (5 levels, hidden 16): TN_ERR_UNSUPPORTED otherwise (use the stage entry points). */
+int tn_density_fwd_train(const tn_density_field *f, const float *positions, int64_t n, float *enc, float *selector, float *raw,
+                         float *density, void *stream);
+int tn_density_bwd_train(const tn_density_field *f, const float *enc, const float *raw, const float *selector,
+                         const float *d_density, int64_t n, float trunc_exp_min, float *d_enc, float *d_w0, float *d_b0,
+                         float *d_w1, float *d_b1, void *stream);
+
 /* mlp_head.0's ray-constant part [REF thermal_field.py:117-126,160-168]: ray_bias [R,64] = bias + W[:, 0:16] . SH(direction) +
  * W[:, 31:63] . embedding[camera] (training-mode appearance), and its adjoint on the per-ray sums d_ray_sum [R,64] of the layer's
  * pre-activation gradient: d_head0_weight (+=, the SH and appearance columns only), d_head0_bias (+=), d_appearance

@@ -339,8 +339,9 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
     # taped = the final level's forward as one MFMA kernel writing the tape (tn_field_fwd_taped) and each MLP's backward as one
     # launch (tn_linear_chain_bwd); stage_forward = one launch per nerfstudio module / layer in both directions
     over = {"gradient_scaling": {"use_gradient_scaling": True}, "same_proposal_network": ONE_NET,
-            "taped": {"tape_free_training": False},
-            "stage_forward": {"tape_free_training": False, "fused_train_forward": False, "fused_train_backward": False},
+            "taped": {"tape_free_training": False, "fused_proposal_training": False},
+            "stage_forward": {"tape_free_training": False, "fused_train_forward": False, "fused_train_backward": False,
+                              "fused_proposal_training": False},
             "trunc_exp_one_sided": {"trunc_exp_clamp_min": float("-inf")},
             "uniform_initial_sampler": {"proposal_initial_sampler": "uniform", "far_plane": 6.0}}.get(variant, {})
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, **over)

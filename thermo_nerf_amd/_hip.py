@@ -204,6 +204,8 @@ SIGNATURES = {
     "tn_linear_chain_bwd_workspace_bytes": (_sz, []),
     "tn_linear_chain_bwd": (C.c_int, [C.POINTER(tn_chain_layer), _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _sz, _vp]),
     "tn_field_fwd_taped": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32] + [_vp] * 12),
+    "tn_density_fwd_train": (C.c_int, [C.POINTER(tn_density_field), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "tn_density_bwd_train": (C.c_int, [C.POINTER(tn_density_field), _vp, _vp, _vp, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tn_ray_head_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _vp, _vp]),
     "tn_ray_head_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tn_field_fwd_train": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _i32] + [_vp] * 6),

@@ -727,6 +727,133 @@ __global__ void __launch_bounds__(256) ray_head_bwd_kernel(const float *__restri
     if (part == 0 && d_b) unsafeAtomicAdd(d_b + lo, ab);
 }
 
+// ---- a proposal level of an update step (one step in six after warm-up: the proposal networks take gradient) -------------------
+// HashMLPDensityField [REF thermal_nerf_model.py:127-149]: 5-level grid -> Linear(10,16) + ReLU -> Linear(16,1) -> trunc_exp.
+// The taped stage chain was tn_hash_encode_fwd + 2 x tn_linear_fwd + tn_density_act_fwd forward and tn_density_act_bwd +
+// tn_linear_chain_bwd<2> backward — the latter 225 us per level for 176 MACs per row, because it tiles [N,16] matrices for
+// the matrix pipe.  Here: lane = sample, the network's 193 weights as SCALAR operands (constant address space -> s_load), the
+// hidden layer recomputed in the backward from the stored hash features, and every weight gradient accumulated per lane in
+// registers (193 accumulators), reduced per wave and per block at the end: one atomic per block and entry.
+constexpr int PE = 10, PH = 16;  // encoding width (5 levels x 2), hidden width
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// every lane <- the sum over its row of 16 lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    v += dpp_get<0x140>(v);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+density_fwd_train_kernel(Grid g, tn_space space, const tn_cfloat *w0, const tn_cfloat *b0, const tn_cfloat *w1, const tn_cfloat *b1,
+                         float avg, const float *__restrict__ positions, long long n, float *__restrict__ enc,
+                         float *__restrict__ sel_out, float *__restrict__ raw_out, float *__restrict__ density) {
+    const Space sp = make_space(space);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float px, py, pz;
+        const float sel = normalize_position(sp, positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2], px, py, pz);
+        float2 f[PE / 2];
+#pragma unroll
+        for (int l = 0; l < PE / 2; ++l) f[l] = encode_level<false, false>(g, l, px, py, pz);
+#pragma unroll
+        for (int l = 0; l < PE / 2; ++l) reinterpret_cast<float2 *>(enc + i * PE)[l] = f[l];
+        float o = b1[0];
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            float a = b0[h];
+#pragma unroll
+            for (int l = 0; l < PE / 2; ++l) {
+                a = fmaf(w0[h * PE + 2 * l], f[l].x, a);
+                a = fmaf(w0[h * PE + 2 * l + 1], f[l].y, a);
+            }
+            o = fmaf(w1[h], fmaxf(a, 0.0f), o);
+        }
+        sel_out[i] = sel;
+        raw_out[i] = o;
+        density[i] = mul_rn(mul_rn(avg, expf(o)), sel);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+density_bwd_train_kernel(const tn_cfloat *w0, const tn_cfloat *b0, const tn_cfloat *w1, float avg, float clamp_min,
+                         const float *__restrict__ enc, const float *__restrict__ raw, const float *__restrict__ sel,
+                         const float *__restrict__ g_density, long long n, float *__restrict__ g_enc, float *__restrict__ d_w0,
+                         float *__restrict__ d_b0, float *__restrict__ d_w1, float *__restrict__ d_b1) {
+    float aw0[PH * PE], ab0[PH], aw1[PH], ab1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PH * PE; ++k) aw0[k] = 0.0f;
+#pragma unroll
+    for (int h = 0; h < PH; ++h) ab0[h] = aw1[h] = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float e[PE];
+#pragma unroll
+        for (int l = 0; l < PE / 2; ++l) {
+            const float2 t = reinterpret_cast<const float2 *>(enc + i * PE)[l];
+            e[2 * l] = t.x;
+            e[2 * l + 1] = t.y;
+        }
+        // NS trunc_exp backward with the selector and the average density folded in
+        const float gr = g_density[i] * sel[i] * avg * expf(fminf(fmaxf(raw[i], clamp_min), 15.0f));
+        float ge[PE];
+#pragma unroll
+        for (int k = 0; k < PE; ++k) ge[k] = 0.0f;
+        ab1 += gr;
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            float a = b0[h];
+#pragma unroll
+            for (int k = 0; k < PE; ++k) a = fmaf(w0[h * PE + k], e[k], a);
+            const float hid = fmaxf(a, 0.0f);
+            aw1[h] = fmaf(gr, hid, aw1[h]);
+            const float gh = a > 0.0f ? w1[h] * gr : 0.0f;
+            ab0[h] += gh;
+#pragma unroll
+            for (int k = 0; k < PE; ++k) {
+                aw0[h * PE + k] = fmaf(gh, e[k], aw0[h * PE + k]);
+                ge[k] = fmaf(w0[h * PE + k], gh, ge[k]);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < PE / 2; ++l) reinterpret_cast<float2 *>(g_enc + i * PE)[l] = make_float2(ge[2 * l], ge[2 * l + 1]);
+    }
+    // row (16-lane) sums on the DPP path — no LDS round trip: as 193 x 6 ds_bpermute steps with a wait each the epilogue cost
+    // more than the loop (50 us) — then the 16 rows of the block through LDS, then one atomic per block and entry
+    constexpr int NV = PH * PE + 2 * PH + 1;
+    __shared__ float red[16][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = wave * 4 + (lane >> 4);
+    const bool leader = (lane & 15) == 0;
+#pragma unroll
+    for (int k = 0; k < PH * PE; ++k) {
+        const float v = row_sum16(aw0[k]);
+        if (leader) red[row][k] = v;
+    }
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        const float v0 = row_sum16(ab0[h]), v1 = row_sum16(aw1[h]);
+        if (leader) {
+            red[row][PH * PE + h] = v0;
+            red[row][PH * PE + PH + h] = v1;
+        }
+    }
+    {
+        const float v = row_sum16(ab1);
+        if (leader) red[row][PH * PE + 2 * PH] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += 256) {
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += red[r][k];
+        float *dst = k < PH * PE ? d_w0 + k : (k < PH * PE + PH ? d_b0 + (k - PH * PE) : (k < PH * PE + 2 * PH ? d_w1 + (k - PH * PE - PH) : d_b1));
+        if (v != 0.0f) unsafeAtomicAdd(dst, v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -852,5 +979,44 @@ int tn_ray_head_bwd(const tn_thermal_field *f, const float *directions, const in
     return TN_OK;
 }
 
+static inline const tn_cfloat *cs(const float *p) { return (const tn_cfloat *)p; }  // the kernels read these as scalars
+
+static int density_train_supported(const tn_density_field *f) {
+    if (!f) return TN_ERR_NULL;
+    TN_TRY(tn_check_density_field(f));
+    if (2 * f->grid.num_levels != PE || f->l0.out_dim != PH) return TN_ERR_UNSUPPORTED;
+    return TN_OK;
+}
+
+int tn_density_fwd_train(const tn_density_field *f, const float *positions, int64_t n, float *enc, float *selector, float *raw,
+                         float *density, void *stream) {
+    if (n == 0) return TN_OK;
+    TN_TRY(density_train_supported(f));
+    if (!positions || !enc || !selector || !raw || !density) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(density_fwd_train_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       tn_make_grid(f->grid), f->space, cs(f->l0.weight), cs(f->l0.bias), cs(f->l1.weight),
+                       cs(f->l1.bias), f->average_init_density, positions, (long long)n, enc, selector, raw, density);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_density_bwd_train(const tn_density_field *f, const float *enc, const float *raw, const float *selector,
+                         const float *d_density, int64_t n, float trunc_exp_min, float *d_enc, float *d_w0, float *d_b0, float *d_w1,
+                         float *d_b1, void *stream) {
+    if (n == 0) return TN_OK;
+    TN_TRY(density_train_supported(f));
+    if (!enc || !raw || !selector || !d_density || !d_enc || !d_w0 || !d_b0 || !d_w1 || !d_b1) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(density_bwd_train_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)stream,
+                       cs(f->l0.weight), cs(f->l0.bias), cs(f->l1.weight), f->average_init_density, trunc_exp_min,
+                       enc, raw, selector, d_density, (long long)n, d_enc, d_w0, d_b0, d_w1, d_b1);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 }  // extern "C"
+
 

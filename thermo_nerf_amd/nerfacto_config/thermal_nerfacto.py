@@ -99,6 +99,10 @@ class NerfactoModelConfig:
     sample (hash features, selector, density, rgb, thermal) instead of ~380; the backward (tn_field_bwd_fused) recomputes the
     five hidden layers from the hash features in registers and runs every adjoint next to them (DESIGN §5.6).  False: the
     taped forward + chained / per-layer backward above, kept as the cross-check (same gradients, tests/test_gpu_training.py)."""
+    fused_proposal_training: bool = True
+    """Training, steps on which the proposal networks take gradient: each level's HashMLPDensityField forward and backward as one
+    launch each (tn_density_fwd_train / tn_density_bwd_train: lane = sample, weights as scalars, hidden layer recomputed);
+    False: the stage entry points + tn_linear_chain_bwd."""
     fused_backward_split: bool = True
     """tn_field_bwd_fused as three launches (colour head | thermal head | mlp_base) of two waves per SIMD each instead of one
     launch of one wave per SIMD holding all ~210 gradient accumulators (DESIGN §5.6)."""

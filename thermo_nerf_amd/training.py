@@ -238,12 +238,23 @@ def _frustum_positions(o: Tensor, d: Tensor, t: "_LevelTape") -> Tuple[Tensor, T
     return pos, ends - starts
 
 
-def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl: Tensor) -> _LevelTape:
+def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl: Tensor, fused: bool = True) -> _LevelTape:
     lib = _hip.load()
     t = _LevelTape()
     t.spacing, t.eucl = spacing, eucl
     t.pos, t.deltas = _frustum_positions(o, d, t)
     n = t.pos.shape[0]
+    t.hid = None
+    if fused:
+        # encode + Linear(10,16)+ReLU + Linear(16,1) + trunc_exp in one launch; the hidden layer is not kept (the backward recomputes it)
+        E = 2 * net_struct.grid.num_levels
+        t.enc, t.sel, t.raw, t.density = _f32((n, E), o.device), _f32((n,), o.device), _f32((n, 1), o.device), _f32((n,), o.device)
+        code = lib.tn_density_fwd_train(net_struct, t.pos.data_ptr(), n, t.enc.data_ptr(), t.sel.data_ptr(), t.raw.data_ptr(),
+                                        t.density.data_ptr(), _stream())
+        if code != -3:  # TN_ERR_UNSUPPORTED: a geometry other than the reference's 5 levels x hidden 16 -> the stage chain below
+            _hip.check(code, "tn_density_fwd_train")
+            t.weights = weights_fwd(t.deltas, t.density.view(t.deltas.shape))
+            return t
     t.enc, t.sel = hash_encode_fwd(net_struct.grid, net_struct.space, t.pos)
     t.hid = linear_fwd(t.enc, 0, t.enc.shape[1], net_struct.l0, ACT_RELU, n)
     t.raw = linear_fwd(t.hid, 0, t.hid.shape[1], net_struct.l1, ACT_NONE, n)
@@ -273,26 +284,32 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
-    g_raw = _f32((n, 1), g_w.device)
-    _hip.check(lib.tn_density_act_bwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density, exp_min,
-                                      g_density.data_ptr(), n, g_raw.data_ptr(), 1, 0, _stream()), "tn_density_act_bwd")
     names = [f"{prefix}.mlp_base.encoder.hash_table", f"{prefix}.mlp_base.mlp.layers.0.weight",
              f"{prefix}.mlp_base.mlp.layers.0.bias", f"{prefix}.mlp_base.mlp.layers.1.weight",
              f"{prefix}.mlp_base.mlp.layers.1.bias"]
     for k in names:
         if k not in grads:
             grads[k] = like.get(k)  # `like` is the step's _GradArena: zero-filled views
-    H = t.hid.shape[1]
     E = t.enc.shape[1]
     g_enc = _f32((n, E), g_w.device)
-    if chained:
-        linear_chain_bwd([(net_struct.l1, t.hid, 0, H, ACT_RELU, grads[names[3]], grads[names[4]]),
-                          (net_struct.l0, t.enc, 0, E, ACT_NONE, grads[names[1]], grads[names[2]])],
-                         None, ACT_NONE, g_raw, 1, n, g_enc, 0, E, False)
+    if t.hid is None:
+        # the fused forward's counterpart: trunc_exp backward + both Linear layers' adjoints in one launch, hidden layer recomputed
+        _hip.check(lib.tn_density_bwd_train(net_struct, t.enc.data_ptr(), t.raw.data_ptr(), t.sel.data_ptr(), g_density.data_ptr(), n,
+                                            exp_min, g_enc.data_ptr(), grads[names[1]].data_ptr(), grads[names[2]].data_ptr(),
+                                            grads[names[3]].data_ptr(), grads[names[4]].data_ptr(), _stream()), "tn_density_bwd_train")
     else:
-        g_hid = _f32((n, H), g_w.device)
-        linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
-        linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
+        g_raw = _f32((n, 1), g_w.device)
+        _hip.check(lib.tn_density_act_bwd(t.raw.data_ptr(), 1, t.sel.data_ptr(), net_struct.average_init_density, exp_min,
+                                          g_density.data_ptr(), n, g_raw.data_ptr(), 1, 0, _stream()), "tn_density_act_bwd")
+        H = t.hid.shape[1]
+        if chained:
+            linear_chain_bwd([(net_struct.l1, t.hid, 0, H, ACT_RELU, grads[names[3]], grads[names[4]]),
+                              (net_struct.l0, t.enc, 0, E, ACT_NONE, grads[names[1]], grads[names[2]])],
+                             None, ACT_NONE, g_raw, 1, n, g_enc, 0, E, False)
+        else:
+            g_hid = _f32((n, H), g_w.device)
+            linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
+            linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
     hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed, spread)
     if ray_grads is not None:
         _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads)
@@ -333,7 +350,7 @@ class RenderTrain(torch.autograd.Function):
                        "tn_sample_initial")
             counts = (P[1], S)
             for lvl in range(2):
-                t = _proposal_level_fwd(prop_structs[lvl], o, d, spacing, eucl)
+                t = _proposal_level_fwd(prop_structs[lvl], o, d, spacing, eucl, bool(getattr(cfg, "fused_proposal_training", True)))
                 tapes.append(t)
                 n_out = counts[lvl]
                 w_in = t.weights if anneal == 1.0 else torch.pow(t.weights, anneal)
