@@ -407,6 +407,8 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * (=), d_ray_sum [R,64] (+=, zero it first) = per-ray sums of mlp_head.0's pre-activation gradient — tn_ray_head_bwd then
  * yields mlp_head.0's bias gradient, its SH and appearance weight columns and the embedding / direction gradients — and the
  * gradients of every other Linear of the field (+=; NULL entries skipped; head0_w receives its geo columns 16..30 only).
+ * d_positions [N,3] (=; NULL to skip; needs `positions` [N,3]): d loss / d sample position through the hash encoding — what
+ * tn_hash_encode_bwd_input computes from d_enc — for camera-pose optimisation, produced by the mlp_base launch.
  * trunc_exp_min: lower clamp of trunc_exp's backward (g * exp(clamp(x, min, 15)); -15 = torch-ngp / nerfstudio's
  * two-sided clamp, -INFINITY = upper clamp only).  pass_thermal_gradients = 0 keeps the thermal branch from the geo
  * features [REF thermal_field.py:171-172].  split = 0: one launch for the whole field (one wave per SIMD: its ~210 gradient
@@ -445,8 +447,8 @@ size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n);
 int tn_field_bwd_fused(const tn_thermal_field *field, int64_t num_rays, int32_t n, const float *enc, const float *selector,
                        const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
                        const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split,
-                       float *d_enc, float *d_ray_sum, const tn_field_grads *grads, void *workspace, size_t workspace_bytes,
-                       void *stream);
+                       float *d_enc, float *d_ray_sum, const float *positions, float *d_positions,
+                       const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
 
 /* NS scale_gradients_by_distance_squared [REF thermal_nerf_model.py:228-231, use_gradient_scaling]: the forward is the
  * identity; in the backward the gradient of EVERY field output of a sample (density [n], rgb [n,3], thermal [n]; any may

@@ -391,6 +391,69 @@ __device__ __forceinline__ float2 encode_level_any(const Grid &g, int l, float p
     return encode_level<false, FAST>(g, l, px, py, pz);
 }
 
+// ---- gradient of the encoding w.r.t. the position (camera-pose optimisation) ---------------------------
+// (gx, gy, gz) += d (ge . enc_l) / d p for one level: d enc / d offset from the 8 corners (table reads, torch's ceil / floor
+// corner convention), times the level scale; p = the normalised position with the selector applied.
+__device__ __forceinline__ void encode_level_grad(const Grid &g, int l, float px, float py, float pz, float2 ge, float &gx,
+                                                  float &gy, float &gz) {
+    const float s = g.scal[l];
+    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
+    const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+    const float ox = sub_rn(sx, fxf), oy = sub_rn(sy, fyf), oz = sub_rn(sz, fzf);
+    const float qx = 1.0f - ox, qy = 1.0f - oy, qz = 1.0f - oz;
+    const unsigned cx = (unsigned)(int)ceilf(sx), cy = (unsigned)(int)ceilf(sy), cz = (unsigned)(int)ceilf(sz);
+    const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
+    const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
+    const float2 *t = g.table + (size_t)l * g.tsize;
+    const unsigned m = g.mask;
+    const float2 f0 = t[(cx ^ hcy ^ hcz) & m], f1 = t[(cx ^ hfy ^ hcz) & m], f2 = t[(fx ^ hfy ^ hcz) & m];
+    const float2 f3 = t[(fx ^ hcy ^ hcz) & m], f4 = t[(cx ^ hcy ^ hfz) & m], f5 = t[(cx ^ hfy ^ hfz) & m];
+    const float2 f6 = t[(fx ^ hfy ^ hfz) & m], f7 = t[(fx ^ hcy ^ hfz) & m];
+    // enc = ((f0 ox + f3 qx) oy + (f1 ox + f2 qx) qy) oz + ((f4 ox + f7 qx) oy + (f5 ox + f6 qx) qy) qz
+#define TN_DENC(c)                                                                                                   \
+    {                                                                                                                \
+        const float f03 = f0.c * ox + f3.c * qx, f12 = f1.c * ox + f2.c * qx;                                        \
+        const float f47 = f4.c * ox + f7.c * qx, f56 = f5.c * ox + f6.c * qx;                                        \
+        const float dox = ((f0.c - f3.c) * oy + (f1.c - f2.c) * qy) * oz + ((f4.c - f7.c) * oy + (f5.c - f6.c) * qy) * qz; \
+        const float doy = (f03 - f12) * oz + (f47 - f56) * qz;                                                       \
+        const float doz = (f03 * oy + f12 * qy) - (f47 * oy + f56 * qy);                                             \
+        gx += ge.c * dox * s;                                                                                        \
+        gy += ge.c * doy * s;                                                                                        \
+        gz += ge.c * doz * s;                                                                                        \
+    }
+    TN_DENC(x)
+    TN_DENC(y)
+#undef TN_DENC
+}
+
+// ... and back from p to the world position (x, y, z): through `p * selector`, the (c + 2) / 4 shift and the L-inf contraction
+// (torch's inf-norm backward splits the subgradient evenly among tied maxima), or the AABB normalisation
+__device__ __forceinline__ void position_grad_finish(const Space &sp, float x, float y, float z, float sel, float gx, float gy,
+                                                     float gz, float &rx, float &ry, float &rz) {
+    gx *= sel; gy *= sel; gz *= sel;  // p = p * selector
+    if (sp.contraction) {
+        gx *= 0.25f; gy *= 0.25f; gz *= 0.25f;  // (c + 2) / 4
+        const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+        const float mag = fmaxf(fmaxf(ax, ay), az);
+        if (mag < 1.0f) {
+            rx = gx; ry = gy; rz = gz;
+        } else {
+            // c = s(m) x,  s = 2/m - 1/m^2,  m = |x_k| (k = arg max)
+            const float sm = 2.0f / mag - 1.0f / (mag * mag);
+            const float dsm = -2.0f / (mag * mag) + 2.0f / (mag * mag * mag);
+            const float dot = gx * x + gy * y + gz * z;
+            rx = sm * gx; ry = sm * gy; rz = sm * gz;
+            const int ties = (ax == mag) + (ay == mag) + (az == mag);
+            const float share = dsm * dot / (float)ties;
+            if (ax == mag) rx += share * (x > 0.0f ? 1.0f : -1.0f);
+            if (ay == mag) ry += share * (y > 0.0f ? 1.0f : -1.0f);
+            if (az == mag) rz += share * (z > 0.0f ? 1.0f : -1.0f);
+        }
+    } else {
+        rx = gx / (sp.mx[0] - sp.mn[0]); ry = gy / (sp.mx[1] - sp.mn[1]); rz = gz / (sp.mx[2] - sp.mn[2]);
+    }
+}
+
 // ---- wave64 collectives ------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

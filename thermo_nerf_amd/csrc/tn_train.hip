@@ -458,37 +458,7 @@ hash_encode_bwd_input_kernel(Grid g, tn_space space, const float *__restrict__ p
         float px, py, pz;
         const float sel = normalize_position(sp, x, y, z, px, py, pz);
         float gx = 0.0f, gy = 0.0f, gz = 0.0f;  // d loss / d p (p = normalised, selector applied)
-        if (live && l < L) {
-            const float2 ge = reinterpret_cast<const float2 *>(d_enc)[ic * L + l];
-            const float s = g.scal[l];
-            const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
-            const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
-            const float ox = sub_rn(sx, fxf), oy = sub_rn(sy, fyf), oz = sub_rn(sz, fzf);
-            const float qx = 1.0f - ox, qy = 1.0f - oy, qz = 1.0f - oz;
-            const unsigned cx = (unsigned)(int)ceilf(sx), cy = (unsigned)(int)ceilf(sy), cz = (unsigned)(int)ceilf(sz);
-            const unsigned fx = (unsigned)(int)fxf, fy = (unsigned)(int)fyf, fz = (unsigned)(int)fzf;
-            const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
-            const float2 *t = g.table + (size_t)l * g.tsize;
-            const unsigned m = g.mask;
-            const float2 f0 = t[(cx ^ hcy ^ hcz) & m], f1 = t[(cx ^ hfy ^ hcz) & m], f2 = t[(fx ^ hfy ^ hcz) & m];
-            const float2 f3 = t[(fx ^ hcy ^ hcz) & m], f4 = t[(cx ^ hcy ^ hfz) & m], f5 = t[(cx ^ hfy ^ hfz) & m];
-            const float2 f6 = t[(fx ^ hfy ^ hfz) & m], f7 = t[(fx ^ hcy ^ hfz) & m];
-            // enc = ((f0 ox + f3 qx) oy + (f1 ox + f2 qx) qy) oz + ((f4 ox + f7 qx) oy + (f5 ox + f6 qx) qy) qz
-#define TN_DENC(c)                                                                                                   \
-            {                                                                                                        \
-                const float f03 = f0.c * ox + f3.c * qx, f12 = f1.c * ox + f2.c * qx;                                \
-                const float f47 = f4.c * ox + f7.c * qx, f56 = f5.c * ox + f6.c * qx;                                \
-                const float dox = ((f0.c - f3.c) * oy + (f1.c - f2.c) * qy) * oz + ((f4.c - f7.c) * oy + (f5.c - f6.c) * qy) * qz; \
-                const float doy = (f03 - f12) * oz + (f47 - f56) * qz;                                               \
-                const float doz = (f03 * oy + f12 * qy) - (f47 * oy + f56 * qy);                                     \
-                gx += ge.c * dox * s;                                                                                \
-                gy += ge.c * doy * s;                                                                                \
-                gz += ge.c * doz * s;                                                                                \
-            }
-            TN_DENC(x)
-            TN_DENC(y)
-#undef TN_DENC
-        }
+        if (live && l < L) encode_level_grad(g, l, px, py, pz, reinterpret_cast<const float2 *>(d_enc)[ic * L + l], gx, gy, gz);
 #pragma unroll
         for (int o = LP / 2; o > 0; o >>= 1) {
             gx += __shfl_xor(gx, o, 64);
@@ -496,30 +466,8 @@ hash_encode_bwd_input_kernel(Grid g, tn_space space, const float *__restrict__ p
             gz += __shfl_xor(gz, o, 64);
         }
         if (!live || l != 0) continue;
-        gx *= sel; gy *= sel; gz *= sel;  // p = p * selector
         float rx, ry, rz;
-        if (sp.contraction) {
-            gx *= 0.25f; gy *= 0.25f; gz *= 0.25f;  // (c + 2) / 4
-            const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
-            const float mag = fmaxf(fmaxf(ax, ay), az);
-            if (mag < 1.0f) {
-                rx = gx; ry = gy; rz = gz;
-            } else {
-                // c = s(m) x,  s = 2/m - 1/m^2,  m = |x_k| (k = arg max)
-                const float sm = 2.0f / mag - 1.0f / (mag * mag);
-                const float dsm = -2.0f / (mag * mag) + 2.0f / (mag * mag * mag);
-                const float dot = gx * x + gy * y + gz * z;
-                rx = sm * gx; ry = sm * gy; rz = sm * gz;
-                // torch's inf-norm backward splits the subgradient evenly among tied maxima
-                const int ties = (ax == mag) + (ay == mag) + (az == mag);
-                const float share = dsm * dot / (float)ties;
-                if (ax == mag) rx += share * (x > 0.0f ? 1.0f : -1.0f);
-                if (ay == mag) ry += share * (y > 0.0f ? 1.0f : -1.0f);
-                if (az == mag) rz += share * (z > 0.0f ? 1.0f : -1.0f);
-            }
-        } else {
-            rx = gx / (sp.mx[0] - sp.mn[0]); ry = gy / (sp.mx[1] - sp.mn[1]); rz = gz / (sp.mx[2] - sp.mn[2]);
-        }
+        position_grad_finish(sp, x, y, z, sel, gx, gy, gz, rx, ry, rz);
         d_pos[i * 3] = rx; d_pos[i * 3 + 1] = ry; d_pos[i * 3 + 2] = rz;
     }
 }

@@ -197,6 +197,10 @@ struct FusedBwdArgs {
     const float *g_dens;    // [N]
     float *g_enc;           // [N,32]
     float *gsum;            // [R,64]  += per-ray sums of mlp_head.0's pre-activation gradient
+    Grid g;                 // the field's hash grid and position normalisation: only for d_pos
+    tn_space space;
+    const float *positions; // [N,3]   sample positions (d_pos != nullptr)
+    float *d_pos;           // [N,3]   d loss / d position through the hash encoding (camera-pose optimisation), or nullptr
     float *g_bo_c, *g_bo_t; // [N,16]  split launches: the colour / thermal head's adjoint of bo's rows (nullptr: that head did not run)
     float *slabs;           // [gridDim.x][SLAB_FLOATS]
 };
@@ -492,6 +496,31 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             if (live) {
                 st4(a.g_enc + (i0 + n) * 32 + 4 * sl, de[0]);
                 st4(a.g_enc + (i0 + n) * 32 + 16 + 4 * sl, de[1]);
+            }
+            if (a.d_pos) {
+                // camera-pose optimisation: d loss / d position of sample n through the encoding.  The lane holds d_enc of four of
+                // the sample's 16 levels (2 sl, 2 sl + 1, 8 + 2 sl, 9 + 2 sl): 32 table reads per lane, in flight under the
+                // weight-gradient MFMAs below, summed over the sample's four lanes.  (As a kernel of its own — one lane per
+                // (sample, level), tn_hash_encode_bwd_input — this was 310 us of pure gather time per step at S=192.)
+                const Space sp = make_space(a.space);
+                const long long ic = live ? i0 + n : a.N - 1;
+                const float x = a.positions[ic * 3], y = a.positions[ic * 3 + 1], z = a.positions[ic * 3 + 2];
+                float px, py, pz;
+                const float selp = normalize_position(sp, x, y, z, px, py, pz);
+                float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        encode_level_grad(a.g, 8 * b + 2 * sl + jj, px, py, pz, make_float2(de[b][2 * jj], de[b][2 * jj + 1]), gx, gy, gz);
+                }
+                gx += __shfl_xor(gx, 16, 64); gy += __shfl_xor(gy, 16, 64); gz += __shfl_xor(gz, 16, 64);
+                gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
+                if (sl == 0 && live) {
+                    float rx, ry, rz;
+                    position_grad_finish(sp, x, y, z, selp, gx, gy, gz, rx, ry, rz);
+                    a.d_pos[(i0 + n) * 3] = rx; a.d_pos[(i0 + n) * 3 + 1] = ry; a.d_pos[(i0 + n) * 3 + 2] = rz;
+                }
             }
             wave_sync();
             dw<4, 2, true>(D, X, n, sl, aw_b0, ab_b0);
@@ -866,10 +895,12 @@ size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n) {
 int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, const float *enc, const float *selector,
                        const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
                        const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split, float *d_enc,
-                       float *d_ray_sum, const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream) {
+                       float *d_ray_sum, const float *positions, float *d_positions, const tn_field_grads *grads, void *workspace,
+                       size_t workspace_bytes, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!f || !enc || !selector || !d_density || !d_enc || !grads || !workspace) return TN_ERR_NULL;
     if (d_rgb && (!rgb || !ray_bias || !d_ray_sum)) return TN_ERR_NULL;
+    if (d_positions && !positions) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1 || (long long)num_rays * n > 0x7fffffffLL) return TN_ERR_SHAPE;
     TN_TRY(tn_check_thermal_field(f));
     if (f->geo_feat_dim != GF || f->app_dim != APP || f->grid.num_levels != 16) return TN_ERR_UNSUPPORTED;
@@ -885,6 +916,7 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     a.pass_thermal = pass_thermal_gradients;
     a.enc = enc; a.sel = selector; a.ray_bias = ray_bias; a.rgb = rgb; a.g_rgb = d_rgb; a.g_th = d_thermal; a.g_dens = d_density;
     a.g_enc = d_enc; a.gsum = d_ray_sum;
+    a.g = tn_make_grid(f->grid); a.space = f->space; a.positions = positions; a.d_pos = d_positions;
     float *slabs = reinterpret_cast<float *>(workspace);
     float *g_bo = slabs + (size_t)3 * kFusedBlocks * SLAB_FLOATS;
     const long long tiles = (a.N + TS - 1) / TS;

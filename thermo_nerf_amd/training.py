@@ -545,11 +545,13 @@ class RenderTrain(torch.autograd.Function):
                     setattr(gr, key + "_b", zeros(name + ".bias").data_ptr())
             g_ray = arena.zeros((R, 64)) if g_rgb_s is not None else None
             ws = _fused_bwd_workspace(dev, R, S)
+            g_pos = _f32((N, 3), dev) if ray_grads else None  # d loss / d sample position, written by the mlp_base launch
             _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), self_bias.data_ptr(), rgb_s.data_ptr(),
                                               _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
                                               1 if model.field.pass_thermal_gradients else 0, exp_min,
                                               1 if getattr(cfg, "fused_backward_split", True) else 0, g_enc.data_ptr(),
-                                              _hip.ptr(g_ray), C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
+                                              _hip.ptr(g_ray), f.pos.data_ptr() if ray_grads else None, _hip.ptr(g_pos),
+                                              C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
                        "tn_field_bwd_fused")
             if g_ray is not None:
                 # mlp_head.0's ray-level part: bias, SH and appearance weight columns, the embedding gradient
@@ -564,7 +566,10 @@ class RenderTrain(torch.autograd.Function):
                                                       ctx.d.data_ptr(), ray_grads[1].data_ptr(), _stream()), "tn_color_input_bwd")
             hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread)
             if ray_grads:
-                _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
+                starts, ends = _starts_ends(f)
+                _hip.check(lib.tn_frustum_positions_bwd(g_pos.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S,
+                                                        ray_grads[0].data_ptr(), ray_grads[1].data_ptr(), _stream()),
+                           "tn_frustum_positions_bwd")
             return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
         ldb = bo.shape[1]
         g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass

@@ -42,7 +42,7 @@ def main():
                                           dens.data_ptr(), rgb.data_ptr(), th.data_ptr(), st), "fwd")
 
     g_rgb, g_th, g_dens = torch.randn(N, 3, device=dev) * 1e-3, torch.randn(N, device=dev) * 1e-3, torch.randn(N, device=dev) * 1e-3
-    g_enc, g_ray = f32(N, 32), torch.zeros(R, 64, device=dev)
+    g_enc, g_ray, g_pos = f32(N, 32), torch.zeros(R, 64, device=dev), f32(N, 3)
     grads = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
     gr = _hip.tn_field_grads()
     names = {"base0": "field.mlp_base.mlp.layers.0", "base1": "field.mlp_base.mlp.layers.1", "head0": "field.mlp_head.layers.0",
@@ -57,7 +57,7 @@ def main():
     def bwd(split):
         _hip.check(lib.tn_field_bwd_fused(fld, R, S, enc.data_ptr(), sel.data_ptr(), ray_bias.data_ptr(), rgb.data_ptr(),
                                           g_rgb.data_ptr(), g_th.data_ptr(), g_dens.data_ptr(), 1, -15.0, split, g_enc.data_ptr(),
-                                          g_ray.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(), st), "bwd")
+                                          g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(), st), "bwd")
 
     def time(fn, *args):
         for _ in range(3):
