@@ -252,7 +252,11 @@ int tn_render_rays_fwd(const tn_density_field *prop0, const tn_density_field *pr
 /* The two halves of tn_render_rays_fwd, callable separately (tn_render_rays_fwd == both, in this order, sharing
  * `workspace`): NS ProposalNetworkSampler.generate_ray_samples [REF thermal_nerf_model.py:222-224] (+ prop_depth_i
  * [REF :267-270]) leaves the final S+1 bin edges in `workspace`; tn_field_render_fwd evaluates
- * ThermalNerfactoTField.forward on them and composites [REF :225-243,271-273]. */
+ * ThermalNerfactoTField.forward on them and composites [REF :225-243,271-273].
+ * PRECONDITION of tn_field_render_fwd: `workspace` was produced by tn_proposal_sample_fwd of the SAME call shape on the same
+ * stream.  Besides the bin edges, that call resets the two words the expected-depth clip accumulates its call-global
+ * [min, max] in (DepthRenderer "expected" clips to them): on a workspace that did not come from it, expected_depth is clipped
+ * to stale bounds.  Every other output is independent of them. */
 int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field *prop1, const tn_render_config *cfg,
                            const tn_render_inputs *in, const tn_render_outputs *out, int64_t num_rays, void *workspace,
                            size_t workspace_bytes, void *stream);

@@ -33,7 +33,9 @@ class SceneContraction(nn.Module):
 
 
 class NearFarCollider(nn.Module):
-    """NS NearFarCollider: eval resets the near plane to 0 when reset_near_plane."""
+    """NS NearFarCollider: eval resets the near plane to 0 when reset_near_plane.  The two constant planes it
+    attaches are SHARED between calls of the same shape (a training loop asks for the same two tensors every step): treat
+    ``ray_bundle.nears`` / ``.fars`` as read-only, or clone them before editing in place."""
 
     def __init__(self, near_plane: float, far_plane: float, reset_near_plane: bool = True) -> None:
         super().__init__()

@@ -57,7 +57,7 @@ def _atomic_levels(lib, grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor
     args = (grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), lo, hi)
     need = lib.tn_hash_encode_bwd_spread_workspace_bytes(grid) if spread and lo == 0 else 0
     if need:
-        key = (pos.device, need)
+        key = (pos.device, _stream(), need)
         ws = _SPREAD_WS.get(key)
         if ws is None:
             ws = _SPREAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=pos.device)
@@ -86,7 +86,12 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
         return
     if first > 0:
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
-    ws = torch.empty(need, dtype=torch.uint8, device=pos.device)
+    try:
+        ws = torch.empty(need, dtype=torch.uint8, device=pos.device)  # 25 B per (sample, level, corner pair): 0.14-0.6 GB, from torch's caching allocator
+    except torch.cuda.OutOfMemoryError:  # no room for the records: the same sums through the global atomics
+        _hip.check(lib.tn_hash_encode_bwd_levels(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
+                                                 grid.num_levels, _stream()), "tn_hash_encode_bwd_levels")
+        return
     _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first, ws.data_ptr(),
                                              need, _stream()), "tn_hash_encode_bwd_sorted")
 
@@ -103,10 +108,11 @@ _LIN_WS: Dict = {}
 
 def _linear_workspace(dev) -> Tensor:
     """per-device scratch for tn_linear_bwd's partial weight gradients (calls on one stream are ordered, so one buffer)"""
-    ws = _LIN_WS.get(dev)
+    key = (dev, _stream())
+    ws = _LIN_WS.get(key)
     if ws is None:
         ws = torch.empty(_hip.load().tn_linear_bwd_workspace_bytes(), dtype=torch.uint8, device=dev)
-        _LIN_WS[dev] = ws
+        _LIN_WS[key] = ws
     return ws
 
 
@@ -130,9 +136,10 @@ def _fused_bwd_workspace(dev, R: int, S: int) -> Tensor:
     """per-device workspace of tn_field_bwd_fused (a slab of parameter gradients per persistent block and launch + the heads'
     adjoints of mlp_base's outputs), grown to the largest batch seen"""
     need = _hip.load().tn_field_bwd_fused_workspace_bytes(R, S)
-    ws = _FUSED_WS.get(dev)
+    key = (dev, _stream())
+    ws = _FUSED_WS.get(key)
     if ws is None or ws.numel() < need:
-        ws = _FUSED_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = _FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -150,9 +157,10 @@ def linear_chain_bwd(layers, y_top: Optional[Tensor], act_top: int, dy: Tensor, 
     (tn_linear, x tensor, x column offset, ldx, activation that produced x, d_weight, d_bias)."""
     lib = _hip.load()
     dev = dy.device
-    ws = _CHAIN_WS.get(dev)
+    key = (dev, _stream())  # calls on one stream are ordered; two streams must not share the partial-sum slabs
+    ws = _CHAIN_WS.get(key)
     if ws is None:
-        ws = _CHAIN_WS[dev] = torch.empty(lib.tn_linear_chain_bwd_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ws = _CHAIN_WS[key] = torch.empty(lib.tn_linear_chain_bwd_workspace_bytes(), dtype=torch.uint8, device=dev)
     arr = (_hip.tn_chain_layer * len(layers))()
     for k, (lin, x, x_off, ldx, act_x, d_w, d_b) in enumerate(layers):
         arr[k].lin = lin
