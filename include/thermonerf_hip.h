@@ -126,6 +126,12 @@ int tn_generate_rays(const float *c2w_host, float fx, float fy, float cx, float 
 int tn_frustum_positions(const float *origins, const float *directions, const float *starts, const float *ends,
                          int64_t num_rays, int32_t n, float *positions, void *stream);
 
+/* The same positions straight from a level's bin edges eucl_bins [R,n+1] (RaySamples.frustums.starts / .ends are its two
+ * edge columns, NS Sampler.generate_ray_samples via get_ray_samples), also writing the contiguous starts / ends / deltas
+ * [R,n] the training step's adjoint kernels read: one launch for the level's geometry. */
+int tn_frustum_from_edges(const float *origins, const float *directions, const float *eucl_bins, int64_t num_rays,
+                          int32_t n, float *positions, float *starts, float *ends, float *deltas, void *stream);
+
 /* HashMLPDensityField.density_fn(positions) [REF thermal_nerf_model.py:146-149,222-224]:
  * positions [N,3] -> density [N]. */
 int tn_density_fwd(const tn_density_field *field, const float *positions, int64_t n, float *density, void *stream);
@@ -515,6 +521,11 @@ int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal,
  * of lossfun_distortion (scale = 1/R for nerfstudio's mean), d_weights [R,n] (=) = scale * d(sum)/dw.  O(n) per ray. */
 int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float scale,
                        float *loss_sum, float *d_weights, void *stream);
+/* the metric and the loss term NerfactoModel makes of it (metrics_dict["distortion"], then distortion_loss_mult * that
+ * [REF thermal_nerf_model.py:301-304]) from the same launch: loss_pair[0] (+=) = scale * sum, loss_pair[1] (+=) = mult * scale *
+ * sum, d_weights [R,n] (=) = the gradient of loss_pair[1]. */
+int tn_distortion_loss_term(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float scale,
+                            float mult, float *loss_pair, float *d_weights, void *stream);
 /* NS losses.interlevel_loss, one proposal level: final bins c [R,n+1] / weights w [R,n] (constants), proposal bins
  * cp [R,p+1] / weights wp [R,p] -> loss_sum[0] (+=) = scale * sum over rays and samples of lossfun_outer (scale = 1/(R*n)),
  * d_wp [R,p] (=) = scale * d(sum)/dwp.  p <= 1024.  Several levels may add into the same loss_sum. */

@@ -270,6 +270,16 @@ def test_distortion_loss_and_gradient(n):
     assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-8
     assert rel(wd.grad, w.grad) <= 2e-5
 
+    # the model's form: the metric plus distortion_loss_mult * metric from the same launch [REF thermal_nerf_model.py:301-304]
+    mult = 0.002
+    w2 = w.detach().to(DEV).requires_grad_(True)
+    metric = TR.distortion_loss([w2], [RS], mult=mult)
+    m, term = metric.scaled_term
+    assert m == mult and abs(metric.item() - want.item()) <= 1e-5 * abs(want.item()) + 1e-8
+    assert abs(term.item() - mult * want.item()) <= 1e-5 * abs(mult * want.item()) + 1e-10
+    (term + 3.0 * metric).backward()  # both outputs differentiate: (mult + 3) * d metric / d w
+    assert rel(w2.grad, (mult + 3.0) * w.grad) <= 2e-5
+
 
 @pytest.mark.parametrize("ns", [(256, 96, 48), (64, 300, 192), (5, 7, 3), (1024, 1000, 1024)])
 def test_interlevel_loss_and_gradient(ns):
@@ -291,6 +301,12 @@ def test_interlevel_loss_and_gradient(ns):
     for a, b in zip(wd[:-1], ws[:-1]):
         assert rel(a.grad, b.grad) <= tol
     assert wd[-1].grad is None and ws[-1].grad is None  # the final level is detached in this loss
+    w5 = [w.detach().to(DEV).requires_grad_(True) for w in ws]
+    got5 = TR.interlevel_loss(w5, [rs(s) for s, _ in lv], mult=0.5)  # interlevel_loss_mult folded into the kernels' scale
+    got5.backward()
+    assert abs(got5.item() - 0.5 * want.item()) <= 1e-5 * abs(want.item()) + 1e-9
+    for a, b in zip(w5[:-1], ws[:-1]):
+        assert rel(a.grad, 0.5 * b.grad) <= tol
 
 
 # --------------------------------------------------------------------------------------------------

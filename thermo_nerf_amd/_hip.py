@@ -150,6 +150,7 @@ SIGNATURES = {
     "tn_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, _i32, _i32,
                                    C.POINTER(C.c_float), _i64, _i64, _vp, _vp, _vp, _vp]),
     "tn_frustum_positions": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "tn_frustum_from_edges": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tn_density_fwd": (C.c_int, [C.POINTER(tn_density_field), _vp, _i64, _vp, _vp]),
     "tn_field_density_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _i64, _vp, _vp, _vp]),
     "tn_field_heads_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
@@ -221,6 +222,7 @@ SIGNATURES = {
     "tn_ray_render_bwd": (C.c_int, [_vp] * 11 + [_i64, _i32, _vp, _vp, _vp, _vp]),
     "tn_image_losses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp, _vp]),
+    "tn_distortion_loss_term": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, C.c_float, _vp, _vp, _vp]),
     "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_version": (C.c_char_p, []),
 }
@@ -283,6 +285,30 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+_ZERO_BLOCKS: dict = {}
+_ZERO_BLOCK_FLOATS = 1 << 20
+
+
+def fresh_zeros(shape, device) -> torch.Tensor:
+    """A zero-initialised float32 tensor nobody else holds, WITHOUT a fill launch per call: small accumulators (a loss scalar,
+    the [num_cameras, 6] pose gradient) are handed out as successive, never reused slices of a 4 MiB block that one fill
+    cleared (a new block when it is used up; a slice keeps its block alive).  Per (device, stream): the fill is ordered with
+    that stream's kernels."""
+    n = 1
+    for k in shape:
+        n *= int(k)
+    n_al = (n + 63) // 64 * 64
+    if n_al > _ZERO_BLOCK_FLOATS // 16:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    key = (torch.device(device), current_stream())
+    blk = _ZERO_BLOCKS.get(key)
+    if blk is None or blk[1] + n_al > _ZERO_BLOCK_FLOATS:
+        blk = _ZERO_BLOCKS[key] = [torch.zeros((_ZERO_BLOCK_FLOATS,), dtype=torch.float32, device=device), 0]
+    out = blk[0][blk[1]:blk[1] + n].view(tuple(shape))
+    blk[1] += n_al
+    return out
 
 
 def make_linear(layer: torch.nn.Linear) -> tn_linear:

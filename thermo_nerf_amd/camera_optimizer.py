@@ -77,7 +77,7 @@ class _ApplyPoseAdjustment(torch.autograd.Function):
             return None, None, None, None
         g_o = None if g_o is None else _hip.require_device_tensor(g_o, "d origins")
         g_d = None if g_d is None else _hip.require_device_tensor(g_d, "d directions")
-        d_pose = torch.zeros_like(pose)
+        d_pose = _hip.fresh_zeros(tuple(pose.shape), pose.device)
         d_dirs = torch.empty_like(d) if ctx.needs_input_grad[3] else None
         _hip.check(_hip.load().tn_camera_opt_bwd(pose.data_ptr(), cam.data_ptr(), d.data_ptr(), _hip.ptr(g_o), _hip.ptr(g_d),
                                                  d.shape[0], pose.shape[0], d_pose.data_ptr(), _hip.ptr(d_dirs),

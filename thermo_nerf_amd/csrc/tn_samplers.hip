@@ -30,6 +30,24 @@ __global__ void frustum_positions_kernel(const float *__restrict__ o, const floa
     pos[i * 3 + 2] = frustum_pos(o[r * 3 + 2], d[r * 3 + 2], s, e);
 }
 
+// the training step's form: both edge columns of eucl [R,n+1] are split into contiguous starts / ends / deltas here (the
+// adjoint kernels read them per sample), so the level costs one launch instead of two strided copies + a subtraction + this
+__global__ void frustum_from_edges_kernel(const float *__restrict__ o, const float *__restrict__ d,
+                                          const float *__restrict__ eucl, long long total, int n,
+                                          float *__restrict__ pos, float *__restrict__ starts,
+                                          float *__restrict__ ends, float *__restrict__ deltas) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long r = i / n;
+    const float s = eucl[i + r], e = eucl[i + r + 1];
+    starts[i] = s;
+    ends[i] = e;
+    deltas[i] = e - s;
+    pos[i * 3 + 0] = frustum_pos(o[r * 3 + 0], d[r * 3 + 0], s, e);
+    pos[i * 3 + 1] = frustum_pos(o[r * 3 + 1], d[r * 3 + 1], s, e);
+    pos[i * 3 + 2] = frustum_pos(o[r * 3 + 2], d[r * 3 + 2], s, e);
+}
+
 __global__ void sample_initial_kernel(const float *__restrict__ lin_bins, const float *__restrict__ t_rand,
                                       const float *__restrict__ nears, const float *__restrict__ fars,
                                       long long num_rays, int n, bool lin, float *__restrict__ spacing,
@@ -378,6 +396,18 @@ int tn_frustum_positions(const float *origins, const float *directions, const fl
     const long long total = (long long)num_rays * n;
     hipLaunchKernelGGL(frustum_positions_kernel, dim3(blocks_for(total, kBlock)), dim3(kBlock), 0,
                        (hipStream_t)stream, origins, directions, starts, ends, total, n, positions);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_frustum_from_edges(const float *origins, const float *directions, const float *eucl_bins, int64_t num_rays,
+                          int32_t n, float *positions, float *starts, float *ends, float *deltas, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!origins || !directions || !eucl_bins || !positions || !starts || !ends || !deltas) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    const long long total = (long long)num_rays * n;
+    hipLaunchKernelGGL(frustum_from_edges_kernel, dim3(blocks_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       origins, directions, eucl_bins, total, n, positions, starts, ends, deltas);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

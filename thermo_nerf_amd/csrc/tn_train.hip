@@ -1629,7 +1629,10 @@ color_input_bwd_dir_kernel(int sh_shifted, const float *__restrict__ d_cin, cons
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weights, long long R, int n, float scale,
-                  float *__restrict__ loss_sum, float *__restrict__ gw) {
+                  float mult, bool pair, float *__restrict__ loss_sum, float *__restrict__ gw) {
+    // pair: loss_sum[0] is the metric (scale * sum), loss_sum[1] the loss term (mult * that) and gw the gradient of the TERM —
+    // what get_metrics_dict / get_loss_dict make of it [REF thermal_nerf_model.py:301-304] without elementwise launches between
+    const float gscale = scale * mult;
     // a wave walks several rays and a block adds ONE value to loss_sum: atomics on a single address retire one at a time in
     // L2 (~12 ns each), so one per ray made this kernel 50 us of waiting for 4096 rays
     __shared__ float red[kBlock / 64];
@@ -1658,7 +1661,7 @@ distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weig
         const float Wgt = W - Wlt - wi, WUgt = WU - WUlt - wi * ui;
         const float Si = ui * (Wlt - Wgt) - (WUlt - WUgt);
         if (live) {
-            gw[ray * n + i] = scale * (2.0f * Si + 2.0f * wi * di / 3.0f);
+            gw[ray * n + i] = gscale * (2.0f * Si + 2.0f * wi * di / 3.0f);
             loss += wi * Si + wi * wi * di / 3.0f;
         }
         cW += __shfl(iw, 63, 64);
@@ -1669,7 +1672,11 @@ distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weig
     loss_acc = wave_sum(loss_acc);
     if (lane == 0) red[threadIdx.x >> 6] = loss_acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f32(loss_sum, scale * ((red[0] + red[1]) + (red[2] + red[3])));
+    if (threadIdx.x == 0) {
+        const float block = (red[0] + red[1]) + (red[2] + red[3]);
+        atomic_add_f32(loss_sum, scale * block);
+        if (pair) atomic_add_f32(loss_sum + 1, gscale * block);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2282,7 +2289,18 @@ int tn_distortion_loss(const float *spacing_bins, const float *weights, int64_t 
     if (!spacing_bins || !weights || !loss_sum || !d_weights) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(distortion_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), 0, (hipStream_t)stream,
-                       spacing_bins, weights, (long long)num_rays, n, scale, loss_sum, d_weights);
+                       spacing_bins, weights, (long long)num_rays, n, scale, 1.0f, false, loss_sum, d_weights);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_distortion_loss_term(const float *spacing_bins, const float *weights, int64_t num_rays, int32_t n, float scale,
+                            float mult, float *loss_pair, float *d_weights, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!spacing_bins || !weights || !loss_pair || !d_weights) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(distortion_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), 0, (hipStream_t)stream,
+                       spacing_bins, weights, (long long)num_rays, n, scale, mult, true, loss_pair, d_weights);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

@@ -208,7 +208,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
         else:
             metrics = {"psnr": 10.0 * torch.log10(1.0 / torch.mean((outputs["rgb"].detach() - gt_rgb) ** 2))}
         if self.training:
-            metrics["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+            metrics["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"],
+                                                    mult=self.config.distortion_loss_mult)
         return metrics
 
     def _fused_image_losses(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]):
@@ -243,10 +244,12 @@ class ThermalNerfModel(ThermalNerfactoModel):
         if self.field.pass_rgb_gradients:
             loss_dict["rgb_loss"] = fused[0] if fused is not None else torch.nn.functional.mse_loss(gt_rgb, pred_rgb)  # REF :294-295
         if self.training:
-            loss_dict["interlevel_loss"] = self.config.interlevel_loss_mult * interlevel_loss(
-                outputs["weights_list"], outputs["ray_samples_list"])  # REF :296-300
+            loss_dict["interlevel_loss"] = interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"],
+                                                           mult=self.config.interlevel_loss_mult)  # REF :296-300
             assert metrics_dict is not None and "distortion" in metrics_dict  # REF :301
-            loss_dict["distortion_loss"] = self.config.distortion_loss_mult * metrics_dict["distortion"]
+            term = getattr(metrics_dict["distortion"], "scaled_term", None)  # the kernel's own mult * metric, when it made one
+            loss_dict["distortion_loss"] = term[1] if term is not None and term[0] == self.config.distortion_loss_mult \
+                else self.config.distortion_loss_mult * metrics_dict["distortion"]
             if self.config.predict_normals:
                 raise NotImplementedError("predict_normals is off on the ThermoNeRF path")
         thermal_batch = batch[RenderedImageModality.THERMAL.value].to(self.device)

@@ -239,11 +239,13 @@ class _GradArena:
 def _frustum_positions(o: Tensor, d: Tensor, t: "_LevelTape") -> Tuple[Tensor, Tensor]:
     R, n1 = t.eucl.shape
     n = n1 - 1
-    starts, ends = _starts_ends(t)
     pos = _f32((R * n, 3), o.device)
-    _hip.check(_hip.load().tn_frustum_positions(o.data_ptr(), d.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, n,
-                                                pos.data_ptr(), _stream()), "tn_frustum_positions")
-    return pos, ends - starts
+    t.starts, t.ends, deltas = _f32((R, n), o.device), _f32((R, n), o.device), _f32((R, n), o.device)
+    eucl = t.eucl if t.eucl.is_contiguous() else t.eucl.contiguous()
+    _hip.check(_hip.load().tn_frustum_from_edges(o.data_ptr(), d.data_ptr(), eucl.data_ptr(), R, n, pos.data_ptr(),
+                                                 t.starts.data_ptr(), t.ends.data_ptr(), deltas.data_ptr(), _stream()),
+               "tn_frustum_from_edges")
+    return pos, deltas
 
 
 def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl: Tensor, fused: bool = True) -> _LevelTape:
@@ -649,34 +651,42 @@ class RenderTrain(torch.autograd.Function):
 # regularisers
 # --------------------------------------------------------------------------------------------------
 class _Distortion(torch.autograd.Function):
+    """apply(weights, spacing_bins, mult) -> (metric, mult * metric): the distortion metric of get_metrics_dict and the loss
+    term get_loss_dict makes of it, from one launch; the saved gradient is the TERM's (already scaled by mult)."""
+
     @staticmethod
-    def forward(ctx, weights: Tensor, spacing_bins: Tensor):
+    def forward(ctx, weights: Tensor, spacing_bins: Tensor, mult: float):
         R, n = weights.shape[0], weights.shape[1]
         w = _hip.require_device_tensor(weights.reshape(R, n), "weights")
         b = _hip.require_device_tensor(spacing_bins, "spacing_bins")
-        loss = torch.zeros((1,), dtype=torch.float32, device=w.device)
+        loss = _hip.fresh_zeros((2,), w.device)
         g = _f32((R, n), w.device)
-        # the mean over rays is applied inside the kernel (loss and gradient): no elementwise launches around it
-        _hip.check(_hip.load().tn_distortion_loss(b.data_ptr(), w.data_ptr(), R, n, 1.0 / R, loss.data_ptr(), g.data_ptr(),
-                                                  _stream()), "tn_distortion_loss")
-        ctx.g, ctx.shape = g, weights.shape
-        return loss[0]
+        # the mean over rays and the loss multiplier are applied inside the kernel (loss and gradient): no elementwise launches around it
+        _hip.check(_hip.load().tn_distortion_loss_term(b.data_ptr(), w.data_ptr(), R, n, 1.0 / R, mult, loss.data_ptr(), g.data_ptr(),
+                                                       _stream()), "tn_distortion_loss_term")
+        ctx.g, ctx.shape, ctx.mult = g, weights.shape, mult
+        ctx.set_materialize_grads(False)
+        return loss[0], loss[1]
 
     @staticmethod
-    def backward(ctx, go):
-        return (go * ctx.g).view(ctx.shape), None
+    def backward(ctx, g_metric, g_term):
+        out = None if g_term is None else g_term * ctx.g
+        if g_metric is not None:  # someone differentiates the metric itself: its gradient is the term's / mult
+            t = (g_metric / ctx.mult) * ctx.g
+            out = t if out is None else out + t
+        return (None if out is None else out.view(ctx.shape)), None, None
 
 
 class _Interlevel(torch.autograd.Function):
     """Both proposal levels of NS interlevel_loss in one Function: apply(w, c, wp_0, cp_0, wp_1, cp_1, ...) — the levels'
-    kernels add into one loss scalar, each already scaled by 1 / (R n)."""
+    kernels add into one loss scalar, each already scaled by mult / (R n) (mult = the model's interlevel_loss_mult)."""
 
     @staticmethod
-    def forward(ctx, w: Tensor, c: Tensor, *levels: Tensor):
+    def forward(ctx, mult: float, w: Tensor, c: Tensor, *levels: Tensor):
         R, n = w.shape[0], w.shape[1]
         w2 = _hip.require_device_tensor(w.reshape(R, n), "weights")
         c2 = _hip.require_device_tensor(c, "bins")
-        loss = torch.zeros((1,), dtype=torch.float32, device=w2.device)
+        loss = _hip.fresh_zeros((1,), w2.device)
         lib = _hip.load()
         ctx.g, ctx.shapes = [], []
         for wp, cp in zip(levels[0::2], levels[1::2]):
@@ -684,7 +694,7 @@ class _Interlevel(torch.autograd.Function):
             wp2 = _hip.require_device_tensor(wp.reshape(R, p), "proposal weights")
             cp2 = _hip.require_device_tensor(cp, "proposal bins")
             g = _f32((R, p), wp2.device)
-            _hip.check(lib.tn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), cp2.data_ptr(), wp2.data_ptr(), R, n, p, 1.0 / (R * n),
+            _hip.check(lib.tn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), cp2.data_ptr(), wp2.data_ptr(), R, n, p, mult / (R * n),
                                               loss.data_ptr(), g.data_ptr(), _stream()), "tn_interlevel_loss")
             ctx.g.append(g)
             ctx.shapes.append(wp.shape)
@@ -692,7 +702,7 @@ class _Interlevel(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
-        out = [None, None]
+        out = [None, None, None]
         for g, shape in zip(ctx.g, ctx.shapes):
             out += [(go * g).view(shape), None]
         return tuple(out)
@@ -725,19 +735,24 @@ def image_losses(rgb: Tensor, thermal: Tensor, gt_rgb: Tensor, gt_thermal: Tenso
     return _ImageLosses.apply(rgb, thermal, gt_rgb, gt_thermal)
 
 
-def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) -> Tensor:
-    """NS losses.distortion_loss (final level), O(S) per ray on the device."""
-    return _Distortion.apply(weights_list[-1], ray_samples_list[-1].spacing_bins)
+def distortion_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence, mult: Optional[float] = None) -> Tensor:
+    """NS losses.distortion_loss (final level), O(S) per ray on the device.  With ``mult`` (non-zero) the returned metric carries
+    ``.scaled_term = (mult, mult * metric)`` computed by the same launch, which get_loss_dict picks up instead of multiplying."""
+    if not mult:
+        return _Distortion.apply(weights_list[-1], ray_samples_list[-1].spacing_bins, 1.0)[0]
+    metric, term = _Distortion.apply(weights_list[-1], ray_samples_list[-1].spacing_bins, float(mult))
+    metric.scaled_term = (float(mult), term)
+    return metric
 
 
-def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence) -> Tensor:
-    """NS losses.interlevel_loss: final level detached, one term per proposal level."""
+def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence, mult: float = 1.0) -> Tensor:
+    """``mult`` * NS losses.interlevel_loss: final level detached, one term per proposal level."""
     c = ray_samples_list[-1].spacing_bins.detach()
     w = weights_list[-1].detach()
     levels = []
     for s, wp in zip(ray_samples_list[:-1], weights_list[:-1]):
         levels += [wp, s.spacing_bins]
-    return _Interlevel.apply(w, c, *levels)
+    return _Interlevel.apply(float(mult), w, c, *levels)
 
 
 # --------------------------------------------------------------------------------------------------
