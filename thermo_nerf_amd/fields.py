@@ -157,6 +157,18 @@ class HashMLPDensityField(nn.Module):
         f.average_init_density = float(self.average_init_density)
         return f
 
+    def train_struct(self) -> _hip.tn_density_field:
+        """``c_struct(dense=False)``, kept for as long as the parameters keep their storage (an optimizer updates them in place,
+        so the pointers in the struct stay right): a training step asks for it several times.  Read-only for the caller."""
+        plist = self.__dict__.get("_tn_plist")
+        if plist is None:
+            plist = self.__dict__["_tn_plist"] = list(self.parameters())
+        ptrs = tuple([p.data_ptr() for p in plist]) + (float(self.average_init_density),)
+        hit = self.__dict__.get("_tn_train_struct")
+        if hit is None or hit[0] != ptrs:
+            hit = self.__dict__["_tn_train_struct"] = (ptrs, self.c_struct(dense=False))
+        return hit[1]
+
     def density_fn(self, positions: Tensor) -> Tensor:
         """NS Field.density_fn: positions [...,3] -> density [...,1]."""
         pos = _hip.require_device_tensor(positions, "positions")

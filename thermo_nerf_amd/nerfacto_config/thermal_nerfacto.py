@@ -118,6 +118,9 @@ class NerfactoModelConfig:
     reference grids) accumulate into 16 private dense copies that a second launch sums and hashes into the gradient
     (tn_hash_encode_bwd_spread): same-address atomics retire one at a time, and at those levels a trained scene's samples
     share a few thousand entries (DESIGN §5.6)."""
+    overlap_table_scatter: bool = True
+    """Training: the bucketed part of the field's table-gradient scatter runs on a second HIP stream beside the atomic part —
+    disjoint levels of the gradient, one waiting on the memory-side atomic unit, the other on LDS and streaming (DESIGN §5.6)."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""

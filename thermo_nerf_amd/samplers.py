@@ -51,6 +51,32 @@ def _samples_from_bins(ray_bundle: RayBundle, spacing: Tensor, eucl: Tensor, uni
     return rs
 
 
+class LazyRaySamples(RaySamples):
+    """The RaySamples of one level of a training step, built from the level's bin edges on first use.  The step itself only
+    exchanges ``spacing_bins`` / ``eucl_bins`` (what the loss kernels read); the [R,n,1] views, the broadcast frustums and
+    ``deltas`` (an elementwise launch) are made when something asks for them."""
+
+    _LAZY = frozenset(("frustums", "camera_indices", "deltas", "spacing_starts", "spacing_ends", "spacing_to_euclidean_fn",
+                       "metadata", "nears", "fars"))
+
+    def __init__(self, ray_bundle: RayBundle, spacing: Tensor, eucl: Tensor, uniform_spacing: bool = False) -> None:
+        d = self.__dict__
+        d["_bundle"], d["spacing_bins"], d["eucl_bins"], d["uniform_spacing"] = ray_bundle, spacing, eucl, uniform_spacing
+
+    def __getattribute__(self, name):
+        if name in LazyRaySamples._LAZY:
+            d = object.__getattribute__(self, "__dict__")
+            if name not in d:
+                rs = _samples_from_bins(d["_bundle"], d["spacing_bins"], d["eucl_bins"], d["uniform_spacing"])
+                for k in LazyRaySamples._LAZY:
+                    d.setdefault(k, getattr(rs, k))
+            return d[name]
+        return object.__getattribute__(self, name)
+
+    def __repr__(self) -> str:
+        return f"LazyRaySamples(spacing_bins={tuple(self.spacing_bins.shape)}, uniform_spacing={self.uniform_spacing})"
+
+
 class UniformLinDispPiecewiseSampler(nn.Module):
     """NS UniformLinDispPiecewiseSampler (the "piecewise" proposal_initial_sampler default)."""
 

@@ -136,6 +136,37 @@ class ThermalNerfactoTField(nn.Module):
                 f.prepared_f16x3 = None if self._prepared_h3 is None else self._prepared_h3.data_ptr()
         return f
 
+    def train_struct(self, prepare: bool = False) -> Optional[_hip.tn_thermal_field]:
+        """The training step's ``c_struct(dense=False)``, kept for as long as the parameters keep their storage (an optimizer
+        updates them in place, so the pointers stay right).  ``prepare``: the same struct with ``prepared`` pointing at ONE
+        buffer per module that ``tn_field_prepare`` refills on every call (the weights have changed since the last step; calls
+        on one stream are ordered) — None for a geometry the MFMA chain does not cover.  Read-only for the caller."""
+        plist = self.__dict__.get("_tn_plist")
+        if plist is None:
+            plist = self.__dict__["_tn_plist"] = list(self.parameters())
+        ptrs = tuple([p.data_ptr() for p in plist]) + (self.sh_input, float(self.average_init_density),
+                                                        bool(self.use_average_appearance_embedding),
+                                                        _hip.current_stream() if prepare else 0)
+        hit = self.__dict__.get("_tn_train_struct")
+        if hit is None or hit[0] != ptrs[:-1]:
+            hit = self.__dict__["_tn_train_struct"] = (ptrs[:-1], self.c_struct(prepare=False, dense=False))
+            self.__dict__.pop("_tn_train_prepared", None)
+        raw = hit[1]
+        if not prepare:
+            return raw
+        lib = _hip.load()
+        prep = self.__dict__.get("_tn_train_prepared")
+        if prep is None or prep[0] != ptrs[-1]:
+            nbytes = lib.tn_field_prepare_bytes(raw)
+            buf = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=plist[0].device)
+            st = _hip.tn_thermal_field.from_buffer_copy(raw)
+            st.prepared = buf.data_ptr() if nbytes > 0 else None
+            prep = self.__dict__["_tn_train_prepared"] = (ptrs[-1], buf, st, nbytes)
+        if prep[3] == 0:
+            return None
+        _hip.check(lib.tn_field_prepare(raw, prep[1].data_ptr(), prep[3], _hip.current_stream()), "tn_field_prepare")
+        return prep[2]
+
     # ------------------------------------------------------------------------------------------------
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
         """NS NerfactoField.get_density: (density [...,1], geo embedding [...,geo_feat_dim])."""

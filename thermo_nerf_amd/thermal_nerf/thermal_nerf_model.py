@@ -355,9 +355,20 @@ class ThermalNerfModel(ThermalNerfactoModel):
         bumping them — so every training forward, after which weights are about to change, calls this."""
         self._struct_key = None
         self.field._prepared_key = None
-        for mod in self.modules():
-            if hasattr(mod, "_dense_key"):
-                mod._dense_key = None
+        mods = self.__dict__.get("_tn_dense_modules")
+        if mods is None:  # the module tree is fixed after populate_modules: walk it once, not every training step
+            mods = self.__dict__["_tn_dense_modules"] = [m for m in self.modules() if hasattr(m, "_dense_key")]
+        for mod in mods:
+            mod._dense_key = None
+
+    def named_parameter_lists(self) -> Tuple[List[str], List[nn.Parameter]]:
+        """(names, parameters) in ``named_parameters()`` order, walked once (the training step passes every parameter to its
+        autograd Function each iteration; the Parameter objects of a built model do not change, only their values)."""
+        hit = self.__dict__.get("_tn_named_params")
+        if hit is None:
+            named = list(self.named_parameters())
+            hit = self.__dict__["_tn_named_params"] = ([n for n, _ in named], [p for _, p in named])
+        return hit
 
     # --- fused: one C-ABI call ------------------------------------------------------------------------
     def _c_structs(self):

@@ -23,7 +23,7 @@ from torch import Tensor
 
 from . import _hip
 from .rays import RayBundle
-from .samplers import linspace_bins, pdf_positions, _samples_from_bins
+from .samplers import LazyRaySamples, linspace_bins, pdf_positions
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -66,13 +66,34 @@ def _atomic_levels(lib, grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor
         _hip.check(lib.tn_hash_encode_bwd_levels(*args, _stream()), "tn_hash_encode_bwd_levels")
 
 
-def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True) -> None:
+_SIDE_STREAMS: Dict = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    """the second stream of a device's training step (one per (device, main stream))"""
+    key = (dev, _stream())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True,
+                    overlap: bool = False, side_work=None) -> None:
     """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
     ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 256, enough table slices: the
     field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
     summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 25 B of scratch per (sample, level, corner pair)), the
     coarser levels keep the atomics.  An int (tests): bucketed from that level on, whatever the library advises.
-    ``spread`` (config.spread_coarse_scatter): the coarsest levels of the atomic part accumulate in private dense copies."""
+    ``spread`` (config.spread_coarse_scatter): the coarsest levels of the atomic part accumulate in private dense copies.
+    ``overlap`` (config.overlap_table_scatter): the two parts write disjoint levels of d_table and wait on different units (the
+    memory-side atomic unit / LDS + streaming), so the bucketed part runs on a second stream beside the atomic part; the
+    calling stream continues when both are done.  ``side_work``: a callable with more launches that depend on neither part
+    (the step's ray-level adjoints); it runs behind the bucketed part on the second stream, or last on the calling stream."""
+    if side_work is not None and not overlap:
+        hash_encode_bwd(grid, space, pos, d_enc, d_table, bucketed, spread)
+        side_work()
+        return
     lib = _hip.load()
     n = pos.shape[0]
     first = -1
@@ -83,17 +104,35 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
     need = lib.tn_hash_encode_bwd_sorted_workspace_bytes(grid, n, first) if first >= 0 else 0
     if not need:
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, grid.num_levels, spread)
+        if side_work is not None:
+            side_work()
         return
-    if first > 0:
-        _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
     try:
         ws = torch.empty(need, dtype=torch.uint8, device=pos.device)  # 25 B per (sample, level, corner pair): 0.14-0.6 GB, from torch's caching allocator
     except torch.cuda.OutOfMemoryError:  # no room for the records: the same sums through the global atomics
+        _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
         _hip.check(lib.tn_hash_encode_bwd_levels(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
                                                  grid.num_levels, _stream()), "tn_hash_encode_bwd_levels")
+        if side_work is not None:
+            side_work()
         return
+    if overlap and first > 0:
+        main, side = torch.cuda.current_stream(pos.device), _side_stream(pos.device)
+        side.wait_stream(main)  # d_enc, positions and the cleared d_table are the main stream's work so far
+        with torch.cuda.stream(side):
+            _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
+                                                     ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
+            if side_work is not None:
+                side_work()
+        _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
+        main.wait_stream(side)  # also what keeps `ws`, d_enc and pos (main-stream allocations) from being reused too early
+        return
+    if first > 0:
+        _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
     _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first, ws.data_ptr(),
                                              need, _stream()), "tn_hash_encode_bwd_sorted")
+    if side_work is not None:
+        side_work()
 
 
 def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor:
@@ -342,8 +381,8 @@ class RenderTrain(torch.autograd.Function):
         S = cfg.num_nerf_samples_per_ray
         # use_same_proposal_network: ONE HashMLPDensityField serves both levels [REF thermal_nerf_model.py:127-139]
         nets = len(model.proposal_networks)
-        prop_structs = [model.proposal_networks[min(i, nets - 1)].c_struct(dense=False) for i in range(2)]
-        fld = model.field.c_struct(prepare=False, dense=False)
+        prop_structs = [model.proposal_networks[min(i, nets - 1)].train_struct() for i in range(2)]
+        fld = model.field.train_struct()
         anneal = float(model.proposal_sampler._anneal)
         uniform = int(model.proposal_sampler.initial_sampler.uniform_spacing)  # REF thermal_nerf_model.py:164-170
 
@@ -409,9 +448,9 @@ class RenderTrain(torch.autograd.Function):
         fused = None
         tape_free = bool(getattr(cfg, "tape_free_training", True))
         if cfg.fused_train_forward or tape_free:
-            fused = model.field.c_struct(prepare=True, dense=False)  # MFMA fragments of the CURRENT weights (rebuilt per step)
-            if not fused.prepared:
-                fused = None  # geometry the MFMA chain does not cover: stage-by-stage entry points below
+            # MFMA fragments of the CURRENT weights (rebuilt per step); None: geometry the MFMA chain does not cover -> the
+            # stage-by-stage entry points below
+            fused = model.field.train_struct(prepare=True)
         tape_free = tape_free and fused is not None
         h1 = bo = cin = c1 = c2 = t1 = t2 = None
         if tape_free:
@@ -481,8 +520,8 @@ class RenderTrain(torch.autograd.Function):
         ctx.acc, ctx.o, ctx.d, ctx.cam = acc, o, d, cam
         ctx.updated = bool(updated)
         ctx.tape_free = tape_free
-        ctx.param_names = [n for n, _ in model.named_parameters()]
-        ctx.params = {n: p for n, p in zip(ctx.param_names, params)}
+        ctx.param_names = model.named_parameter_lists()[0]
+        ctx.params = dict(zip(ctx.param_names, params))
         # ctx must not hold a tensor OBJECT that is also returned as a differentiable output (output -> grad_fn -> ctx ->
         # output is a cycle the collector cannot see: the step's whole tape would leak); return fresh views instead
         outs = (rgb, thermal, acc.view(R, 1), tapes[0].weights[..., None], tapes[1].weights[..., None], f.weights[..., None],
@@ -502,7 +541,7 @@ class RenderTrain(torch.autograd.Function):
         h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s = ctx.acts
         R, S = f.weights.shape
         N = R * S
-        fld = model.field.c_struct(prepare=False, dense=False)
+        fld = model.field.train_struct()
         like = ctx.params
         grads: Dict[str, Tensor] = {}
         # camera-pose optimisation: the ray origins / directions carry gradient (NS CameraOptimizer.apply_to_raybundle)
@@ -563,23 +602,31 @@ class RenderTrain(torch.autograd.Function):
                                               _hip.ptr(g_ray), f.pos.data_ptr() if ray_grads else None, _hip.ptr(g_pos),
                                               C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
                        "tn_field_bwd_fused")
+            zeros("field.mlp_base.encoder.hash_table")
             if g_ray is not None:
-                # mlp_head.0's ray-level part: bias, SH and appearance weight columns, the embedding gradient
-                g_cin = _f32((R, 64), dev) if sh_grads else None
-                _hip.check(lib.tn_ray_head_bwd(fld, ctx.d.data_ptr(), ctx.cam.data_ptr(), R, g_ray.data_ptr(),
-                                               grads["field.mlp_head.layers.0.weight"].data_ptr(),
-                                               zeros("field.mlp_head.layers.0.bias").data_ptr(),
-                                               zeros("field.embedding_appearance.embedding.weight").data_ptr(), _hip.ptr(g_cin),
-                                               _stream()), "tn_ray_head_bwd")
-                if sh_grads:  # ... and on through the SH basis to the directions (camera-pose optimisation, differentiable-SH switch)
-                    _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, 1, None, 0, None,
-                                                      ctx.d.data_ptr(), ray_grads[1].data_ptr(), _stream()), "tn_color_input_bwd")
-            hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread)
-            if ray_grads:
-                starts, ends = _starts_ends(f)
-                _hip.check(lib.tn_frustum_positions_bwd(g_pos.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S,
-                                                        ray_grads[0].data_ptr(), ray_grads[1].data_ptr(), _stream()),
-                           "tn_frustum_positions_bwd")
+                for name in ("field.mlp_head.layers.0.bias", "field.embedding_appearance.embedding.weight"):
+                    zeros(name)
+            g_cin = _f32((R, 64), dev) if g_ray is not None and sh_grads else None
+
+            def ray_level_adjoints() -> None:  # nothing here touches the table gradient: queued beside its scatter
+                if g_ray is not None:
+                    # mlp_head.0's ray-level part: bias, SH and appearance weight columns, the embedding gradient
+                    _hip.check(lib.tn_ray_head_bwd(fld, ctx.d.data_ptr(), ctx.cam.data_ptr(), R, g_ray.data_ptr(),
+                                                   grads["field.mlp_head.layers.0.weight"].data_ptr(),
+                                                   grads["field.mlp_head.layers.0.bias"].data_ptr(),
+                                                   grads["field.embedding_appearance.embedding.weight"].data_ptr(), _hip.ptr(g_cin),
+                                                   _stream()), "tn_ray_head_bwd")
+                    if sh_grads:  # ... and on through the SH basis to the directions (camera-pose optimisation, differentiable-SH switch)
+                        _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, 1, None, 0, None,
+                                                          ctx.d.data_ptr(), ray_grads[1].data_ptr(), _stream()), "tn_color_input_bwd")
+                if ray_grads:
+                    starts, ends = _starts_ends(f)
+                    _hip.check(lib.tn_frustum_positions_bwd(g_pos.data_ptr(), starts.data_ptr(), ends.data_ptr(), R, S,
+                                                            ray_grads[0].data_ptr(), ray_grads[1].data_ptr(), _stream()),
+                               "tn_frustum_positions_bwd")
+
+            hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, grads["field.mlp_base.encoder.hash_table"], bucketed, spread,
+                            getattr(cfg, "overlap_table_scatter", True), ray_level_adjoints)
             return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
         ldb = bo.shape[1]
         g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass
@@ -623,7 +670,8 @@ class RenderTrain(torch.autograd.Function):
             g_h1 = _f32((N, W), dev)
             linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
             linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
-        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread)
+        hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread,
+                        getattr(cfg, "overlap_table_scatter", True))
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
         return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
@@ -637,7 +685,7 @@ class RenderTrain(torch.autograd.Function):
                     continue
                 t = ctx.tapes[lvl]
                 which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
-                net = model.proposal_networks[which].c_struct(dense=False)
+                net = model.proposal_networks[which].train_struct()
                 _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
                                     ray_grads, chained, bucketed, exp_min, bool(getattr(model.config, "spread_coarse_scatter", True)))
 
@@ -780,7 +828,7 @@ def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = N
     jitter = _hip.require_device_tensor(jitter, "jitter")
     sampler = model.proposal_sampler
     updated = sampler._steps_since_update > sampler.update_sched(sampler._step) or sampler._step < 10
-    params = [p for _, p in model.named_parameters()]
+    params = model.named_parameter_lists()[1]
     (rgb, thermal, acc, w0, w1, w2, depth, expected, pd0, pd1, sp0, sp1, sp2, eu0, eu1, eu2) = RenderTrain.apply(
         model, o, d, nears, fars, cam, jitter, updated, *params)
     if updated:
@@ -788,7 +836,7 @@ def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = N
     return {
         "rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": expected,
         "weights_list": [w0, w1, w2],
-        "ray_samples_list": [_samples_from_bins(ray_bundle, sp, eu, sampler.initial_sampler.uniform_spacing)
+        "ray_samples_list": [LazyRaySamples(ray_bundle, sp, eu, sampler.initial_sampler.uniform_spacing)
                              for sp, eu in ((sp0, eu0), (sp1, eu1), (sp2, eu2))],
         "prop_depth_0": pd0, "prop_depth_1": pd1, "thermal": thermal,
     }

@@ -19,9 +19,9 @@ rec = []
 stats = []
 
 
-def timed(grid, space, pos, d_enc, d_table, bucketed=False):
+def timed(grid, space, pos, d_enc, d_table, bucketed=False, spread=True):
     if grid.num_levels != 16:
-        return orig(grid, space, pos, d_enc, d_table, bucketed)
+        return orig(grid, space, pos, d_enc, d_table, bucketed, spread)
     lib = _hip.load()
     n = pos.shape[0]
     for l in range(16):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--taped", action="store_true", help="config.tape_free_training = False (the round-2 taped forward + chained backward)")
     ap.add_argument("--one-launch", action="store_true", help="config.fused_backward_split = False")
     ap.add_argument("--no-spread", action="store_true", help="config.spread_coarse_scatter = False")
+    ap.add_argument("--no-overlap", action="store_true", help="config.overlap_table_scatter = False")
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
@@ -34,7 +35,8 @@ def main():
     dev = torch.device("cuda:0")
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt,
                                  bucketed_table_scatter=not a.atomic_scatter, tape_free_training=not a.taped,
-                                 fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread)
+                                 fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread,
+                                 overlap_table_scatter=not a.no_overlap)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
@@ -87,14 +89,21 @@ def main():
             for _ in range(100):
                 step(a.start_step + a.warmup + i)
                 i += 1
+            issued = time.perf_counter() - t0  # the host has queued the window; what is left until the sync is the device's backlog
             torch.cuda.synchronize()
-            marks.append((i, time.perf_counter() - t0))
+            marks.append((i, time.perf_counter() - t0, issued))
             if marks[-1][1] >= a.seconds:
                 break
         print("after: ", smi(), flush=True)
+        prev = 0.0
+        per = []
+        for _, t_end, t_issued in marks:
+            per.append(f"{(t_end - prev) * 10:.2f}({(t_end - t_issued) * 1e3:.1f})")
+            prev = t_end
+        print("ms/step per 100-step window (device backlog in ms when the host finished queueing it):", " ".join(per), flush=True)
         half = next(k for k, m in enumerate(marks) if m[1] >= marks[-1][1] / 2)
-        n1, t1 = marks[half]
-        n2, t2 = marks[-1]
+        n1, t1 = marks[half][:2]
+        n2, t2 = marks[-1][:2]
         first, second = t1 / n1, (t2 - t1) / max(n2 - n1, 1)
         print(f"rays {R} S {a.samples}: sustained {n2} consecutive steps in {t2:.1f} s: first half {first * 1e3:.3f} ms/step, "
               f"second half {second * 1e3:.3f} ms/step ({R / second / 1e6:.3f} M rays/s)")
