@@ -53,3 +53,29 @@ def test_exp_map_se3_is_the_matrix_exponential_of_the_twist():
     so3 = T.exp_map_SO3xR3(tangent)
     assert (so3[:, :, :3] - want[:, :, :3]).abs().max().item() <= 1e-12 and torch.equal(so3[:, :, 3], u)
     assert (_so3xr3_exp(tangent) - so3).abs().max().item() <= 1e-12
+
+
+def test_lazy_ray_samples_materialise_to_the_eager_ones():
+    """The training outputs' ray_samples_list entries (LazyRaySamples) are RaySamples whose [R,n,1] views, frustums and
+    deltas appear on first use and equal what RayBundle.get_ray_samples builds eagerly [REF thermal_nerf_model.py:272-273]."""
+    import torch
+
+    from thermo_nerf_amd.rays import RayBundle, RaySamples
+    from thermo_nerf_amd.samplers import LazyRaySamples, _samples_from_bins
+
+    g = torch.Generator().manual_seed(3)
+    R, n = 5, 7
+    rb = RayBundle(origins=torch.rand(R, 3, generator=g), directions=torch.rand(R, 3, generator=g),
+                   pixel_area=torch.rand(R, 1, generator=g), camera_indices=torch.arange(R)[:, None],
+                   nears=torch.zeros(R, 1), fars=torch.ones(R, 1))
+    spacing = torch.sort(torch.rand(R, n + 1, generator=g), dim=1).values
+    eucl = spacing * 3.0
+    lazy, eager = LazyRaySamples(rb, spacing, eucl, True), _samples_from_bins(rb, spacing, eucl, True)
+    assert isinstance(lazy, RaySamples) and "deltas" not in lazy.__dict__ and lazy.uniform_spacing is True
+    assert lazy.spacing_bins is spacing and lazy.eucl_bins is eucl
+    assert lazy.shape == eager.shape == (R, n)
+    for name in ("deltas", "spacing_starts", "spacing_ends", "camera_indices", "nears", "fars"):
+        assert torch.equal(getattr(lazy, name), getattr(eager, name)), name
+    for name in ("origins", "directions", "starts", "ends", "pixel_area"):
+        assert torch.equal(getattr(lazy.frustums, name), getattr(eager.frustums, name)), name
+    assert lazy.metadata is None and lazy.spacing_to_euclidean_fn is None
