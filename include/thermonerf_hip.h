@@ -531,6 +531,11 @@ int tn_distortion_loss_term(const float *spacing_bins, const float *weights, int
  * d_wp [R,p] (=) = scale * d(sum)/dwp.  p <= 1024.  Several levels may add into the same loss_sum. */
 int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
                        int32_t p, float scale, float *loss_sum, float *d_wp, void *stream);
+/* every proposal level of NS interlevel_loss in one launch (the levels are independent): cp / wp / d_wp are HOST arrays of
+ * num_levels (<= 4) device pointers, p the levels' sample counts; same sums as num_levels calls of tn_interlevel_loss. */
+int tn_interlevel_loss_levels(const float *c, const float *w, int64_t num_rays, int32_t n, int32_t num_levels,
+                              const float *const *cp, const float *const *wp, const int32_t *p, float scale, float *loss_sum,
+                              float *const *d_wp, void *stream);
 
 /* library identification: returns a static string "thermonerf_hip <version> gfx950". */
 const char *tn_version(void);

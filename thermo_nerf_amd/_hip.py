@@ -224,6 +224,8 @@ SIGNATURES = {
     "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_distortion_loss_term": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, C.c_float, _vp, _vp, _vp]),
     "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
+    "tn_interlevel_loss_levels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_int32), C.c_float, _vp, C.POINTER(C.c_void_p), _vp]),
     "tn_version": (C.c_char_p, []),
 }
 

@@ -1693,12 +1693,28 @@ __device__ __forceinline__ int upper_bound(const float *a, int len, float x) {  
     return lo;
 }
 
-__global__ void __launch_bounds__(kBlock)
-interlevel_kernel(const float *__restrict__ c, const float *__restrict__ w, const float *__restrict__ cp,
-                  const float *__restrict__ wp, long long R, int n, int p, float scale, float *__restrict__ loss_sum,
-                  float *__restrict__ g_wp) {
+// all proposal levels of the loss in one launch: blockIdx.y = level (the levels are independent and each is latency-bound)
+constexpr int kMaxInterlevels = 4;
+struct InterlevelArgs {
+    const float *c, *w;
+    const float *cp[kMaxInterlevels], *wp[kMaxInterlevels];
+    float *g_wp[kMaxInterlevels];
+    int p[kMaxInterlevels];
+    long long R;
+    int n;
+    float scale;
+    float *loss_sum;
+};
+
+__global__ void __launch_bounds__(kBlock) interlevel_kernel(InterlevelArgs a) {
     extern __shared__ float lds[];
     __shared__ float red[kBlock / 64];  // one atomic on loss_sum per block (see distortion_kernel)
+    const float *__restrict__ c = a.c, *__restrict__ w = a.w;
+    const float *__restrict__ cp = a.cp[blockIdx.y], *__restrict__ wp = a.wp[blockIdx.y];
+    float *__restrict__ g_wp = a.g_wp[blockIdx.y], *__restrict__ loss_sum = a.loss_sum;
+    const long long R = a.R;
+    const int n = a.n, p = a.p[blockIdx.y];
+    const float scale = a.scale;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float loss_acc = 0.0f;
     for (long long ray = (long long)blockIdx.x * (kBlock / 64) + wave; ray < R; ray += (long long)gridDim.x * (kBlock / 64)) {
@@ -2305,17 +2321,32 @@ int tn_distortion_loss_term(const float *spacing_bins, const float *weights, int
     return TN_OK;
 }
 
-int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
-                       int32_t p, float scale, float *loss_sum, float *d_wp, void *stream) {
-    if (num_rays == 0) return TN_OK;
-    if (!c || !w || !cp || !wp || !loss_sum || !d_wp) return TN_ERR_NULL;
-    if (num_rays < 0 || n < 1 || p < 1 || p > kMaxP) return TN_ERR_SHAPE;
-    const size_t lds = (size_t)(kBlock / 64) * 4 * (p + 2) * sizeof(float);
+int tn_interlevel_loss_levels(const float *c, const float *w, int64_t num_rays, int32_t n, int32_t num_levels,
+                              const float *const *cp, const float *const *wp, const int32_t *p, float scale, float *loss_sum,
+                              float *const *d_wp, void *stream) {
+    if (num_rays == 0 || num_levels == 0) return TN_OK;
+    if (!c || !w || !cp || !wp || !p || !loss_sum || !d_wp) return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1 || num_levels < 0 || num_levels > kMaxInterlevels) return TN_ERR_SHAPE;
+    InterlevelArgs a{};
+    a.c = c; a.w = w; a.R = (long long)num_rays; a.n = n; a.scale = scale; a.loss_sum = loss_sum;
+    int pmax = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        if (!cp[l] || !wp[l] || !d_wp[l]) return TN_ERR_NULL;
+        if (p[l] < 1 || p[l] > kMaxP) return TN_ERR_SHAPE;
+        a.cp[l] = cp[l]; a.wp[l] = wp[l]; a.g_wp[l] = d_wp[l]; a.p[l] = p[l];
+        pmax = p[l] > pmax ? p[l] : pmax;
+    }
+    const size_t lds = (size_t)(kBlock / 64) * 4 * (pmax + 2) * sizeof(float);
     if (lds > 48 * 1024 && !tn_ensure_dynamic_lds<interlevel_kernel>(lds)) return TN_ERR_LAUNCH;
-    hipLaunchKernelGGL(interlevel_kernel, dim3(grid_for(num_rays, kBlock / 64, 512)), dim3(kBlock), lds, (hipStream_t)stream, c, w,
-                       cp, wp, (long long)num_rays, n, p, scale, loss_sum, d_wp);
+    hipLaunchKernelGGL(interlevel_kernel, dim3(grid_for(num_rays, kBlock / 64, 512), num_levels), dim3(kBlock), lds,
+                       (hipStream_t)stream, a);
     TN_LAUNCH_CHECK();
     return TN_OK;
+}
+
+int tn_interlevel_loss(const float *c, const float *w, const float *cp, const float *wp, int64_t num_rays, int32_t n,
+                       int32_t p, float scale, float *loss_sum, float *d_wp, void *stream) {
+    return tn_interlevel_loss_levels(c, w, num_rays, n, 1, &cp, &wp, &p, scale, loss_sum, &d_wp, stream);
 }
 
 int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal, const float *gt_thermal, int64_t num_rays,

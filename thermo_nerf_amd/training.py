@@ -737,15 +737,21 @@ class _Interlevel(torch.autograd.Function):
         loss = _hip.fresh_zeros((1,), w2.device)
         lib = _hip.load()
         ctx.g, ctx.shapes = [], []
-        for wp, cp in zip(levels[0::2], levels[1::2]):
+        L = len(levels) // 2
+        cps, wps, gs, ps = (C.c_void_p * L)(), (C.c_void_p * L)(), (C.c_void_p * L)(), (C.c_int32 * L)()
+        keep = []
+        for k, (wp, cp) in enumerate(zip(levels[0::2], levels[1::2])):
             p = wp.shape[1]
             wp2 = _hip.require_device_tensor(wp.reshape(R, p), "proposal weights")
             cp2 = _hip.require_device_tensor(cp, "proposal bins")
             g = _f32((R, p), wp2.device)
-            _hip.check(lib.tn_interlevel_loss(c2.data_ptr(), w2.data_ptr(), cp2.data_ptr(), wp2.data_ptr(), R, n, p, mult / (R * n),
-                                              loss.data_ptr(), g.data_ptr(), _stream()), "tn_interlevel_loss")
+            cps[k], wps[k], gs[k], ps[k] = cp2.data_ptr(), wp2.data_ptr(), g.data_ptr(), p
+            keep += [wp2, cp2]
             ctx.g.append(g)
             ctx.shapes.append(wp.shape)
+        # both levels in one launch (they are independent and each is latency-bound), each scaled by mult / (R n)
+        _hip.check(lib.tn_interlevel_loss_levels(c2.data_ptr(), w2.data_ptr(), R, n, L, cps, wps, ps, mult / (R * n), loss.data_ptr(),
+                                                 gs, _stream()), "tn_interlevel_loss_levels")
         return loss[0]
 
     @staticmethod
