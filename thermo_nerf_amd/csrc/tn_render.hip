@@ -161,7 +161,11 @@ __device__ __forceinline__ void store_bins(const float *bins, int nb, float s_ne
         for (int j = lane; j < nb; j += 64) eucl[r * nb + j] = spacing_to_eucl<true>(bins[j], s_near, s_far, lin);
 }
 
-__global__ void __launch_bounds__(kBlock) proposal_kernel(PropArgs a, int nmax, int nbmax) {
+// One ray per wave is a chain of dependent round trips (4 + 2 chunks of gathers, scans, two binary-search resamples): the
+// kernel is latency-bound and wants every ray of a training batch resident at once.  At the 176 VGPRs hipcc takes when left
+// alone, 2 waves fit a SIMD and a 4096-ray batch runs as two rounds (101 us); capped at 128 (42 spilled dwords, L1-resident
+// scratch) all 4096 waves are resident: 85 us.
+__global__ void __launch_bounds__(kBlock, 4) proposal_kernel(PropArgs a, int nmax, int nbmax) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int in0 = 2 * a.net[0].g.num_levels, in1 = 2 * a.net[1].g.num_levels;
     float *wbase0 = smem;
