@@ -32,8 +32,15 @@ def _f32(shape, dev) -> Tensor:
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
+_STREAM_OVERRIDE: List[Optional[int]] = [None]
+
+
 def _stream():
-    return _hip.current_stream()
+    """the HIP stream the next launch goes to: torch's current stream, or the second stream of the step while its section of
+    the backward is being queued (set explicitly: `with torch.cuda.stream(...)` costs ~0.1 ms of host time per use — its
+    enter / exit look the current device up through torch.cuda.is_available() and os.environ)"""
+    forced = _STREAM_OVERRIDE[0]
+    return _hip.current_stream() if forced is None else forced
 
 
 # --------------------------------------------------------------------------------------------------
@@ -69,13 +76,14 @@ def _atomic_levels(lib, grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor
 _SIDE_STREAMS: Dict = {}
 
 
-def _side_stream(dev) -> "torch.cuda.Stream":
-    """the second stream of a device's training step (one per (device, main stream))"""
-    key = (dev, _stream())
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return st
+def _stream_pair(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream"]:
+    """(torch's current stream on ``dev``, the second stream of that stream's training step), as Stream objects — looked up
+    by the raw handle, made once per (device, main stream)"""
+    key = (dev, _hip.current_stream())
+    pair = _SIDE_STREAMS.get(key)
+    if pair is None:
+        pair = _SIDE_STREAMS[key] = (torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev))
+    return pair
 
 
 def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True,
@@ -117,13 +125,16 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
             side_work()
         return
     if overlap and first > 0:
-        main, side = torch.cuda.current_stream(pos.device), _side_stream(pos.device)
+        main, side = _stream_pair(pos.device)
         side.wait_stream(main)  # d_enc, positions and the cleared d_table are the main stream's work so far
-        with torch.cuda.stream(side):
+        _STREAM_OVERRIDE[0] = side.cuda_stream  # launches only (no torch op, no allocation) until it is cleared
+        try:
             _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
                                                      ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
             if side_work is not None:
                 side_work()
+        finally:
+            _STREAM_OVERRIDE[0] = None
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
         main.wait_stream(side)  # also what keeps `ws`, d_enc and pos (main-stream allocations) from being reused too early
         return

@@ -53,16 +53,25 @@ def main():
     cam = torch.randint(0, 8, (R, 1), generator=g).to(dev)
     batch = {"image": torch.rand(R, 3, generator=g).to(dev), "thermal": torch.rand(R, 1, generator=g).to(dev)}
 
+    phase = [0.0] * 5
+
     def step(i):
+        t0 = time.perf_counter()
         model.set_step(i)
         rb = RayBundle(origins=o, directions=d, camera_indices=cam)
         out = model(rb)
+        t1 = time.perf_counter()
         metrics = model.get_metrics_dict(out, batch)
         loss = sum(model.get_loss_dict(out, batch, metrics).values())
+        t2 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        t3 = time.perf_counter()
         if not a.no_opt:
             opt.step()
+        t4 = time.perf_counter()
+        for k, dt in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            phase[k] += dt
         return loss
 
     def smi():
@@ -91,16 +100,17 @@ def main():
                 i += 1
             issued = time.perf_counter() - t0  # the host has queued the window; what is left until the sync is the device's backlog
             torch.cuda.synchronize()
-            marks.append((i, time.perf_counter() - t0, issued))
+            marks.append((i, time.perf_counter() - t0, issued, tuple(phase)))
+            phase[:] = [0.0] * 5
             if marks[-1][1] >= a.seconds:
                 break
         print("after: ", smi(), flush=True)
         prev = 0.0
         per = []
-        for _, t_end, t_issued in marks:
-            per.append(f"{(t_end - prev) * 10:.2f}({(t_end - t_issued) * 1e3:.1f})")
+        for _, t_end, t_issued, ph in marks:
+            per.append(f"{(t_end - prev) * 10:.2f}({(t_end - t_issued) * 1e3:.1f}|" + "/".join(f"{x * 10:.2f}" for x in ph[:4]) + ")")
             prev = t_end
-        print("ms/step per 100-step window (device backlog in ms when the host finished queueing it):", " ".join(per), flush=True)
+        print("ms/step per 100-step window (device backlog in ms when the host finished queueing it | host ms per step in forward / losses / backward / optimizer):", " ".join(per), flush=True)
         half = next(k for k, m in enumerate(marks) if m[1] >= marks[-1][1] / 2)
         n1, t1 = marks[half][:2]
         n2, t2 = marks[-1][:2]
