@@ -76,14 +76,14 @@ def _atomic_levels(lib, grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor
 _SIDE_STREAMS: Dict = {}
 
 
-def _stream_pair(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream"]:
-    """(torch's current stream on ``dev``, the second stream of that stream's training step), as Stream objects — looked up
-    by the raw handle, made once per (device, main stream)"""
+def _step_streams(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch.cuda.Stream"]:
+    """(torch's current stream on ``dev``, the second and the third stream of that stream's training step), as Stream objects —
+    looked up by the raw handle, made once per (device, main stream)"""
     key = (dev, _hip.current_stream())
-    pair = _SIDE_STREAMS.get(key)
-    if pair is None:
-        pair = _SIDE_STREAMS[key] = (torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev))
-    return pair
+    trio = _SIDE_STREAMS.get(key)
+    if trio is None:
+        trio = _SIDE_STREAMS[key] = (torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return trio
 
 
 def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True,
@@ -97,7 +97,8 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
     ``overlap`` (config.overlap_table_scatter): the two parts write disjoint levels of d_table and wait on different units (the
     memory-side atomic unit / LDS + streaming), so the bucketed part runs on a second stream beside the atomic part; the
     calling stream continues when both are done.  ``side_work``: a callable with more launches that depend on neither part
-    (the step's ray-level adjoints); it runs behind the bucketed part on the second stream, or last on the calling stream."""
+    (the step's ray-level adjoints): queued on the calling stream behind the atomic part, before the join — the bucketed part
+    on the second stream is the longer of the two."""
     if side_work is not None and not overlap:
         hash_encode_bwd(grid, space, pos, d_enc, d_table, bucketed, spread)
         side_work()
@@ -125,17 +126,17 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
             side_work()
         return
     if overlap and first > 0:
-        main, side = _stream_pair(pos.device)
+        main, side, _ = _step_streams(pos.device)
         side.wait_stream(main)  # d_enc, positions and the cleared d_table are the main stream's work so far
         _STREAM_OVERRIDE[0] = side.cuda_stream  # launches only (no torch op, no allocation) until it is cleared
         try:
             _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
                                                      ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
-            if side_work is not None:
-                side_work()
         finally:
             _STREAM_OVERRIDE[0] = None
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
+        if side_work is not None:
+            side_work()  # behind the atomic part: the bucketed part is the longer of the two (timeline in DESIGN 5.6)
         main.wait_stream(side)  # also what keeps `ws`, d_enc and pos (main-stream allocations) from being reused too early
         return
     if first > 0:
@@ -325,12 +326,14 @@ def _proposal_level_fwd(net_struct, o: Tensor, d: Tensor, spacing: Tensor, eucl:
     return t
 
 
-def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, g_d: Tensor) -> None:
+def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, g_d: Tensor, keep: Optional[list] = None) -> None:
     """d loss / d (origins, directions) through the sample positions of one level (camera-pose optimisation)."""
     lib = _hip.load()
     n = t.pos.shape[0]
     R, per = t.deltas.shape
     g_pos = _f32((n, 3), g_enc.device)
+    if keep is not None:
+        keep.append(g_pos)
     _hip.check(lib.tn_hash_encode_bwd_input(grid, space, t.pos.data_ptr(), g_enc.data_ptr(), n, g_pos.data_ptr(), _stream()),
                "tn_hash_encode_bwd_input")
     starts, ends = _starts_ends(t)
@@ -340,7 +343,9 @@ def _ray_grads_from_enc(grid, space, t: _LevelTape, g_enc: Tensor, g_o: Tensor, 
 
 def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str, Tensor], prefix: str, like: Dict,
                         ray_grads: Optional[Tuple[Tensor, Tensor]] = None, chained: bool = True, bucketed: bool = False,
-                        exp_min: float = -15.0, spread: bool = True) -> None:
+                        exp_min: float = -15.0, spread: bool = True, keep: Optional[list] = None) -> None:
+    """``keep``: a list the temporaries are appended to — the caller queues this level on another stream than the allocator's
+    and holds them until that stream has been joined (the tape-free / fused form only: no torch op in between)."""
     lib = _hip.load()
     n = t.pos.shape[0]
     g_density = weights_bwd(t.deltas, t.density.view(t.deltas.shape), g_w)
@@ -352,6 +357,8 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
             grads[k] = like.get(k)  # `like` is the step's _GradArena: zero-filled views
     E = t.enc.shape[1]
     g_enc = _f32((n, E), g_w.device)
+    if keep is not None:
+        keep += [g_density, g_enc, g_w]
     if t.hid is None:
         # the fused forward's counterpart: trunc_exp backward + both Linear layers' adjoints in one launch, hidden layer recomputed
         _hip.check(lib.tn_density_bwd_train(net_struct, t.enc.data_ptr(), t.raw.data_ptr(), t.sel.data_ptr(), g_density.data_ptr(), n,
@@ -372,7 +379,7 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
             linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
     hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed, spread)
     if ray_grads is not None:
-        _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads)
+        _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads, keep=keep)
 
 
 class RenderTrain(torch.autograd.Function):
@@ -569,6 +576,32 @@ class RenderTrain(torch.autograd.Function):
             grads[name] = arena.get(name)
             return grads[name]
 
+        chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
+        bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
+        spread = bool(getattr(cfg, "spread_coarse_scatter", True))
+        exp_min = float(getattr(cfg, "trunc_exp_clamp_min", -15.0))
+        # ---- proposal levels, update steps (1 in 6 after warm-up) ---------------------------------------------------
+        # Their chain (get_weights adjoint -> density MLP -> the proposal grids' scatter -> positions) shares nothing with the final
+        # level's but the ray gradients: queued on the step's third stream it runs beside the MFMA-bound field backward (its own
+        # ray-gradient buffers, added at the join).  Only the fused forms qualify: the stage chain issues torch ops.
+        prop_join = None
+        g_prop = (g_w0, g_w1)
+        if ctx.updated and any(g is not None for g in g_prop):
+            fused_levels = all(t.hid is None for t in ctx.tapes)
+            if fused_levels and getattr(cfg, "overlap_table_scatter", True):
+                main, _, third = _step_streams(dev)
+                ray_p = (arena.zeros(tuple(ctx.o.shape)), arena.zeros(tuple(ctx.d.shape))) if ray_grads else None
+                gs = [None if g is None else g.reshape(t.weights.shape).contiguous() for g, t in zip(g_prop, ctx.tapes)]
+                keep: list = []
+                third.wait_stream(main)  # the cleared arena and the interlevel gradients are the main stream's work so far
+                _STREAM_OVERRIDE[0] = third.cuda_stream  # launches and allocations only until it is cleared
+                try:
+                    RenderTrain._proposal_levels(ctx, model, grads, arena, ray_p, chained, bucketed, exp_min, gs, keep)
+                finally:
+                    _STREAM_OVERRIDE[0] = None
+                prop_join = (third, ray_p, keep)
+                g_prop = (None, None)
+
         # ---- final level ------------------------------------------------------------------------------------
         # adjoints of the level's renderers and of get_weights (+ use_gradient_scaling, REF :228-231): one launch
         g_rgb_s = _f32((N, 3), dev) if g_rgb is not None else None
@@ -582,11 +615,7 @@ class RenderTrain(torch.autograd.Function):
                                          _hip.ptr(None if g_acc is None else g_acc.contiguous()), _hip.ptr(g_wx),
                                          _hip.ptr(st_en[0]), _hip.ptr(st_en[1]), R, S, _hip.ptr(g_rgb_s), _hip.ptr(g_th_s),
                                          g_density.data_ptr(), _stream()), "tn_ray_render_bwd")
-        exp_min = float(getattr(cfg, "trunc_exp_clamp_min", -15.0))
         W = 64
-        chained = bool(cfg.fused_train_backward)  # each MLP's layers in ONE launch (tn_linear_chain_bwd) vs one launch per layer
-        bucketed = bool(getattr(cfg, "bucketed_table_scatter", True))
-        spread = bool(getattr(cfg, "spread_coarse_scatter", True))
         E = f.enc.shape[1]
         g_enc = _f32((N, E), dev)  # row-major [N,32] in both forms (what the table scatter reads)
         if ctx.tape_free:
@@ -638,7 +667,7 @@ class RenderTrain(torch.autograd.Function):
 
             hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, grads["field.mlp_base.encoder.hash_table"], bucketed, spread,
                             getattr(cfg, "overlap_table_scatter", True), ray_level_adjoints)
-            return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
+            return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop, prop_join)
         ldb = bo.shape[1]
         g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass
         _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density, exp_min,
@@ -685,20 +714,33 @@ class RenderTrain(torch.autograd.Function):
                         getattr(cfg, "overlap_table_scatter", True))
         if ray_grads:
             _ray_grads_from_enc(fld.grid, fld.space, f, g_enc, *ray_grads)
-        return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, (g_w0, g_w1))
+        return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop, prop_join)
 
     @staticmethod
-    def _finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop):
-        """proposal levels (only through their weights), then the gradient tuple in parameter order"""
+    def _proposal_levels(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop, keep=None) -> None:
+        """backward of the proposal levels (they receive gradient only through their weights: the interlevel loss)"""
+        for lvl, g in enumerate(g_prop):
+            if g is None:
+                continue
+            t = ctx.tapes[lvl]
+            which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
+            net = model.proposal_networks[which].train_struct()
+            _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
+                                ray_grads, chained, bucketed, exp_min, bool(getattr(model.config, "spread_coarse_scatter", True)), keep)
+
+    @staticmethod
+    def _finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop, prop_join=None):
+        """proposal levels unless they are already queued on the third stream (then: the join), then the gradient tuple in
+        parameter order"""
         if ctx.updated:
-            for lvl, g in enumerate(g_prop):
-                if g is None:
-                    continue
-                t = ctx.tapes[lvl]
-                which = min(lvl, len(model.proposal_networks) - 1)  # one shared network: both levels accumulate into it
-                net = model.proposal_networks[which].train_struct()
-                _proposal_level_bwd(net, t, g.reshape(t.weights.shape).contiguous(), grads, f"proposal_networks.{which}", arena,
-                                    ray_grads, chained, bucketed, exp_min, bool(getattr(model.config, "spread_coarse_scatter", True)))
+            RenderTrain._proposal_levels(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop)
+        if prop_join is not None:
+            third, ray_p, keep = prop_join
+            _step_streams(ctx.o.device)[0].wait_stream(third)
+            if ray_grads and ray_p:
+                ray_grads[0].add_(ray_p[0])
+                ray_grads[1].add_(ray_p[1])
+            keep.clear()
 
         g_o, g_d = ray_grads if ray_grads else (None, None)
         result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)
