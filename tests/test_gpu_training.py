@@ -619,6 +619,40 @@ def test_bucketed_table_scatter_in_the_training_step():
             assert rel(got[n], want[n]) <= 1e-5, n  # (atomic orders differ from run to run)
 
 
+@pytest.mark.parametrize("update_step", [True, False])
+def test_step_streams_do_not_change_the_step(update_step):
+    """config.overlap_table_scatter: the bucketed half of the field's table scatter on the step's second stream, the proposal
+    levels' backward of an update step on its third (own ray-gradient buffers, added at the join) — against the same step queued
+    on one stream, on the full-size grids with ray gradients asked for (what the camera optimizer backpropagates, from all three
+    levels): same parameter and ray gradients up to the order of the atomics, same table entries touched."""
+    got = {}
+    for overlap in (True, False):
+        gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("scene", 48, small=False, overlap_table_scatter=overlap)
+        assert gm.config.overlap_table_scatter is overlap
+        if not update_step:
+            gm.set_step(5000)  # past the warm-up: the sampler skips the proposal networks' update on this step
+        b = {k: v.to(DEV) for k, v in batch.items()}
+        for _ in range(2):  # twice: the second step reuses the streams, workspaces and cached structs of the first
+            gm.proposal_sampler._steps_since_update = 0
+            od, dd = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+            rb = gm.collider(RayBundle(origins=od, directions=dd, camera_indices=cam.to(DEV)))
+            out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+            gm.zero_grad(set_to_none=True)
+            sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values()).backward()
+        assert out["weights_list"][0].requires_grad is update_step
+        torch.cuda.synchronize()
+        got[overlap] = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+        got[overlap]["__origins__"], got[overlap]["__directions__"] = od.grad.clone(), dd.grad.clone()
+    on, off = got[True], got[False]
+    assert set(on) == set(off)
+    assert ("proposal_networks.0.mlp_base.encoder.hash_table" in on) is update_step
+    assert float(off["__origins__"].abs().sum()) > 0 and float(off["__directions__"].abs().sum()) > 0
+    for n, g in off.items():
+        assert rel(on[n], g) <= (1e-4 if n.startswith("__") else 1e-5), (n, rel(on[n], g))
+        if n.endswith("hash_table"):
+            assert torch.equal(on[n] == 0, g == 0), n
+
+
 def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_dir):
     """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of the
     CPU reference path (torch autograd over the oracle; tests/test_config1_cpu.py runs them live, tools/make_config1_golden.py
