@@ -16,6 +16,7 @@ SH basis when a camera optimizer makes them depend on ``pose_adjustment``.  Not 
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -32,7 +33,20 @@ def _f32(shape, dev) -> Tensor:
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
-_STREAM_OVERRIDE: List[Optional[int]] = [None]
+class _StreamOverride(threading.local):
+    """per thread (autograd runs a device's backward on its own thread): [raw stream handle or None]"""
+
+    def __init__(self) -> None:
+        self.slot: List[Optional[int]] = [None]
+
+    def __getitem__(self, k: int) -> Optional[int]:
+        return self.slot[k]
+
+    def __setitem__(self, k: int, v: Optional[int]) -> None:
+        self.slot[k] = v
+
+
+_STREAM_OVERRIDE = _StreamOverride()
 
 
 def _stream():
