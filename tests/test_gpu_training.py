@@ -1094,3 +1094,50 @@ def test_out_of_range_camera_index_poisons_the_ray_instead_of_reading_elsewhere(
     bad = torch.isnan(rgb).any(dim=-1)
     assert bad[5] and bad[9] and int(bad.sum()) == 2
     assert torch.isnan(loss["rgb_loss"]).item()
+
+
+def test_cached_training_structs_follow_the_parameter_storage():
+    """train_struct() keeps the C structs of a network while its parameters keep their storage (an optimizer updates in place);
+    moving a parameter to new storage (what .to(), .float() or a manual `p.data = ...` do) must rebuild them — the step then
+    reads the NEW memory: same gradients as before when the values are the same, different ones when they are not."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("scene", 48)
+    _gpu_step(gm, o, d, jit, cam, batch)
+    before = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+    s0 = gm.field.train_struct()
+    assert gm.field.train_struct() is s0  # cached
+    old = {}
+    for n, p in gm.named_parameters():
+        old[n] = p.data
+        p.data = p.data.clone()  # same values, new storage
+    assert gm.field.train_struct() is not s0
+    _gpu_step(gm, o, d, jit, cam, batch)
+    for n, p in gm.named_parameters():
+        if n in before:
+            assert rel(p.grad, before[n]) <= 1e-5, n
+    for t in old.values():
+        t.fill_(float("nan"))  # the old storage is dead: a stale pointer would now read NaN
+    with torch.no_grad():
+        gm.field.mlp_head.layers[2].bias += 0.25
+    _gpu_step(gm, o, d, jit, cam, batch)
+    g = dict(gm.named_parameters())["field.mlp_head.layers.2.bias"].grad
+    assert torch.isfinite(g).all() and rel(g, before["field.mlp_head.layers.2.bias"]) > 1e-3
+
+
+def test_fresh_zeros_are_zero_disjoint_and_survive_a_block_rollover():
+    """_hip.fresh_zeros: the small zero-initialised accumulators of a step (loss scalars, pose gradient) are successive slices of
+    a pre-cleared block — never handed out twice, zero on arrival, also across the change to a new block."""
+    from thermo_nerf_amd import _hip as H
+
+    seen = []
+    n = H._ZERO_BLOCK_FLOATS // 16  # the largest request a block serves
+    for k in range(40):  # 40 x 1/16 of a block: at least two rollovers
+        t = H.fresh_zeros((n,), DEV)
+        assert t.shape == (n,) and float(t.abs().sum()) == 0.0
+        t.fill_(float(k + 1))
+        seen.append(t)
+    for k, t in enumerate(seen):
+        assert float(t.min()) == float(t.max()) == float(k + 1)  # nobody else got the same memory
+    big = H.fresh_zeros((H._ZERO_BLOCK_FLOATS,), DEV)  # larger than a block serves: a plain zeros tensor
+    assert big.numel() == H._ZERO_BLOCK_FLOATS and float(big.abs().sum()) == 0.0
+    s = H.fresh_zeros((3, 6), DEV)
+    assert s.shape == (3, 6) and s.is_contiguous() and s.data_ptr() % 256 == 0
