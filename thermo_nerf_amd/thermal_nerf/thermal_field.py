@@ -116,7 +116,10 @@ class ThermalNerfactoTField(nn.Module):
         f.prepared_f16x3 = None
         if prepare:
             lib = _hip.load()
-            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            plist = self.__dict__.get("_tn_plist")
+            if plist is None:
+                plist = self.__dict__["_tn_plist"] = list(self.parameters())
+            key = tuple([(p.data_ptr(), p._version) for p in plist])
             if self._prepared_key != key:
                 self._prepared, self._prepared_h3 = None, None
                 nbytes = lib.tn_field_prepare_bytes(f)

@@ -372,8 +372,9 @@ class ThermalNerfModel(ThermalNerfactoModel):
 
     # --- fused: one C-ABI call ------------------------------------------------------------------------
     def _c_structs(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.config.use_mfma,
-                                                                              self.config.mlp_precision)
+        # (the cached parameter list: walking the module tree costs more than a small eval call's kernels)
+        key = tuple([(p.data_ptr(), p._version) for p in self.named_parameter_lists()[1]]) + (self.config.use_mfma,
+                                                                                              self.config.mlp_precision)
         if self._struct_key != key:
             nets = len(self.proposal_networks)  # 1 with use_same_proposal_network [REF :127-139]
             self._structs = (self.proposal_networks[0].c_struct(), self.proposal_networks[min(1, nets - 1)].c_struct(),
