@@ -108,3 +108,24 @@ def test_generate_rays_with_lens_distortion_matches_oracle(k):
         assert (d - plain).abs().max().item() > 1e-3  # the distortion actually bends the corner rays
     else:
         assert torch.equal(d, plain)
+
+
+def test_random_pixel_batch_draws_the_same_rays_as_the_orbit_images():
+    """synthetic.random_pixel_rays (the PixelSampler-style training batch of bench.py / tools/train_bench.py) against the
+    per-image ray generator at the drawn pixels: same origins, same directions, camera index = the view."""
+    from thermo_nerf_amd import synthetic
+
+    n, H, W = 512, 80, 60
+    o, d, cam = synthetic.random_pixel_rays(n, H, W, num_views=8, seed=3)
+    assert o.shape == (n, 3) and d.shape == (n, 3) and cam.shape == (n, 1) and cam.dtype == torch.int64
+    g = torch.Generator().manual_seed(3)
+    view = torch.randint(0, 8, (n,), generator=g)
+    ys = torch.randint(0, H, (n,), generator=g)
+    xs = torch.randint(0, W, (n,), generator=g)
+    assert torch.equal(cam[:, 0], view)
+    assert len(view.unique()) == 8  # every image contributes
+    for v in range(8):
+        oi, di, _ = synthetic.orbit_camera_rays(H, W, view=v)
+        m = view == v
+        assert torch.allclose(o[m], oi[ys[m], xs[m]], atol=0, rtol=0)
+        assert torch.allclose(d[m], di[ys[m], xs[m]], atol=1e-6, rtol=0)

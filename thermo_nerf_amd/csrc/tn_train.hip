@@ -213,10 +213,16 @@ __global__ void __launch_bounds__(kBlock) spread_reduce_kernel(Grid g, Spread sp
 //     coalesced loads / stores.
 // Traffic: 20 B per record written and read once (252 MB per 196 k-sample call) + the table once, all streaming.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kSortSliceLog2 = 14;         // entries per owner slice (x 8 B = 128 KB of LDS)
+#ifndef TN_SORT_SLICE_LOG2
+#define TN_SORT_SLICE_LOG2 14
+#endif
+#ifndef TN_OWNER_BLOCK
+#define TN_OWNER_BLOCK 1024
+#endif
+constexpr int kSortSliceLog2 = TN_SORT_SLICE_LOG2;  // entries per owner slice (x 8 B = 128 KB of LDS)
 constexpr int kSortSamples = 1024;         // samples per block (4 per thread) in the count / emit passes
 constexpr int kSortMaxOwners = 1024;       // log2_hashmap_size <= 24
-constexpr int kOwnerBlock = 1024;
+constexpr int kOwnerBlock = TN_OWNER_BLOCK;
 constexpr int kSortMinBins = 128;
 constexpr float kSortMinScaling = 256.0f;
 
@@ -374,6 +380,9 @@ sort_owner_kernel(const unsigned *__restrict__ cursors, unsigned capacity, const
         int f = (lane > 0 && up == pk) ? 0 : 1;  // head of a run
         const int next_head = __shfl_down(f, 1, 64);
         const bool tail = (lane == 63) | (next_head != 0);
+#ifdef TN_OWNER_SKIP_SCAN
+        if (__any(f == 0))  // wave-uniform: a wave without a single run (the usual case on the finest levels) skips the scan
+#endif
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int o = 1 << k;

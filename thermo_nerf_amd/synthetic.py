@@ -122,6 +122,28 @@ def orbit_camera_rays(height: int, width: int, view: int = 0, num_views: int = 8
     return o.float(), d.float().contiguous(), pixel_area.float()
 
 
+def random_pixel_rays(rays: int, height: int = 800, width: int = 800, num_views: int = 8, seed: int = 0, radius: float = 0.8,
+                      fov_deg: float = 50.0, elevation_deg: float = 20.0) -> Tuple[Tensor, Tensor, Tensor]:
+    """A training batch the way nerfstudio's PixelSampler draws it: ``rays`` pixels uniformly at random over ALL
+    ``num_views`` images of the orbit (not a patch of one image), same pinhole model as ``orbit_camera_rays``.
+    Returns origins [rays,3], unit directions [rays,3], camera indices [rays,1] (int64) on the host."""
+    g = torch.Generator().manual_seed(seed)
+    view = torch.randint(0, num_views, (rays,), generator=g)
+    ys = torch.randint(0, height, (rays,), generator=g).float() + 0.5
+    xs = torch.randint(0, width, (rays,), generator=g).float() + 0.5
+    f = 0.5 * width / math.tan(0.5 * math.radians(fov_deg))
+    cam = torch.stack([(xs - width / 2.0) / f, -(ys - height / 2.0) / f, -torch.ones_like(xs)], dim=-1)
+    o = torch.empty(rays, 3)
+    d = torch.empty(rays, 3)
+    for v in range(num_views):
+        m = view == v
+        c2w, eye = orbit_pose(v, num_views, radius, elevation_deg)
+        dv = cam[m] @ c2w.T
+        d[m] = dv / dv.norm(dim=-1, keepdim=True)
+        o[m] = eye
+    return o.float().contiguous(), d.float().contiguous(), view[:, None].contiguous()
+
+
 def model_state_dict_cpu(model: torch.nn.Module) -> Dict[str, Tensor]:
     """CPU fp32 copy of the state dict (nerfstudio key names) — what the oracle consumes in tests/bench."""
     return {k: v.detach().to("cpu").clone() for k, v in model.state_dict().items()}

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
+    ap.add_argument("--ray-batch", default="patch", choices=["patch", "random"],
+                    help="patch: the sqrt(rays)^2 image of one orbit view (rounds 1-3); random: pixels drawn uniformly over all 8 "
+                         "views of an 800x800 orbit, the way nerfstudio's PixelSampler fills a batch")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
@@ -51,6 +54,9 @@ def main():
     o, d = o.reshape(-1, 3)[: a.rays].contiguous().to(dev), d.reshape(-1, 3)[: a.rays].contiguous().to(dev)
     R = o.shape[0]
     cam = torch.randint(0, 8, (R, 1), generator=g).to(dev)
+    if a.ray_batch == "random":
+        o, d, cam = (t.to(dev) for t in synthetic.random_pixel_rays(a.rays))
+        R = o.shape[0]
     batch = {"image": torch.rand(R, 3, generator=g).to(dev), "thermal": torch.rand(R, 1, generator=g).to(dev)}
 
     phase = [0.0] * 5
