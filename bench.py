@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render (default): the BASELINE metric.  train: one optimisation step per 'step' "
                          "(BASELINE configs 3/5; with N ranks every rank trains its own scene replica, no collective)")
+    ap.add_argument("--ray-batch", default="patch", choices=["patch", "random"],
+                    help="--mode train: the batch's rays — one small orbit view (default, the scatter's worst case) or random "
+                         "pixels over 8 800x800 views (nerfstudio's PixelSampler)")
     ap.add_argument("--shard", default="weak", choices=["weak", "frame"],
                     help="N > 1 render: weak = one frame per rank (default); frame = ONE 1920x1080 frame ray-sharded over the "
                          "ranks on chunk boundaries + all-gather (BASELINE config 4, strong scaling)")
@@ -163,11 +166,13 @@ def load_profile_json(name: str):
 
 
 def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, warmup: int = 24, start_step: int = 5000,
-                       cpu: bool = True):
+                       cpu: bool = True, ray_batch: str = "patch"):
     """Secondary measurement (BASELINE configs 3/5): one optimisation step = train-mode forward (tape-free
     final level, config.tape_free_training) + get_metrics_dict/get_loss_dict + backward + Adam(lr 1e-2, eps 1e-15) [REF config_thermal_nerf.py:32-45] on
     `rays` random-target rays, full-size tables, starting at `start_step` (>= proposal_warmup: the proposal networks take
-    gradient every 6th step, as in nerfstudio's schedule)."""
+    gradient every 6th step, as in nerfstudio's schedule).  ``ray_batch``: "patch" = the sqrt(rays)^2 image of one orbit view
+    (what rounds 1-3 timed: its samples crowd the same table entries, the scatter's worst case); "random" = pixels drawn
+    uniformly over all 8 views of an 800x800 orbit, the way nerfstudio's PixelSampler fills a batch."""
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.rays import RayBundle
 
@@ -187,6 +192,8 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
     R = o_cpu.shape[0]
     cam_cpu = torch.randint(0, 8, (R, 1), generator=g)
     batch_cpu = {"image": torch.rand(R, 3, generator=g), "thermal": torch.rand(R, 1, generator=g)}
+    if ray_batch == "random":
+        o_cpu, d_cpu, cam_cpu = synthetic.random_pixel_rays(rays)
     o, d, cam = o_cpu.to(dev), d_cpu.to(dev), cam_cpu.to(dev)
     batch = {k: v.to(dev) for k, v in batch_cpu.items()}
 
@@ -218,8 +225,10 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
     # trace of tools/train_bench.py) is named beside it.
     hbm = 3 * b_all * R / dt / 1e9
     tfl = 3 * f_all * R / dt / 1e12
-    res = {"what": "train step: forward + losses + backward + Adam, %d rays/step, P=(256,96)+%d samples/ray, "
-                   "steps %d.. (proposal nets updated every 6th step), camera optimizer SO3xR3" % (R, samples, start_step),
+    res = {"what": "train step: forward + losses + backward + Adam, %d rays/step (%s), P=(256,96)+%d samples/ray, "
+                   "steps %d.. (proposal nets updated every 6th step), camera optimizer SO3xR3" % (
+                       R, "one %dx%d view" % (side, side) if ray_batch == "patch" else "random pixels of 8 800x800 views", samples,
+                       start_step),
            "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps,
            "roofline": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_ray": 3 * b_all, "algorithmic_flops_per_ray": 3 * f_all,
@@ -440,7 +449,7 @@ def main():
         if world > 1:
             dist.barrier()
         res = measure_train_step(dev, args.samples or 48, steps=max(args.steps, 1), warmup=max(args.warmup, 1),
-                                 cpu=(solo and not args.no_cpu_baseline))
+                                 cpu=(solo and not args.no_cpu_baseline), ray_batch=args.ray_batch)
         t = torch.tensor([res["ms_per_step"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -598,6 +607,8 @@ def main():
             torch.cuda.empty_cache()
             cpu_train = sd_cpu is not None
             variants["train_step_S192"] = measure_train_step(dev, 192, cpu=False)  # (before S48's CPU leg, for the same reason)
+            variants["train_step_S192_random_pixels"] = measure_train_step(dev, 192, cpu=False, ray_batch="random")
+            variants["train_step_S48_random_pixels"] = measure_train_step(dev, 48, cpu=False, ray_batch="random")
             variants["train_step_S48"] = measure_train_step(dev, 48, cpu=cpu_train)
             line["variants"] = variants
         if sd_cpu is not None:

@@ -380,9 +380,6 @@ sort_owner_kernel(const unsigned *__restrict__ cursors, unsigned capacity, const
         int f = (lane > 0 && up == pk) ? 0 : 1;  // head of a run
         const int next_head = __shfl_down(f, 1, 64);
         const bool tail = (lane == 63) | (next_head != 0);
-#ifdef TN_OWNER_SKIP_SCAN
-        if (__any(f == 0))  // wave-uniform: a wave without a single run (the usual case on the finest levels) skips the scan
-#endif
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int o = 1 << k;
