@@ -1,7 +1,8 @@
 """Timeline of ONE training step out of a rocprofv3 kernel trace (rocpd .db): every kernel's start / end relative to the
 step's first kernel, its queue, and the union of busy time — to see what the step's wall time is made of when its kernels
 run on several streams (sum of durations > step time) and how much of it no kernel covers at all (launch gaps).
-usage: python tools/step_timeline.py <trace dir> <out.txt> [anchor kernel substring = field_fwd_taped] [which occurrence = -3]"""
+usage: python tools/step_timeline.py <trace dir> <out.txt> [anchor kernel substring = field_fwd_taped] [which occurrence = -3 |
+       a kernel substring: the last whole step that contains it, e.g. density_bwd_train = a step on which the proposal networks update]"""
 import glob
 import os
 import sqlite3
@@ -11,7 +12,7 @@ import sys
 def main():
     d, dst = sys.argv[1], sys.argv[2]
     anchor = sys.argv[3] if len(sys.argv) > 3 else "field_fwd_taped"
-    which = int(sys.argv[4]) if len(sys.argv) > 4 else -3
+    which = sys.argv[4] if len(sys.argv) > 4 else "-3"
     db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0]
     con = sqlite3.connect(db)
     cur = con.cursor()
@@ -20,6 +21,13 @@ def main():
     sel = "name, start, end" + (", " + qcol if qcol else ", 0")
     rows = sorted(cur.execute(f"select {sel} from kernels"), key=lambda r: r[1])
     starts = [i for i, r in enumerate(rows) if anchor in r[0]]
+    if which.lstrip("-").isdigit():
+        which = int(which)
+    else:  # the last whole step holding a kernel of that name
+        hit = [k for k in range(len(starts) - 1) if any(which in r[0] for r in rows[starts[k]:starts[k + 1]])]
+        if not hit:
+            raise SystemExit(f"no step contains {which!r}")
+        which = hit[-1] - len(starts)
     if len(starts) < abs(which) + 1:
         raise SystemExit(f"anchor {anchor!r} found {len(starts)} times")
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)

@@ -14,4 +14,5 @@ cd $repo
 python tools/prof_summary.py $out/trace gpurun_out/${tag}_kernel_trace_train_S${S}.txt \
   "rocprofv3 --kernel-trace --stats -- python tools/train_bench.py --steps 36 --warmup 6 --samples $S $extra (42 steps in the trace)" > /dev/null
 python tools/step_timeline.py $out/trace gpurun_out/${tag}_timeline_train_S${S}.txt > /dev/null 2>gpurun_out/${tag}_timeline_err.txt || true
+python tools/step_timeline.py $out/trace gpurun_out/${tag}_timeline_train_S${S}_update_step.txt field_fwd_taped density_bwd_train > /dev/null 2>>gpurun_out/${tag}_timeline_err.txt || true
 grep "ms/step" $out/trace.log
