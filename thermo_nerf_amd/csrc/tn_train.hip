@@ -220,7 +220,10 @@ __global__ void __launch_bounds__(kBlock) spread_reduce_kernel(Grid g, Spread sp
 #define TN_OWNER_BLOCK 1024
 #endif
 constexpr int kSortSliceLog2 = TN_SORT_SLICE_LOG2;  // entries per owner slice (x 8 B = 128 KB of LDS)
-constexpr int kSortSamples = 1024;         // samples per block (4 per thread) in the count / emit passes
+#ifndef TN_SORT_SAMPLES
+#define TN_SORT_SAMPLES 256
+#endif
+constexpr int kSortSamples = TN_SORT_SAMPLES;  // samples per block of the emit pass (22 B of LDS staging per record, 4 records per sample)
 constexpr int kSortMaxOwners = 1024;       // log2_hashmap_size <= 24
 constexpr int kOwnerBlock = TN_OWNER_BLOCK;
 constexpr int kSortMinBins = 128;
@@ -276,63 +279,108 @@ struct SortArgs {
     float *d_table;      // for the records that overflow a region
 };
 
-// blockIdx.x = chunk * levels + level: 1024 consecutive samples at one level -> ranks, one reservation per bin, records
+// blockIdx.x = chunk * levels + level: kSortSamples consecutive samples at one level -> ranks, one reservation per bin, records.
+// The records leave the block as CONTIGUOUS RUNS: a store instruction whose 64 lanes go to 64 different lines costs the CU
+// ~4 cycles per line in the texture path (the first form wrote every record straight from the lane that made it — 32 such
+// instructions per thread, 329 us per 786 k-sample call for 440 MB: bound by store instructions, not by bytes), so the block
+// first gathers its records per bin in LDS (slot = bin's offset in the block + rank) and then copies LDS record r to
+// base[bin] + (r - offset[bin]): consecutive threads write consecutive 16-byte records of one bin's run.
 __global__ void __launch_bounds__(kBlock) sort_emit_kernel(SortArgs a) {
-    __shared__ unsigned hist[kSortMaxOwners];
-    __shared__ unsigned base[kSortMaxOwners];
+    __shared__ unsigned wave_tot[kBlock / 64];
+    __shared__ unsigned total_s;
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
+    constexpr int REC = kSortSamples * 4;       // records per block at most
+    float4 *sval = reinterpret_cast<float4 *>(stage_raw);                                   // [REC]
+    unsigned *spair = reinterpret_cast<unsigned *>(stage_raw + (size_t)REC * 16);           // [REC]
+    unsigned short *sown = reinterpret_cast<unsigned short *>(stage_raw + (size_t)REC * 20);  // [REC]
+    const int PER = (a.owners + kBlock - 1) / kBlock, own_pad = PER * kBlock;  // bins per thread in the scan
+    unsigned *hist = reinterpret_cast<unsigned *>(stage_raw + (size_t)REC * 22);  // [own_pad] records per bin in this block
+    unsigned *base = hist + own_pad;   // [own_pad] the run's first slot in the bin's global region
+    unsigned *off = base + own_pad;    // [own_pad] the run's first slot in the block's LDS staging area
     const Space sp = make_space(a.space);
     const int L = a.g.num_levels;
     const long long chunk = blockIdx.x / a.levels;
     const int lb = (int)(blockIdx.x - chunk * a.levels), l = a.level_begin + lb;  // lb: level index inside the bins
-    for (int o = threadIdx.x; o < a.owners; o += kBlock) hist[o] = 0u;
+    for (int o = threadIdx.x; o < own_pad; o += kBlock) hist[o] = 0u;
     __syncthreads();
-    unsigned slot[kSortSamples / kBlock][4];
+    constexpr int SPT = kSortSamples / kBlock;
+    SortRec rec[SPT];
+    unsigned slot[SPT][4];
+    bool has[SPT];
 #pragma unroll
-    for (int k = 0; k < kSortSamples / kBlock; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         const long long i = chunk * kSortSamples + k * kBlock + threadIdx.x;
         float2 ge = make_float2(0.0f, 0.0f);
         if (i < a.n) ge = reinterpret_cast<const float2 *>(a.d_enc)[i * L + l];
-        if (ge.x != 0.0f || ge.y != 0.0f) {  // a sample without gradient writes no record
+        has[k] = ge.x != 0.0f || ge.y != 0.0f;  // a sample without gradient writes no record
+        if (has[k]) {
             float px, py, pz;
             normalize_position(sp, a.positions[i * 3], a.positions[i * 3 + 1], a.positions[i * 3 + 2], px, py, pz);
-            SortRec r;
-            sort_records<false>(a.g, l, a.slice_log2, px, py, pz, ge, r);
+            sort_records<true>(a.g, l, a.slice_log2, px, py, pz, ge, rec[k]);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) slot[k][p] = atomicAdd(&hist[r.owner[p]], 1u);
+            for (int p = 0; p < 4; ++p) slot[k][p] = atomicAdd(&hist[rec[k].owner[p]], 1u);
         }
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < a.owners; o += kBlock)
-        base[o] = hist[o] ? atomicAdd(&a.cursors[(size_t)lb * a.owners + o], hist[o]) : 0u;
+    // exclusive scan of hist over the bins (PER per thread) -> off[]; the global reservation of every non-empty bin beside it
+    {
+        unsigned sum = 0u;
+        for (int j = 0; j < PER; ++j) sum += hist[threadIdx.x * PER + j];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u, all = 0u;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            if (w < wave) before += wave_tot[w];
+            all += wave_tot[w];
+        }
+        unsigned run = before + incl - sum;
+        for (int j = 0; j < PER; ++j) {
+            const int o = threadIdx.x * PER + j;
+            const unsigned h = hist[o];
+            off[o] = run;
+            run += h;
+            base[o] = (h && o < a.owners) ? atomicAdd(&a.cursors[(size_t)lb * a.owners + o], h) : 0u;
+        }
+        if (threadIdx.x == 0) total_s = all;
+    }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        if (!has[k]) continue;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned o = rec[k].owner[p], at = off[o] + slot[k][p];
+            sval[at] = rec[k].val[p];
+            spair[at] = rec[k].pair[p];
+            sown[at] = (unsigned short)o;
+        }
+    }
+    __syncthreads();
+    const unsigned total = total_s;
     float *tb = a.d_table + ((size_t)l * a.g.tsize) * 2;
-#pragma unroll
-    for (int k = 0; k < kSortSamples / kBlock; ++k) {
-        const long long i = chunk * kSortSamples + k * kBlock + threadIdx.x;
-        float2 ge = make_float2(0.0f, 0.0f);
-        if (i < a.n) ge = reinterpret_cast<const float2 *>(a.d_enc)[i * L + l];
-        if (ge.x != 0.0f || ge.y != 0.0f) {
-            float px, py, pz;
-            normalize_position(sp, a.positions[i * 3], a.positions[i * 3 + 1], a.positions[i * 3 + 2], px, py, pz);
-            SortRec r;
-            sort_records<true>(a.g, l, a.slice_log2, px, py, pz, ge, r);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned o = r.owner[p], at = base[o] + slot[k][p];
-                if (at < a.capacity) {
-                    const size_t w = ((size_t)lb * a.owners + o) * a.capacity + at;
-                    a.rec_pair[w] = r.pair[p];
-                    a.rec_val[w] = r.val[p];
-                } else {  // the bin's region is full: straight into the table
-                    float *pa = tb + (((size_t)o << a.slice_log2) + (r.pair[p] & 0xffffu)) * 2;
-                    float *pb = tb + (((size_t)o << a.slice_log2) + (r.pair[p] >> 16)) * 2;
-                    const float4 v = r.val[p];
-                    if (v.x != 0.0f) atomic_add_f32(pa, v.x);
-                    if (v.y != 0.0f) atomic_add_f32(pa + 1, v.y);
-                    if (v.z != 0.0f) atomic_add_f32(pb, v.z);
-                    if (v.w != 0.0f) atomic_add_f32(pb + 1, v.w);
-                }
-            }
+    for (unsigned r = threadIdx.x; r < total; r += kBlock) {
+        const unsigned o = sown[r], at = base[o] + (r - off[o]);
+        const unsigned pk = spair[r];
+        const float4 v = sval[r];
+        if (at < a.capacity) {
+            const size_t w = ((size_t)lb * a.owners + o) * a.capacity + at;
+            a.rec_pair[w] = pk;
+            a.rec_val[w] = v;
+        } else {  // the bin's region is full: straight into the table
+            float *pa = tb + (((size_t)o << a.slice_log2) + (pk & 0xffffu)) * 2;
+            float *pb = tb + (((size_t)o << a.slice_log2) + (pk >> 16)) * 2;
+            if (v.x != 0.0f) atomic_add_f32(pa, v.x);
+            if (v.y != 0.0f) atomic_add_f32(pa + 1, v.y);
+            if (v.z != 0.0f) atomic_add_f32(pb, v.z);
+            if (v.w != 0.0f) atomic_add_f32(pb + 1, v.w);
         }
     }
 }
@@ -1948,9 +1996,10 @@ int tn_hash_encode_bwd_sorted_first_level(const tn_hashgrid *grid, int64_t n) {
     return w.bins >= kSortMinBins ? first : -1;
 }
 
-int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
-                              int64_t n, float *d_table, int32_t level_begin, void *workspace, size_t workspace_bytes,
-                              void *stream) {
+// phase 1 = the emit pass (clears the cursors, writes the records), 2 = the owner pass (sums them into d_table), 3 = both
+static int hash_encode_bwd_sorted_phases(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                                         int64_t n, float *d_table, int32_t level_begin, void *workspace, size_t workspace_bytes,
+                                         int phases, void *stream) {
     if (!grid || !space) return TN_ERR_NULL;
     TN_TRY(tn_check_grid(*grid));
     if (n == 0) return TN_OK;
@@ -1973,18 +2022,30 @@ int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, co
     a.rec_pair = reinterpret_cast<unsigned *>(ws + w.off_pair);
     a.rec_val = reinterpret_cast<float4 *>(ws + w.off_val);
     a.d_table = d_table;
-    if (hipMemsetAsync(ws, 0, (size_t)w.bins * 4, s) != hipSuccess) return TN_ERR_LAUNCH;
-    const long long chunks = (n + kSortSamples - 1) / kSortSamples;
-    const long long blocks = chunks * a.levels;
-    if (blocks > 0x7fffffffLL) return TN_ERR_SHAPE;
-    hipLaunchKernelGGL(sort_emit_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, a);
-    TN_LAUNCH_CHECK();
-    const size_t smem = (size_t)(2 << w.slice_log2) * sizeof(float);
-    if (smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_owner_kernel>(smem)) return TN_ERR_LAUNCH;
-    hipLaunchKernelGGL(sort_owner_kernel, dim3((unsigned)w.bins), dim3(kOwnerBlock), smem, s, a.cursors, w.capacity, a.rec_pair,
-                       a.rec_val, w.owners, w.slice_log2, 1u << grid->log2_hashmap_size, level_begin, d_table);
-    TN_LAUNCH_CHECK();
+    if (phases & 1) {
+        if (hipMemsetAsync(ws, 0, (size_t)w.bins * 4, s) != hipSuccess) return TN_ERR_LAUNCH;
+        const long long chunks = (n + kSortSamples - 1) / kSortSamples;
+        const long long blocks = chunks * a.levels;
+        if (blocks > 0x7fffffffLL) return TN_ERR_SHAPE;
+        const size_t emit_smem = (size_t)kSortSamples * 4 * 22 + (size_t)3 * 4 * kBlock * ((w.owners + kBlock - 1) / kBlock);
+        if (emit_smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_emit_kernel>(emit_smem)) return TN_ERR_LAUNCH;
+        hipLaunchKernelGGL(sort_emit_kernel, dim3((unsigned)blocks), dim3(kBlock), emit_smem, s, a);
+        TN_LAUNCH_CHECK();
+    }
+    if (phases & 2) {
+        const size_t smem = (size_t)(2 << w.slice_log2) * sizeof(float);
+        if (smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_owner_kernel>(smem)) return TN_ERR_LAUNCH;
+        hipLaunchKernelGGL(sort_owner_kernel, dim3((unsigned)w.bins), dim3(kOwnerBlock), smem, s, a.cursors, w.capacity, a.rec_pair,
+                           a.rec_val, w.owners, w.slice_log2, 1u << grid->log2_hashmap_size, level_begin, d_table);
+        TN_LAUNCH_CHECK();
+    }
     return TN_OK;
+}
+
+int tn_hash_encode_bwd_sorted(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,
+                              int64_t n, float *d_table, int32_t level_begin, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+    return hash_encode_bwd_sorted_phases(grid, space, positions, d_enc, n, d_table, level_begin, workspace, workspace_bytes, 3, stream);
 }
 
 int tn_hash_encode_bwd_input(const tn_hashgrid *grid, const tn_space *space, const float *positions, const float *d_enc,

@@ -142,12 +142,8 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
     if overlap and first > 0:
         main, side, _ = _step_streams(pos.device)
         side.wait_stream(main)  # d_enc, positions and the cleared d_table are the main stream's work so far
-        _STREAM_OVERRIDE[0] = side.cuda_stream  # launches only (no torch op, no allocation) until it is cleared
-        try:
-            _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
-                                                     ws.data_ptr(), need, _stream()), "tn_hash_encode_bwd_sorted")
-        finally:
-            _STREAM_OVERRIDE[0] = None
+        _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
+                                                 ws.data_ptr(), need, side.cuda_stream), "tn_hash_encode_bwd_sorted")
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
         if side_work is not None:
             side_work()  # behind the atomic part: the bucketed part is the longer of the two (timeline in DESIGN 5.6)

@@ -12,5 +12,5 @@ for so in ab_*.so; do
   echo "== $so"
   timeout 600 python -m pytest tests/test_gpu_training.py -x -q -m gpu -k "bucketed" 2>&1 | tail -1
   bash tools/train_profile.sh $tag $S "$@" | tail -1
-  grep -E "$pat" gpurun_out/${tag}_kernel_trace_train_S${S}.txt | awk -F'",' '{split($2,a,","); n=$1; sub(/^"/,"",n); sub(/\(.*/,"",n); printf "   %-60s calls %s avg %s us\n", n, a[1], a[3]}'
+  grep -E "$pat" gpurun_out/${tag}_kernel_trace_train_S${S}.txt | sed 's/(anonymous namespace):://g' | awk -F'",' '{split($2,a,","); n=$1; sub(/^"/,"",n); sub(/\(.*/,"",n); printf "   %-60s calls %s avg %s us\n", n, a[1], a[3]}'
 done
