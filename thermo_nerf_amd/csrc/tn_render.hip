@@ -351,22 +351,39 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     float run = 0.0f, c0 = 0.0f;          // running cumsum(pdf); cdf[i] = min(1, run) before adding bin i
     float b0 = edge(0);
     float uj = jittered ? add_rn(u[0], jit) : u[0];
-    for (int i = 0; i < n_in; ++i) {
-        const float wi = w[(size_t)i * 64];
-        const float wa = (anneal == 1.0f) ? wi : powf(wi, anneal);
-        run += add_rn(add_rn(wa, 0.01f), pad_each) * rws;
-        const float c1 = fminf(1.0f, run);
-        const float b1 = edge(i + 1);
-        // searchsorted(cdf, u, side="right") lands in bin i  <=>  cdf[i] <= u < cdf[i+1]
-        while (j < nb && uj < c1) {
-            float t = nan_to_num(t_div<true>(sub_rn(uj, c0), sub_rn(c1, c0)));
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            emit(j, add_rn(b0, mul_rn(t, sub_rn(b1, b0))));
-            ++j;
-            if (j < nb) uj = jittered ? add_rn(u[j], jit) : u[j];
+#ifndef TN_PDF_WALK_BLOCK
+#define TN_PDF_WALK_BLOCK 8
+#endif
+    // TN_PDF_WALK_BLOCK bins at a time: their weights (scratch) and right edges are loaded up front, so a lane has that many
+    // loads in flight instead of one round trip per bin (the emit stores inside the walk keep hipcc from hoisting them itself)
+    constexpr int WB = TN_PDF_WALK_BLOCK;
+    for (int i0 = 0; i0 < n_in; i0 += WB) {
+        float wv[WB], ev[WB];
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            const int i = i0 + k < n_in ? i0 + k : n_in - 1;
+            wv[k] = w[(size_t)i * 64];
+            ev[k] = edge(i + 1);
         }
-        c0 = c1;
-        b0 = b1;
+#pragma unroll
+        for (int k = 0; k < WB; ++k) {
+            if (i0 + k >= n_in) break;
+            const float wi = wv[k];
+            const float wa = (anneal == 1.0f) ? wi : powf(wi, anneal);
+            run += add_rn(add_rn(wa, 0.01f), pad_each) * rws;
+            const float c1 = fminf(1.0f, run);
+            const float b1 = ev[k];
+            // searchsorted(cdf, u, side="right") lands in bin i  <=>  cdf[i] <= u < cdf[i+1]
+            while (j < nb && uj < c1) {
+                float t = nan_to_num(t_div<true>(sub_rn(uj, c0), sub_rn(c1, c0)));
+                t = fminf(fmaxf(t, 0.0f), 1.0f);
+                emit(j, add_rn(b0, mul_rn(t, sub_rn(b1, b0))));
+                ++j;
+                if (j < nb) uj = jittered ? add_rn(u[j], jit) : u[j];
+            }
+            c0 = c1;
+            b0 = b1;
+        }
     }
     // u >= cdf[n_in]: below == above == n_in -> t * 0 -> the last edge
     for (; j < nb; ++j) emit(j, b0);
