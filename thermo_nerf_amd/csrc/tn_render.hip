@@ -15,6 +15,12 @@
 
 #include <type_traits>
 
+#ifndef TN_PROP_WAVES
+#define TN_PROP_WAVES 4   // waves per SIMD of proposal_rays_kernel (= workgroups per CU)
+#endif
+#ifndef TN_PROP_GROUPS
+#define TN_PROP_GROUPS 32  // levels per gather stage of the lean proposal density: 3 + 2 (32) or 2 + 2 + 1 (221)
+#endif
 using namespace tn;
 
 namespace tn {
@@ -284,8 +290,14 @@ __device__ __forceinline__ float proposal_density_kmajor(const Grid &g, const tn
                 for (int l = l0; l < l1; ++l) f[l] = hash_blend(t[l - l0], fv[l - l0]);
                 TN_STAGE_FENCE();
             };
+#if TN_PROP_GROUPS == 221
+            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            group(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            group(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+#else
             group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
             group(std::integral_constant<int, 3>{}, std::integral_constant<int, 5>{});
+#endif
         } else {
 #pragma unroll
             for (int l = 0; l < 5; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);
@@ -395,7 +407,7 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
 // 5-level / 16-hidden shape, no per-level outputs): the run-time switches of the general form cost scalar registers
 // (spilled to lanes and read back per sample) and branches inside the sample loops.
 template <int ND0, int ND1, bool LEAN>
-__global__ void __launch_bounds__(kBlock, 4) proposal_rays_kernel(PropRaysArgs ra) {
+__global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_rays_kernel(PropRaysArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PropArgs &a = ra.p;
     const int in0 = 2 * a.net[0].g.num_levels, in1 = 2 * a.net[1].g.num_levels;
@@ -781,7 +793,8 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
                                       two_layer_floats(2 * prop1->grid.num_levels, PH, 1) + (P0 + 1) + (P1 + 1) + (S + 1)) *
                              sizeof(float);
         const long long need = ((long long)tiles + kWaves - 1) / kWaves;
-        const unsigned grid = (unsigned)(need < 1024 ? (need < 1 ? 1 : need) : 1024);  // 4 workgroups (16 waves) per CU
+        constexpr long long kMaxGrid = 256LL * TN_PROP_WAVES;  // TN_PROP_WAVES workgroups (x 4 waves) per CU
+        const unsigned grid = (unsigned)(need < kMaxGrid ? (need < 1 ? 1 : need) : kMaxGrid);
         const int nd0 = pa.net[0].g.num_dense, nd1 = pa.net[1].g.num_dense;
         const bool five = pa.net[0].g.num_levels == 5 && pa.net[1].g.num_levels == 5;
         bool lean = five && !pa.jitter && !pa.lin && pa.anneal == 1.0f && pa.net[0].space.contraction && pa.net[1].space.contraction &&
