@@ -555,9 +555,13 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
         bool med_found = false;
+        // the bin edges come from the workspace (HBM / Infinity Cache): the next one is requested a sample ahead, so that its
+        // round trip is not the first thing a sample waits for (field kernel 32.0 -> 31.75 ms per 640 k rays at S=192)
+        float sb_next = tb[64];
         for (int i = 0; i < S; ++i) {
             const float st = en;
-            en = spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far, lin);
+            en = spacing_to_eucl<true>(sb_next, s_near, s_far, lin);
+            sb_next = tb[(size_t)(i + 2 <= S ? i + 2 : S) * 64];
             step = add_rn(st, en) / 2.0f;
             float px, py, pz;
             const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
