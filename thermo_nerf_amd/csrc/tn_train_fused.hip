@@ -211,17 +211,22 @@ struct TileIn {
     unsigned ray;
 };
 
+// the tile's hash features (what the recomputed forward starts from) ...
+__device__ __forceinline__ void tile_load_enc(f32x4 (&e)[2], const FusedBwdArgs &a, long long tile, int n, int sl) {
+    const long long i = tile * TS + n;
+    const long long ic = i < a.N ? i : a.N - 1;
+    // pass tiles of tn_field_fwd_train: [pass of 64 samples][level][sample][2]; features 4 sl .. = levels 2 sl, 2 sl + 1
+    const float2 *et = reinterpret_cast<const float2 *>(a.enc) + (ic >> 6) * (16 * 64) + (ic & 63);
+    const float2 f0 = et[(2 * sl) * 64], f1 = et[(2 * sl + 1) * 64], f2 = et[(8 + 2 * sl) * 64], f3 = et[(9 + 2 * sl) * 64];
+    e[0] = f32x4{f0.x, f0.y, f1.x, f1.y};
+    e[1] = f32x4{f2.x, f2.y, f3.x, f3.y};
+}
+// ... and the rest of its inputs (output gradients, the forward's rgb, the selector)
 template <int MODE>
-__device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long long tile, int n, int sl) {
+__device__ __forceinline__ void tile_load_rest(TileIn &t, const FusedBwdArgs &a, long long tile, int n, int sl) {
     const long long i = tile * TS + n;
     const bool live = i < a.N;
     const long long ic = live ? i : a.N - 1;
-    {   // pass tiles of tn_field_fwd_train: [pass of 64 samples][level][sample][2]; features 4 sl .. = levels 2 sl, 2 sl + 1
-        const float2 *et = reinterpret_cast<const float2 *>(a.enc) + (ic >> 6) * (16 * 64) + (ic & 63);
-        const float2 f0 = et[(2 * sl) * 64], f1 = et[(2 * sl + 1) * 64], f2 = et[(8 + 2 * sl) * 64], f3 = et[(9 + 2 * sl) * 64];
-        t.e[0] = f32x4{f0.x, f0.y, f1.x, f1.y};
-        t.e[1] = f32x4{f2.x, f2.y, f3.x, f3.y};
-    }
     t.ray = (unsigned)ic / (unsigned)a.S;
     if (MODE & 4) {
         t.sel = a.sel[ic];
@@ -235,6 +240,11 @@ __device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long
             t.g_rgb[c] = (a.g_rgb && live) ? a.g_rgb[ic * 3 + c] : 0.0f;
         }
     }
+}
+template <int MODE>
+__device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long long tile, int n, int sl) {
+    tile_load_enc(t.e, a, tile, n, sl);
+    tile_load_rest<MODE>(t, a, tile, n, sl);
 }
 
 template <int MODE, int WAVES>
@@ -309,10 +319,19 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
     long long tile = (long long)blockIdx.x * WAVES + wave;
     const unsigned R = (unsigned)(a.N / a.S);
     TileIn cur, nxt;
-    if (tile < tiles) tile_load<MODE>(cur, a, tile, n, sl);
+    // BASE launch: the next tile's inputs are requested at the start of the mlp_base section and are in flight under its products.
+    // Head launches (80 accumulators + their working set in 256 registers: no room for a second TileIn): the hash features are
+    // only read by the first product of a tile, so the NEXT tile's features are requested into the same registers right after
+    // it; the tile's remaining inputs (output gradients, rgb) are requested at the top of the tile, a hundred MFMAs before
+    // they are read.  No load is issued right in front of its use.
+    if (tile < tiles) {
+        if (BASE) tile_load<MODE>(cur, a, tile, n, sl);
+        else tile_load_enc(cur.e, a, tile, n, sl);
+    }
     for (; tile < tiles; tile += stride) {
         const long long i0 = tile * TS;
         const bool live = i0 + n < a.N;
+        if (!BASE) tile_load_rest<MODE>(cur, a, tile, n, sl);
         // ---- mlp_head.0's per-ray part: issued now, consumed after mlp_base ---------------------------------------------
         f32x4 c1[4];
         if (has_rgb) {
@@ -324,6 +343,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) h1[ob] = ld4(lds + O_BB0 + 16 * ob + 4 * sl);
         mm<4, 2, LD_B0, false>(lds + O_B0R, n, sl, cur.e, h1);
+        if (!BASE && tile + stride < tiles) tile_load_enc(cur.e, a, tile + stride, n, sl);
         f32x4 G[1] = {ld4(lds + O_BB1 + 4 * sl)};   // G[0][q] = row 4 sl + q of bo (0 = raw density, 1.. = geo), sample n
         mm<1, 4, LD_64, true>(lds + O_B1R, n, sl, h1, G);
         // adjoint of bo's 16 rows, same layout; the heads add their parts
@@ -525,12 +545,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             wave_sync();
             dw<4, 2, true>(D, X, n, sl, aw_b0, ab_b0);
             wave_sync();
-        } else {
-            // (the head launches hold 80 accumulators + their working set in 256 registers: no room to keep the next tile's
-            // inputs in flight across a phase; the SIMD's other wave covers the latency)
-            if (tile + stride < tiles) tile_load<MODE>(nxt, a, tile + stride, n, sl);
+            cur = nxt;
         }
-        cur = nxt;
     }
 
     // ---- block slab: the waves' accumulators summed through an LDS image of the slab ---------------------------------------
