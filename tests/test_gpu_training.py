@@ -1141,3 +1141,47 @@ def test_fresh_zeros_are_zero_disjoint_and_survive_a_block_rollover():
     assert big.numel() == H._ZERO_BLOCK_FLOATS and float(big.abs().sum()) == 0.0
     s = H.fresh_zeros((3, 6), DEV)
     assert s.shape == (3, 6) and s.is_contiguous() and s.data_ptr() % 256 == 0
+
+
+@pytest.mark.parametrize("S", [48, 192])
+def test_regularisers_launched_by_the_forward_equal_the_ones_launched_on_demand(S):
+    """config.overlap_regularisers: the training forward launches distortion + interlevel on the step's side streams;
+    get_metrics_dict / get_loss_dict must pick exactly those results up (entry consumed), every loss and every gradient must
+    equal the on-demand launches (same kernels, same inputs; their block sums meet in fp32 atomics, so to rounding), and a call
+    with OTHER tensors or another multiplier must not be served from the forward's launch."""
+    gm, _, _, o, d, jit, cam, batch = _train_setup("scene", S)
+
+    def run(flag):
+        gm.config.overlap_regularisers = flag
+        out, loss_dict = _gpu_step(gm, o, d, jit, cam, batch)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+        return {k: v.detach().clone() for k, v in loss_dict.items()}, grads
+
+    l0, g0 = run(False)
+    assert not TR._REG_PRE
+    l1, g1 = run(True)
+    assert not TR._REG_PRE  # both results were taken
+    assert set(l0) == set(l1) and set(g0) == set(g1)
+    for k in l0:
+        assert torch.allclose(l0[k], l1[k], rtol=2e-6, atol=0), (k, l0[k].item(), l1[k].item())
+    for n in g0:
+        if "hash_table" in n:  # fp32 atomics: order-dependent
+            assert torch.allclose(g0[n], g1[n], rtol=1e-4, atol=1e-9), n
+        else:
+            assert torch.allclose(g0[n], g1[n], rtol=2e-5, atol=1e-9), n
+
+    # a forward whose regularisers are asked for with a different multiplier / different tensors: computed afresh, same numbers
+    rb = gm.collider(RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV)))
+    out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+    assert TR._REG_PRE
+    other = TR.distortion_loss(out["weights_list"], out["ray_samples_list"], mult=0.5 * gm.config.distortion_loss_mult)
+    assert "dist" not in next(iter(TR._REG_PRE.values()))  # consumed, not used
+    gm.config.overlap_regularisers = False
+    want = TR.distortion_loss(out["weights_list"], out["ray_samples_list"], mult=0.5 * gm.config.distortion_loss_mult)
+    assert torch.allclose(other, want, rtol=2e-6, atol=0)
+    clone = [w.clone() for w in out["weights_list"]]
+    a = TR.interlevel_loss(clone, out["ray_samples_list"], mult=gm.config.interlevel_loss_mult)
+    assert not TR._REG_PRE  # the forward's launch was for other tensors: dropped
+    b = TR.interlevel_loss(out["weights_list"], out["ray_samples_list"], mult=gm.config.interlevel_loss_mult)
+    assert torch.allclose(a, b, rtol=2e-6, atol=0)

@@ -121,6 +121,11 @@ class NerfactoModelConfig:
     overlap_table_scatter: bool = True
     """Training: the bucketed part of the field's table-gradient scatter runs on a second HIP stream beside the atomic part —
     disjoint levels of the gradient, one waiting on the memory-side atomic unit, the other on LDS and streaming (DESIGN §5.6)."""
+    overlap_regularisers: Union[bool, str] = "auto"
+    """Training: the distortion and interlevel terms are launched by the forward itself, on the step's side streams beside
+    the depth renderers and the image losses (they depend on the forward's weights and bins only); get_metrics_dict /
+    get_loss_dict pick the results up.  False: each is launched where it is asked for; "auto": on from 4096 x 96 final-level
+    samples per step, where the step's device time leaves room for the extra stream joins on the host (DESIGN §5.6)."""
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""

@@ -530,6 +530,8 @@ class RenderTrain(torch.autograd.Function):
         _hip.check(lib.tn_ray_render_fwd(f.deltas.data_ptr(), f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), R, S,
                                          f.weights.data_ptr(), rgb.data_ptr(), thermal.data_ptr(), acc.data_ptr(), _stream()),
                    "tn_ray_render_fwd")
+        # the step's regularisers start now, beside the depth renderers (config.overlap_regularisers)
+        _precompute_regularisers(model, [t.weights for t in tapes] + [f.weights], [t.spacing for t in tapes] + [f.spacing])
         depth, expected = _f32((R, 1), dev), _f32((R, 1), dev)
         scratch = _f32((2,), dev)
         starts, ends = _starts_ends(f)
@@ -761,6 +763,91 @@ class RenderTrain(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 # regularisers
 # --------------------------------------------------------------------------------------------------
+def _distortion_run(w: Tensor, b: Tensor, mult: float, side=None) -> Tuple[Tensor, Tensor]:
+    """tn_distortion_loss_term on [R,n] weights / [R,n+1] bins -> (loss pair, gradient of the term); ``side``: a stream to run it on
+    beside the calling one (its outputs are allocated and cleared on the calling stream first)"""
+    R, n = w.shape
+    loss = _hip.fresh_zeros((2,), w.device)
+    g = _f32((R, n), w.device)
+    stream = _stream()
+    if side is not None:
+        side.wait_stream(_step_streams(w.device)[0])
+        stream = side.cuda_stream
+    # the mean over rays and the loss multiplier are applied inside the kernel (loss and gradient): no elementwise launches around it
+    _hip.check(_hip.load().tn_distortion_loss_term(b.data_ptr(), w.data_ptr(), R, n, 1.0 / R, mult, loss.data_ptr(), g.data_ptr(),
+                                                   stream), "tn_distortion_loss_term")
+    return loss, g
+
+
+def _interlevel_run(mult: float, w2: Tensor, c2: Tensor, levels: Sequence[Tuple[Tensor, Tensor]], side=None) -> Tuple[Tensor, List[Tensor]]:
+    """tn_interlevel_loss_levels: final level (w2 [R,n], c2 [R,n+1]) against the proposal levels [(wp [R,p], cp [R,p+1]), ...] ->
+    (loss [1], one gradient per level); both levels in one launch, each scaled by mult / (R n)"""
+    R, n = w2.shape
+    loss = _hip.fresh_zeros((1,), w2.device)
+    L = len(levels)
+    cps, wps, gs, ps = (C.c_void_p * L)(), (C.c_void_p * L)(), (C.c_void_p * L)(), (C.c_int32 * L)()
+    grads = []
+    for k, (wp2, cp2) in enumerate(levels):
+        g = _f32((R, wp2.shape[1]), wp2.device)
+        cps[k], wps[k], gs[k], ps[k] = cp2.data_ptr(), wp2.data_ptr(), g.data_ptr(), wp2.shape[1]
+        grads.append(g)
+    stream = _stream()
+    if side is not None:
+        side.wait_stream(_step_streams(w2.device)[0])
+        stream = side.cuda_stream
+    _hip.check(_hip.load().tn_interlevel_loss_levels(c2.data_ptr(), w2.data_ptr(), R, n, L, cps, wps, ps, mult / (R * n), loss.data_ptr(),
+                                                     gs, stream), "tn_interlevel_loss_levels")
+    return loss, grads
+
+
+# The two regularisers of a training step depend on the forward's weights and bins only, and each is a short latency-bound
+# launch (22 + 31 us at S=192 for 4096 rays) that get_metrics_dict / get_loss_dict would queue one after the other behind the
+# depth renderers.  With config.overlap_regularisers the training forward launches them right behind the final level's
+# weights, on the step's side streams, beside the depth renderers and the image losses; _Distortion / _Interlevel pick the
+# results up (same tensors, same multipliers: checked) after joining that stream.  One entry per (device, stream): the current step's.
+_REG_PRE: Dict = {}
+
+
+def _precompute_regularisers(model, w_levels: Sequence[Tensor], c_levels: Sequence[Tensor]) -> None:
+    cfg = model.config
+    dev = w_levels[-1].device
+    slot = (dev, _hip.current_stream())
+    _REG_PRE.pop(slot, None)
+    want = getattr(cfg, "overlap_regularisers", "auto")
+    if want == "auto":
+        # the side launches cost the host four stream joins (~40 us): they pay once the step's device time is well above its
+        # host time — S=192: 2.64 against 2.68 ms per step; S=48 (device 1.34 ms, host ~1 ms): 1.34-1.46 against 1.34-1.35
+        want = w_levels[-1].numel() >= 4096 * 96
+    if not want or len(w_levels) < 2:
+        return
+    _, second, third = _step_streams(dev)
+    w2, c2 = w_levels[-1], c_levels[-1]
+    entry = {"hold": (list(w_levels), list(c_levels))}  # the inputs stay alive (and their addresses theirs) while the entry exists
+    mult_d = float(cfg.distortion_loss_mult)
+    if mult_d:
+        entry["dist"] = ((w2.data_ptr(), tuple(w2.shape), c2.data_ptr(), mult_d), _distortion_run(w2, c2, mult_d, second), second)
+    mult_i = float(cfg.interlevel_loss_mult)
+    levels = list(zip(w_levels[:-1], c_levels[:-1]))
+    key = (w2.data_ptr(), tuple(w2.shape), c2.data_ptr(), mult_i) + tuple((wp.data_ptr(), cp.data_ptr()) for wp, cp in levels)
+    entry["inter"] = (key, _interlevel_run(mult_i, w2, c2, levels, third), third)
+    _REG_PRE[slot] = entry
+
+
+def _take_precomputed(dev, which: str, key):
+    """the side-stream result of this step's forward for exactly these inputs, joined into the calling stream — or None"""
+    slot = (dev, _hip.current_stream())
+    entry = _REG_PRE.get(slot)
+    if entry is None or which not in entry:
+        return None
+    k, result, side = entry.pop(which)
+    if not any(x in entry for x in ("dist", "inter")):
+        _REG_PRE.pop(slot, None)
+    if k != key:
+        return None  # other tensors or another multiplier: computed afresh by the caller (the side launch is simply dropped)
+    _step_streams(dev)[0].wait_stream(side)
+    return result
+
+
 class _Distortion(torch.autograd.Function):
     """apply(weights, spacing_bins, mult) -> (metric, mult * metric): the distortion metric of get_metrics_dict and the loss
     term get_loss_dict makes of it, from one launch; the saved gradient is the TERM's (already scaled by mult)."""
@@ -770,11 +857,8 @@ class _Distortion(torch.autograd.Function):
         R, n = weights.shape[0], weights.shape[1]
         w = _hip.require_device_tensor(weights.reshape(R, n), "weights")
         b = _hip.require_device_tensor(spacing_bins, "spacing_bins")
-        loss = _hip.fresh_zeros((2,), w.device)
-        g = _f32((R, n), w.device)
-        # the mean over rays and the loss multiplier are applied inside the kernel (loss and gradient): no elementwise launches around it
-        _hip.check(_hip.load().tn_distortion_loss_term(b.data_ptr(), w.data_ptr(), R, n, 1.0 / R, mult, loss.data_ptr(), g.data_ptr(),
-                                                       _stream()), "tn_distortion_loss_term")
+        pre = _take_precomputed(w.device, "dist", (w.data_ptr(), (R, n), b.data_ptr(), float(mult)))
+        loss, g = pre if pre is not None else _distortion_run(w, b, mult)
         ctx.g, ctx.shape, ctx.mult = g, weights.shape, mult
         ctx.set_materialize_grads(False)
         return loss[0], loss[1]
@@ -797,24 +881,16 @@ class _Interlevel(torch.autograd.Function):
         R, n = w.shape[0], w.shape[1]
         w2 = _hip.require_device_tensor(w.reshape(R, n), "weights")
         c2 = _hip.require_device_tensor(c, "bins")
-        loss = _hip.fresh_zeros((1,), w2.device)
-        lib = _hip.load()
-        ctx.g, ctx.shapes = [], []
-        L = len(levels) // 2
-        cps, wps, gs, ps = (C.c_void_p * L)(), (C.c_void_p * L)(), (C.c_void_p * L)(), (C.c_int32 * L)()
-        keep = []
-        for k, (wp, cp) in enumerate(zip(levels[0::2], levels[1::2])):
-            p = wp.shape[1]
-            wp2 = _hip.require_device_tensor(wp.reshape(R, p), "proposal weights")
-            cp2 = _hip.require_device_tensor(cp, "proposal bins")
-            g = _f32((R, p), wp2.device)
-            cps[k], wps[k], gs[k], ps[k] = cp2.data_ptr(), wp2.data_ptr(), g.data_ptr(), p
-            keep += [wp2, cp2]
-            ctx.g.append(g)
+        pairs = []
+        ctx.shapes = []
+        for wp, cp in zip(levels[0::2], levels[1::2]):
+            pairs.append((_hip.require_device_tensor(wp.reshape(R, wp.shape[1]), "proposal weights"),
+                          _hip.require_device_tensor(cp, "proposal bins")))
             ctx.shapes.append(wp.shape)
+        key = (w2.data_ptr(), (R, n), c2.data_ptr(), float(mult)) + tuple((wp2.data_ptr(), cp2.data_ptr()) for wp2, cp2 in pairs)
+        pre = _take_precomputed(w2.device, "inter", key)
         # both levels in one launch (they are independent and each is latency-bound), each scaled by mult / (R n)
-        _hip.check(lib.tn_interlevel_loss_levels(c2.data_ptr(), w2.data_ptr(), R, n, L, cps, wps, ps, mult / (R * n), loss.data_ptr(),
-                                                 gs, _stream()), "tn_interlevel_loss_levels")
+        loss, ctx.g = pre if pre is not None else _interlevel_run(mult, w2, c2, pairs)
         return loss[0]
 
     @staticmethod

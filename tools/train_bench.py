@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--one-launch", action="store_true", help="config.fused_backward_split = False")
     ap.add_argument("--no-spread", action="store_true", help="config.spread_coarse_scatter = False")
     ap.add_argument("--no-overlap", action="store_true", help="config.overlap_table_scatter = False")
+    ap.add_argument("--no-reg-overlap", action="store_true", help="config.overlap_regularisers = False")
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
@@ -39,7 +40,7 @@ def main():
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt,
                                  bucketed_table_scatter=not a.atomic_scatter, tape_free_training=not a.taped,
                                  fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread,
-                                 overlap_table_scatter=not a.no_overlap)
+                                 overlap_table_scatter=not a.no_overlap, overlap_regularisers=(False if a.no_reg_overlap else "auto"))
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
