@@ -327,7 +327,7 @@ int tn_hash_encode_bwd_spread(const tn_hashgrid *grid, const tn_space *space, co
  * record that does not fit its bin's region is added with global atomics instead); that function returns 0 — and tn_hash_encode_bwd_sorted
  * TN_ERR_UNSUPPORTED — for a geometry the bucketing does not cover (finest scaling + 2 >= 2^14 with more than one slice, or
  * >= 2^32 records).  tn_hash_encode_bwd_sorted_first_level: the level from which this form is the faster one on this part
- * (levels with a scaling >= 256, at least 128 (level, slice) bins), or -1: the caller runs tn_hash_encode_bwd_levels on the
+ * (levels with a scaling >= 200, at least 128 (level, slice) bins), or -1: the caller runs tn_hash_encode_bwd_levels on the
  * levels below it and this on the rest. */
 size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_t n, int32_t level_begin);
 int tn_hash_encode_bwd_sorted_first_level(const tn_hashgrid *grid, int64_t n);

@@ -227,7 +227,10 @@ constexpr int kSortSamples = TN_SORT_SAMPLES;  // samples per block of the emit 
 constexpr int kSortMaxOwners = 1024;       // log2_hashmap_size <= 24
 constexpr int kOwnerBlock = TN_OWNER_BLOCK;
 constexpr int kSortMinBins = 128;
-constexpr float kSortMinScaling = 256.0f;
+#ifndef TN_SORT_MIN_SCALING
+#define TN_SORT_MIN_SCALING 200.0f
+#endif
+constexpr float kSortMinScaling = TN_SORT_MIN_SCALING;  // 200: from level 8 of the reference grid (scalings 154 | 212.8 | 294)
 
 struct SortRec {
     unsigned owner[4];   // slice of the (y, z) combination
@@ -1982,9 +1985,12 @@ size_t tn_hash_encode_bwd_sorted_workspace_bytes(const tn_hashgrid *grid, int64_
 }
 
 // Where the bucketed form pays: the first level from which it should take over (the atomic kernel keeps the levels below), or
-// -1 = nowhere.  Measured on a real step's inputs (tools/scatter_bench.py --real --levels): below a scaling of ~256 the samples
+// -1 = nowhere.  Measured on a real step's inputs (tools/scatter_bench.py --real --levels): at the coarse levels the samples
 // of a ray — and of its neighbours — crowd into few entries and the owner pass's compare-and-swap adds retry (40-90 us per
-// level against 20-30 for the atomics); from there up the bucketed form costs 16-20 us per level against 29-33.  And one block
+// level against 20-30 for the atomics); from a scaling of ~256 up the bucketed form costs 16-20 us per level against 29-33.
+// With the run-writing emit pass (round 3c) the step is shortest with the split one level lower, at a scaling of 200 = level 8
+// of the reference grid: 2.55 against 2.63 ms per step at S=192 (levels 7 / 6 / 5: 2.68 / 2.64 / 2.70, and 3.1 - 3.7 ms on a
+// single-view batch, whose samples crowd), within noise at S = 48 ... 96; 8 levels x 32 slices = one bin per CU.  And one block
 // per bin owns a CU's LDS: fewer than 128 bins (the proposal grids: 5 levels x 8 slices) leave the chip idle behind a few long
 // buckets.
 int tn_hash_encode_bwd_sorted_first_level(const tn_hashgrid *grid, int64_t n) {

@@ -110,7 +110,7 @@ class NerfactoModelConfig:
     """Lower clamp of trunc_exp's backward, g * exp(clamp(x, min, 15)): -15 = nerfstudio's activations.trunc_exp (taken from
     torch-ngp, two-sided); float("-inf") = upper clamp only (SURVEY A.3 [UNSURE])."""
     bucketed_table_scatter: bool = True
-    """Training: hash-table gradient of the field's fine levels (scaling >= 256) as bucketed records + LDS sums instead of
+    """Training: hash-table gradient of the field's fine levels (scaling >= 200: levels 8-15) as bucketed records + LDS sums instead of
     global atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,
     2.24 against 2.27 at S=48 (DESIGN §5.6)."""
     spread_coarse_scatter: bool = True

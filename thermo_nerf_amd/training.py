@@ -103,7 +103,7 @@ def _step_streams(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch
 def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True,
                     overlap: bool = False, side_work=None) -> None:
     """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
-    ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 256, enough table slices: the
+    ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 200, enough table slices: the
     field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
     summed in LDS (tn_hash_encode_bwd_sorted: no global atomics; 25 B of scratch per (sample, level, corner pair)), the
     coarser levels keep the atomics.  An int (tests): bucketed from that level on, whatever the library advises.

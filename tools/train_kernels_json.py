@@ -32,8 +32,8 @@ def main():
         scat_us, scat_calls = group(r"hash_encode_bwd_kernel|spread_reduce_kernel|sort_emit_kernel|sort_owner_kernel")
         field_us, field_calls = group(r"field_fwd_taped_kernel<false>|field_bwd_fused_kernel|field_bwd_reduce_kernel|ray_head_")
         out["S" + S] = {
-            "kernel": "table-gradient scatter: hash_encode_bwd_kernel (levels 0-8 + proposal grids; coarsest levels through private "
-                      "dense copies + spread_reduce_kernel) + sort_emit_kernel / sort_owner_kernel (levels 9-15)",
+            "kernel": "table-gradient scatter: hash_encode_bwd_kernel (levels 0-7 + proposal grids; coarsest levels through private "
+                      "dense copies + spread_reduce_kernel) + sort_emit_kernel / sort_owner_kernel (levels 8-15)",
             "calls_per_step": scat_calls, "avg_us": scat_us / max(scat_calls, 1e-9), "us_per_step": scat_us,
             "tape_free_field_us_per_step": field_us, "tape_free_field_launches_per_step": field_calls,
             "all_kernels_us_per_step": tot, "launches_per_step": launches,
