@@ -52,6 +52,43 @@ hash_encode_fwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
     }
 }
 
+// ---- segmented wave scan on the vector unit ----------------------------------------------------------------------------
+// The run merging of the scatter kernels is an inclusive segmented scan over the 64 lanes (heads flagged).  As __shfl_up
+// steps it is 6 x (values + 1) ds_bpermute — the LDS pipe's work, next to the pass's own LDS adds (the owner pass without its
+// scan: 463 -> 370 us per 786 k-sample call).  The same combination tree on DPP: row_shr 1 / 2 / 4 / 8 inside the rows of 16,
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 (the GCN wave64 scan), with the flag riding along: a lane
+// that has no source, or is masked off, receives (flag 0, value 0) and stays as it is.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS, int NV>
+__device__ __forceinline__ void seg_scan_step(int &f, float (&v)[NV]) {
+    const int fu = dpp_i<CTRL, ROWS>(f);
+    float u[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) u[e] = dpp_f<CTRL, ROWS>(v[e]);
+    if (f == 0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] += u[e];
+        f = fu;
+    }
+}
+// f: 1 on the first lane of a run (lane 0 included), 0 elsewhere; v: per-lane values -> per-lane sums over the run up to the lane
+template <int NV>
+__device__ __forceinline__ void seg_scan_wave(int f, float (&v)[NV]) {
+    seg_scan_step<0x111, 0xf>(f, v);  // row_shr:1
+    seg_scan_step<0x112, 0xf>(f, v);  // row_shr:2
+    seg_scan_step<0x114, 0xf>(f, v);  // row_shr:4
+    seg_scan_step<0x118, 0xf>(f, v);  // row_shr:8
+    seg_scan_step<0x142, 0xa>(f, v);  // row_bcast:15 -> rows 1, 3
+    seg_scan_step<0x143, 0xc>(f, v);  // row_bcast:31 -> rows 2, 3
+}
+
 // Scatter-add of d_enc into the table.  Device-scope float atomics execute memory-side on this part (one fabric
 // transaction each, ~10 G/s measured whatever the address pattern), so the kernel's job is to issue fewer of them:
 // a wave takes 64 CONSECUTIVE samples (neighbours along a ray) at ONE level; samples in the same grid cell form
@@ -108,32 +145,14 @@ hash_encode_bwd_kernel(Grid g, tn_space space, const float *__restrict__ positio
         }
         // runs of lanes with identical floor AND ceil corners (=> identical 8 table entries)
         // (shuffles first, all lanes active: a short-circuit && would run them under divergence)
-        const int ufx = __shfl_up(fxi, 1, 64), ufy = __shfl_up(fyi, 1, 64), ufz = __shfl_up(fzi, 1, 64);
-        const int ucx = __shfl_up(cxi, 1, 64), ucy = __shfl_up(cyi, 1, 64), ucz = __shfl_up(czi, 1, 64);
+        // (all lanes active: the DPP moves read every lane's registers)
+        auto prev = [](int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); };  // wave_shr:1
+        const int ufx = prev(fxi), ufy = prev(fyi), ufz = prev(fzi), ucx = prev(cxi), ucy = prev(cyi), ucz = prev(czi);
         const bool same = (lane > 0) & (ufx == fxi) & (ufy == fyi) & (ufz == fzi) & (ucx == cxi) & (ucy == cyi) & (ucz == czi);
-        int head = same ? 0 : 1;
-        const int next_head = __shfl_down(head, 1, 64);  // unconditional: every lane must be active for the shuffle
-        const bool tail = (lane == 63) | (next_head != 0);
-        bool take[6];
-        {
-            int f = head;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int o = 1 << k;
-                const int fu = __shfl_up(f, o, 64);
-                take[k] = lane >= o && f == 0;
-                if (lane >= o) f |= fu;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int o = 1 << k;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float u = __shfl_up(v[e], o, 64);
-                if (take[k]) v[e] += u;
-            }
-        }
+        const int head = same ? 0 : 1;
+        const int next_head = __builtin_amdgcn_update_dpp(1, head, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63 keeps 1)
+        const bool tail = next_head != 0;
+        seg_scan_wave<16>(head, v);  // run sums on the vector unit (102 ds_bpermute as shuffle steps)
         const unsigned cx = (unsigned)cxi, cy = (unsigned)cyi, cz = (unsigned)czi;
         const unsigned fx = (unsigned)fxi, fy = (unsigned)fyi, fz = (unsigned)fzi;
         const unsigned hcy = cy * TN_P1, hfy = fy * TN_P1, hcz = cz * TN_P2, hfz = fz * TN_P2;
@@ -427,18 +446,14 @@ sort_owner_kernel(const unsigned *__restrict__ cursors, unsigned capacity, const
         const bool live = r < r1;
         const unsigned pk = live ? rec_pair[r] : 0xffffffffu - lane;  // dead lanes: distinct keys nobody shares
         float4 v = live ? rec_val[r] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const unsigned up = (unsigned)__shfl_up((int)pk, 1, 64);
-        int f = (lane > 0 && up == pk) ? 0 : 1;  // head of a run
-        const int next_head = __shfl_down(f, 1, 64);
-        const bool tail = (lane == 63) | (next_head != 0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int o = 1 << k;
-            const int fu = __shfl_up(f, o, 64);
-            const bool take = lane >= o && f == 0;
-            const float ux = __shfl_up(v.x, o, 64), uy = __shfl_up(v.y, o, 64), uz = __shfl_up(v.z, o, 64), uw = __shfl_up(v.w, o, 64);
-            if (take) { v.x += ux; v.y += uy; v.z += uz; v.w += uw; }
-            if (lane >= o) f |= fu;
+        const unsigned up = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x138, 0xf, 0xf, false);  // wave_shr:1 (lane 0: unused)
+        const int f = (lane > 0 && up == pk) ? 0 : 1;  // head of a run
+        const int next_head = __builtin_amdgcn_update_dpp(1, f, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63 keeps 1)
+        const bool tail = next_head != 0;
+        {
+            float sv[4] = {v.x, v.y, v.z, v.w};
+            seg_scan_wave<4>(f, sv);
+            v = make_float4(sv[0], sv[1], sv[2], sv[3]);
         }
         if (live && tail) {
             float *pa = slice + 2 * (pk & 0xffffu), *pb = slice + 2 * (pk >> 16);
