@@ -455,24 +455,51 @@ __device__ __forceinline__ void position_grad_finish(const Space &sp, float x, f
 }
 
 // ---- wave64 collectives ------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#ifndef TN_WAVE_SCAN_DPP
+#define TN_WAVE_SCAN_DPP 1
+#endif
+// The wave scans on the vector unit's data-parallel primitives instead of ds_bpermute steps (six dependent LDS round trips per
+// scan in kernels that are one latency chain per ray): row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast:15 into rows 1
+// and 3, row_bcast:31 into rows 2 and 3 — the GCN wave64 scan; a lane without a source keeps its value.  All lanes must be active.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
 }
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#if TN_WAVE_SCAN_DPP
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+#else
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const float t = __shfl_up(v, o, 64);
         if (lane >= o) v += t;
     }
+#endif
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#if TN_WAVE_SCAN_DPP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_scan(v, 0)), 63));
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
 }
 
 // exclusive prefix from an inclusive one (robust to inf entries: no inf - inf)
 __device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
+#if TN_WAVE_SCAN_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138, 0xf, 0xf, false));  // wave_shr:1, lane 0 <- 0
+#else
     const float up = __shfl_up(incl, 1, 64);
     return lane == 0 ? 0.0f : up;
+#endif
 }
 
 }  // namespace tn
