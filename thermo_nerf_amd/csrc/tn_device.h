@@ -492,6 +492,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 #endif
 }
 
+// one lane's value in every lane (v_readlane_b32: a scalar move, no LDS round trip; the lane must be active)
+template <int LANE>
+__device__ __forceinline__ float lane_value(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE));
+}
+
 // exclusive prefix from an inclusive one (robust to inf entries: no inf - inf)
 __device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
 #if TN_WAVE_SCAN_DPP

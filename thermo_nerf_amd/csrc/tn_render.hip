@@ -95,11 +95,11 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
         const float incl = wave_incl_scan(dd, lane);
         const float excl = carry + wave_excl_from_incl(incl, lane);
         const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-excl))) : 0.0f;
-        carry += __shfl(incl, 63, 64);
+        carry += lane_value<63>(incl);
         const float incl_w = wave_incl_scan(wi, lane) + carry_w;
         const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
         if (hit && med_idx == n) med_idx = base + __ffsll((long long)hit) - 1;
-        carry_w = __shfl(incl_w, 63, 64);
+        carry_w = lane_value<63>(incl_w);
         if (ok) wts[i] = wi;
     }
     const int idx = min(med_idx, n - 1);
@@ -132,7 +132,7 @@ __device__ __forceinline__ void pdf_resample(const float *wts, const float *bins
         }
         const float incl = wave_incl_scan(pdf, lane) + carry;
         if (i < n_in) cdf[i + 1] = fminf(1.0f, incl);
-        carry = __shfl(incl, 63, 64);
+        carry = lane_value<63>(incl);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -634,11 +634,11 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
             const float incl = wave_incl_scan(dd, lane);
             const float excl = carry + wave_excl_from_incl(incl, lane);
             const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-dd)), expf(-excl))) : 0.0f;
-            carry += __shfl(incl, 63, 64);
+            carry += lane_value<63>(incl);
             const float incl_w = wave_incl_scan(wi, lane) + carry_w;
             const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
             if (hit && med_idx == S) med_idx = base + __ffsll((long long)hit) - 1;
-            carry_w = __shfl(incl_w, 63, 64);
+            carry_w = lane_value<63>(incl_w);
             wsum += wi;
             wr += mul_rn(wi, c[0]);
             wg += mul_rn(wi, c[1]);

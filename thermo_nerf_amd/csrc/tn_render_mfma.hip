@@ -422,11 +422,11 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
             const float incl = wave_incl_scan(dd, lane);
             const float excl = carry + wave_excl_from_incl(incl, lane);
             const float wi = ok ? nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-excl))) : 0.0f;
-            carry += __shfl(incl, 63, 64);
+            carry += lane_value<63>(incl);
             const float incl_w = wave_incl_scan(wi, lane) + carry_w;
             const unsigned long long hit = __ballot(ok && (incl_w >= 0.5f));
             if (hit && med_idx == S) med_idx = base + __ffsll((long long)hit) - 1;
-            carry_w = __shfl(incl_w, 63, 64);
+            carry_w = lane_value<63>(incl_w);
             wsum += wi;
             wr += mul_rn(wi, cr);
             wg += mul_rn(wi, cg);

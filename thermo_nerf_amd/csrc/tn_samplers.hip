@@ -88,7 +88,7 @@ __global__ void weights_kernel(const float *__restrict__ deltas, const float *__
             const float alpha = sub_rn(1.0f, expf(-dd));
             w[i] = nan_to_num(mul_rn(alpha, expf(-excl)));
         }
-        carry += __shfl(incl, 63, 64);
+        carry += lane_value<63>(incl);
     }
 }
 
@@ -121,7 +121,7 @@ __global__ void sample_pdf_kernel(const float *__restrict__ weights, const float
         const float pdf = (i < n_in) ? add_rn(add_rn(w[i], 0.01f), pad_each) / ws : 0.0f;
         const float incl = wave_incl_scan(pdf, lane) + carry;
         if (i < n_in) cdf[i + 1] = fminf(1.0f, incl);
-        carry = __shfl(incl, 63, 64);
+        carry = lane_value<63>(incl);
     }
     for (int i = lane; i <= n_in; i += 64) bins[i] = ex[i];
     __builtin_amdgcn_wave_barrier();
@@ -221,7 +221,7 @@ __global__ void depth_kernel(const float *__restrict__ weights, const float *__r
         const float incl = wave_incl_scan(wi, lane) + carry;
         const unsigned long long hit = __ballot(ok && (incl >= 0.5f));
         if (hit && med_idx == n) med_idx = base + __ffsll((long long)hit) - 1;
-        carry = __shfl(incl, 63, 64);
+        carry = lane_value<63>(incl);
         wsum += wi;
         wsteps += mul_rn(wi, step);
         if (ok) {

@@ -1428,7 +1428,7 @@ weights_bwd_kernel(const float *__restrict__ deltas, const float *__restrict__ d
         const float rincl = wave_incl_scan_rev(gwv, lane);
         const float behind = rincl - gwv + suffix;  // sum_{i > k}
         if (live) out[i] = dl[i] * (gi * ea * T - behind);
-        suffix += __shfl(rincl, 0, 64);
+        suffix += lane_value<0>(rincl);
     }
 }
 
@@ -1456,7 +1456,7 @@ ray_render_fwd_kernel(const float *__restrict__ deltas, const float *__restrict_
         const float a = live ? mul_rn(dl[i], dn[i]) : 0.0f;
         const float incl = wave_incl_scan(a, lane);
         const float excl = wave_excl_from_incl(incl, lane) + carry;
-        carry += __shfl(incl, 63, 64);
+        carry += lane_value<63>(incl);
         const float w = live ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-a)), expf(-excl))) : 0.0f;
         if (live) {
             const long long t = ray * n + i;
@@ -1547,7 +1547,7 @@ ray_render_bwd_kernel(const float *__restrict__ deltas, const float *__restrict_
         const float rincl = wave_incl_scan_rev(gwv, lane);
         const float behind = rincl - gwv + suffix;  // sum_{k > i}
         if (live) d_dens[t] = dl[i] * (gi * ea * T - behind) * scale;
-        suffix += __shfl(rincl, 0, 64);
+        suffix += lane_value<0>(rincl);
     }
 }
 
@@ -1736,8 +1736,8 @@ distortion_kernel(const float *__restrict__ bins, const float *__restrict__ weig
             gw[ray * n + i] = gscale * (2.0f * Si + 2.0f * wi * di / 3.0f);
             loss += wi * Si + wi * wi * di / 3.0f;
         }
-        cW += __shfl(iw, 63, 64);
-        cWU += __shfl(iwu, 63, 64);
+        cW += lane_value<63>(iw);
+        cWU += lane_value<63>(iwu);
     }
     loss_acc += loss;
     }
@@ -1804,7 +1804,7 @@ __global__ void __launch_bounds__(kBlock) interlevel_kernel(InterlevelArgs a) {
         const float incl = wave_incl_scan(v, lane);
         if (k <= p) cum[k] = carry + incl - v;
         if (k <= p) { dlo[k] = 0.0f; if (k < p) dhi[k] = 0.0f; }
-        carry += __shfl(incl, 63, 64);
+        carry += lane_value<63>(incl);
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -1837,8 +1837,8 @@ __global__ void __launch_bounds__(kBlock) interlevel_kernel(InterlevelArgs a) {
         const float rh = wave_incl_scan_rev(vh, lane);
         const float rl = wave_incl_scan_rev(vl, lane);
         if (k < p) g_wp[ray * p + k] = scale * ((s_hi + rh) - (s_lo + rl));
-        s_hi += __shfl(rh, 0, 64);
-        s_lo += __shfl(rl, 0, 64);
+        s_hi += lane_value<0>(rh);
+        s_lo += lane_value<0>(rl);
     }
     loss_acc += loss;
     __builtin_amdgcn_wave_barrier();
