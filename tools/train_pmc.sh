@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes of the training step (rocprofv3 --pmc with --kernel-trace only), summarised on the GPU box:
-#   git rev-parse HEAD > tools/.head_stamp && gpurun -- 'bash tools/train_pmc.sh <tag> [samples] [kernel regex]'
+#   git rev-parse HEAD > tools/.head_stamp && gpurun -- 'bash tools/train_pmc.sh <tag> [samples] [kernel regex] [extra train_bench args]'
 # Writes gpurun_out/<tag>_pmc_train_S<S>.txt: mean counter value per dispatch for every kernel whose name matches the regex.
 tag=${1:-train}
 S=${2:-192}
@@ -9,7 +9,8 @@ repo=$(pwd)
 export TMPDIR=/tmp
 out=/tmp/pmc_${tag}_S${S}
 rm -rf $out; mkdir -p $out $repo/gpurun_out
-cmd="python $repo/tools/train_bench.py --steps 12 --warmup 3 --samples $S"
+shift; shift; shift
+cmd="python $repo/tools/train_bench.py --steps 12 --warmup 3 --samples $S $*"
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $out/a -o a -- $cmd > $out/a.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU \
