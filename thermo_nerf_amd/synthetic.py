@@ -170,3 +170,38 @@ def analytic_scene(origins: Tensor, directions: Tensor) -> Tuple[Tensor, Tensor]
     th_b = torch.full_like(th_s, 0.15)
     h = hit[..., None]
     return torch.where(h, rgb_s, rgb_b), torch.where(h, th_s, th_b)
+
+
+def analytic_room_scene(origins: Tensor, directions: Tensor, room_radius: float = 2.0) -> Tuple[Tensor, Tensor]:
+    """The sphere of ``analytic_scene`` inside a textured spherical room of radius ``room_radius`` (cameras inside it).  The
+    backdrop of ``analytic_scene`` is a function of the ray DIRECTION only — geometry at infinity, which a radiance field with a
+    view-dependent colour head can paint at any depth (a long optimisation at full capacity then parks it right in front of
+    the cameras and held-out views fall apart); here every pixel is a point in WORLD space, so parallax between the training
+    views pins the geometry, as it does for a captured scene.  Same contract as ``analytic_scene``."""
+    o, d = origins, directions
+    rgb_s, th_s = analytic_scene(o, d)
+    b = (o * d).sum(-1)
+    hit = ((b * b - ((o * o).sum(-1) - 0.3 * 0.3)) > 0) & (-b - torch.sqrt((b * b - ((o * o).sum(-1) - 0.09)).clamp_min(0)) > 0)
+    t_wall = -b + torch.sqrt((b * b - ((o * o).sum(-1) - room_radius * room_radius)).clamp_min(0))
+    p = o + d * t_wall[..., None]
+    x, y, z = p[..., 0], p[..., 1], p[..., 2]
+    tiles = torch.sin(3.0 * x + 1.0) * torch.sin(3.0 * y - 0.5) * torch.sin(3.0 * z + 2.0)
+    rgb_w = torch.stack([0.45 + 0.30 * torch.sin(2.2 * x + 0.7 * z) + 0.15 * tiles,
+                         0.40 + 0.25 * torch.sin(2.6 * y - 0.9 * x) - 0.15 * tiles,
+                         0.50 + 0.30 * torch.sin(2.4 * z + 1.1 * y)], dim=-1).clamp(0, 1)
+    th_w = (0.22 + 0.10 * torch.sin(1.7 * z + 0.6 * x) + 0.05 * tiles)[..., None].clamp(0, 1)
+    h = hit[..., None]
+    return torch.where(h, rgb_s, rgb_w), torch.where(h, th_s, th_w)
+
+
+def spiral_cameras(height: int, width: int, count: int, radius: float = 0.8, fov_deg: float = 50.0,
+                   elevation_range=(-15.0, 65.0), phase: float = 0.0):
+    """``count`` cameras looking at the origin from a golden-angle spiral over a band of elevations (even coverage of the band;
+    ``phase`` shifts the spiral so that a second set falls between the first one's cameras)."""
+    lo, hi = (math.sin(math.radians(e)) for e in elevation_range)
+    views, elev = [], []
+    for k in range(count):
+        u = (k + 0.5 + 0.37 * phase) / count
+        elev.append(math.degrees(math.asin(lo + (hi - lo) * u)))
+        views.append(((k + phase) * 137.50776405) % 360.0)
+    return orbit_cameras(height, width, views, num_views=360, radius=radius, fov_deg=fov_deg, elevation_deg=elev)
