@@ -270,6 +270,26 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
                         const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* One launch for SEVERAL of the reference's chunks, or for parts of them.  The one cross-ray quantity of the path is
+ * DepthRenderer("expected")'s clip to the [min, max] of the sample mid-points of its call = of one eval_num_rays_per_chunk chunk of
+ * the row-major frame [REF render/renderer.py:182-187 -> NS Model.get_outputs_for_camera_ray_bundle; REF config_thermal_nerf.py:30].
+ * tn_field_render_chunked_fwd is tn_field_render_fwd for rays [first_ray, first_ray + num_rays) of such a frame: it keeps one
+ * [min, max] pair per chunk the call touches (chunk = (first_ray + ray) / chunk_rays) and writes them to depth_bounds
+ * [tn_depth_bound_slots(...), 2] (device floats; slot 0 = the call's first chunk).
+ *   clip != 0: every ray's expected depth is clipped to its chunk's pair — a call that covers its chunks wholly (a whole frame in
+ *              one launch pair) then equals the reference's chunk-by-chunk loop bit for bit at the throughput of one launch;
+ *   clip == 0: expected_depth is left unclipped — the caller (ray sharding finer than the chunks, thermo_nerf_amd/distributed.py)
+ *              reduces the pairs with the other parts' (min / max over the ranks sharing a chunk) and applies
+ *              tn_expected_depth_clip_chunked with the reduced array.
+ * first_ray and chunk_rays must be multiples of 64 (a 64-ray wavefront tile never straddles two chunks): TN_ERR_UNSUPPORTED
+ * otherwise.  Same workspace precondition as tn_field_render_fwd. */
+int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays);
+int tn_field_render_chunked_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                                const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
+                                int64_t first_ray, int64_t chunk_rays, float *depth_bounds, int32_t clip, void *stream);
+int tn_expected_depth_clip_chunked(float *expected_depth, int64_t num_rays, int64_t first_ray, int64_t chunk_rays,
+                                   const float *depth_bounds, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Weight preparation (layout-only transforms, run once per weight update)
  * ---------------------------------------------------------------------------------------------------- */

@@ -55,6 +55,95 @@ def test_row_sharded_frame_gathers_back(h, w, chunk):
         assert shape == (h, w, 3)
 
 
+class ToyEngine:
+    """CPU stand-in with RayRenderEngine's shard interface: fake_render per ray, and — like the real path — an
+    ``expected_depth`` that is clipped to the [min, max] of a per-ray quantity over each ``chunk``-ray chunk of the frame."""
+
+    def __init__(self, chunk):
+        self.chunk = chunk
+
+    @staticmethod
+    def _mid(o, d):
+        return (o * 3.0 + d).sum(-1, keepdim=True) * 0.5
+
+    def render(self, o, d):  # the unsharded frame
+        out = fake_render(o, d)
+        mid = self._mid(o, d)
+        ed = out["expected_depth"].clone()
+        for i in range(0, o.shape[0], self.chunk):
+            m = mid[i:i + self.chunk]
+            ed[i:i + self.chunk] = ed[i:i + self.chunk].clamp(m.min() * 0.9, m.max() * 0.9)
+        out["expected_depth"] = ed
+        return out
+
+    def render_shard(self, o, d, start, frame_rays):
+        n = o.shape[0]
+        out = fake_render(o, d)  # expected_depth unclipped
+        mid = self._mid(o, d)
+        n_chunks = -(-frame_rays // self.chunk)
+        bounds = torch.tensor([[float("inf"), float("-inf")]] * n_chunks)
+        if n:
+            for c in range(start // self.chunk, (start + n - 1) // self.chunk + 1):
+                p0, p1 = max(c * self.chunk, start), min((c + 1) * self.chunk, frame_rays, start + n)
+                m = mid[p0 - start:p1 - start]
+                bounds[c, 0], bounds[c, 1] = m.min() * 0.9, m.max() * 0.9
+        return out, bounds
+
+    def apply_depth_bounds(self, out, start, bounds):
+        n = out["expected_depth"].shape[0]
+        for c in range(start // self.chunk, (start + n - 1) // self.chunk + 1) if n else ():
+            i, j = max(c * self.chunk, start) - start, min((c + 1) * self.chunk, start + n) - start
+            out["expected_depth"][i:j].clamp_(bounds[c, 0], bounds[c, 1])
+
+
+def _fine_worker(rank, world, port, h, w, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o, d, _ = synthetic.orbit_camera_rays(h, w, view=2)
+        eng = ToyEngine(chunk)
+        full = D.render_frame_sharded_fine(eng, o, d, align=4)
+        want = eng.render(o.reshape(-1, 3), d.reshape(-1, 3))
+        ok = all(torch.equal(full[k].reshape(-1, full[k].shape[-1]), want[k]) for k in D.OUTPUT_KEYS)
+        q.put((rank, ok, tuple(full["rgb"].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+# world sizes 2 and 3; chunks split between ranks, a short last chunk, one chunk for the whole frame, fewer tiles than ranks
+@pytest.mark.parametrize("h,w,chunk,world", [(16, 12, 50, 2), (16, 12, 50, 3), (7, 5, 64, 3), (16, 12, 48, 2), (1, 3, 64, 3)])
+def test_sub_chunk_sharded_frame_restores_the_chunk_wide_depth_clip(h, w, chunk, world):
+    """distributed.render_frame_sharded_fine: even ray shards that cut through the reference's chunks, the per-chunk clip bounds
+    joined by ONE all-reduce, the frame equal to the unsharded one (the toy engine clips per chunk like the real one)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fine_worker, args=(r, world, port, h, w, chunk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, shape in res:
+        assert ok, f"rank {rank} mismatch"
+        assert shape == (h, w, 3)
+
+
+def test_ray_blocks_are_even_whatever_the_chunk_size():
+    for n in (640000, 2073600, 100, 64, 5):
+        for world in (1, 2, 3, 8):
+            blocks = [D.ray_block(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            assert all(b[0] % 64 == 0 for b in blocks if b[0] < n)
+            sizes = [b[1] - b[0] for b in blocks]
+            assert max(sizes) - min(sizes) < 128  # one 64-ray tile, plus the frame's ragged last tile
+    # the headline frame over 8 ranks: 80 000 rays each (whole 65 536-ray chunks give 2, 2, 1, 1, 1, 1, 1, 1 chunks)
+    assert [b[1] - b[0] for b in (D.ray_block(640000, r, 8) for r in range(8))] == [80000] * 8
+
+
 def test_row_blocks_partition_the_image():
     for h in (1, 7, 800, 1080):
         for world in (1, 2, 3, 8):

@@ -85,6 +85,28 @@ def test_full_1080p_frame_properties():
         assert err.mean().item() <= tol and err.max().item() <= 20 * tol, (k, err.mean().item(), err.max().item())
 
 
+def test_camera_path_poses_through_the_plugin_surface_match_the_oracle():
+    """BASELINE config 4's loop [REF scripts/render_video_script.py:59-91, render/renderer.py:160-201] on three poses of the
+    reference's camera path (first, middle, last): Cameras.generate_rays -> get_outputs_for_camera_ray_bundle at the reference's
+    chunk size -> [1080,1920,C] frames, each against the CPU oracle on a strided sample of its rays (bench.py times all 96)."""
+    from oracle import hotpath as H
+    from tests import helpers
+    from thermo_nerf_amd import RayBundle
+
+    model, sd, cfg = _model()
+    for pose in (0, 48, 95):
+        o3, d3 = _frame_rays(pose)
+        out = model.get_outputs_for_camera_ray_bundle(RayBundle(origins=o3, directions=d3))
+        torch.cuda.synchronize()
+        assert out["rgb"].shape == (1080, 1920, 3) and out["thermal"].shape == (1080, 1920, 1) and out["depth"].shape == (1080, 1920, 1)
+        n = 1080 * 1920
+        idx = torch.linspace(0, n - 1, 768).long().to(DEV)
+        want = H.get_outputs(sd, o3.reshape(-1, 3)[idx].cpu(), d3.reshape(-1, 3)[idx].cpu(), None, helpers.oracle_config(cfg))
+        for k, tol in (("rgb", 1e-4), ("thermal", 1e-4), ("accumulation", 2e-5)):
+            err = (out[k].reshape(n, -1)[idx].cpu() - want[k]).abs()
+            assert err.mean().item() <= tol and err.max().item() <= 20 * tol, (pose, k, err.mean().item(), err.max().item())
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -169,6 +191,101 @@ def test_sharded_frame_two_ranks_sharing_the_gpu():
         assert r0[f"chunks.{k}"], f"chunk-aligned shard differs in {k}"
         if k != "expected_depth":
             assert r0[f"rows.{k}"], f"row-block shard differs in {k}"
+
+
+@pytest.mark.parametrize("h,w,chunk,world", [(800, 800, CHUNK, 8), (1080, 1920, CHUNK, 8), (300, 400, CHUNK, 3), (250, 300, CHUNK, 2),
+                                             (200, 300, 1 << 20, 4)])
+def test_sub_chunk_shards_reproduce_the_unsharded_frame(h, w, chunk, world):
+    """distributed.ray_block + RayRenderEngine.render_shard / apply_depth_bounds in ONE process: the shards all ``world`` ranks
+    would render (even runs of rays cut on multiples of 64, NOT on chunk boundaries: 800x800 over 8 ranks = 80 000 rays each
+    where whole chunks give 2, 2, 1, 1, 1, 1, 1, 1), their per-chunk depth bounds min/max-reduced as the all-reduce does, against
+    the unsharded frame: bit-equal in all seven outputs, expected depth included.  Frame sizes on both sides of the two
+    call-size thresholds of kernel_family="auto" (57 344 / 81 920 rays) and a frame that is one chunk."""
+    from thermo_nerf_amd import distributed as D
+    from thermo_nerf_amd import synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    model, _, _ = _model()
+    o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=5)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    n = h * w
+    eng = RayRenderEngine(model, chunk=chunk)
+    want = {k: v.clone() for k, v in eng.render(o, d).items()}
+    blocks = [D.ray_block(n, r, world) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) < 128  # one tile + the ragged last tile
+    shards = []
+    for a, b in blocks:
+        out, bounds = eng.render_shard(o[a:b].contiguous(), d[a:b].contiguous(), a, n)
+        shards.append(({k: v.clone() for k, v in out.items()}, a, bounds.clone()))
+    lo = torch.stack([b[:, 0] for _, _, b in shards]).min(dim=0).values
+    hi = torch.stack([b[:, 1] for _, _, b in shards]).max(dim=0).values
+    bounds = torch.stack([lo, hi], dim=1).contiguous()
+    assert torch.isfinite(bounds).all()  # every chunk of the frame was touched by some shard
+    for out, a, _ in shards:
+        eng.apply_depth_bounds(out, a, bounds)
+    torch.cuda.synchronize()
+    # the engine's own two forms of the unsharded frame agree as well: chunks fused into one launch pair (default) and one
+    # launch pair per chunk
+    # (from 81 920 rays per call both passes run lane = ray in either form; below, kernel_family="auto" may pick the
+    # ray-per-wave proposal pass for the one fused call and lane = ray for overlapping chunk calls: same tolerance, other bits)
+    if n >= 81920:
+        per_chunk = RayRenderEngine(model, chunk=chunk, fuse_chunks=False).render(o, d)
+        torch.cuda.synchronize()
+        for k in D.OUTPUT_KEYS:
+            assert torch.equal(per_chunk[k], want[k]), (k, "fused chunks differ from launch-per-chunk")
+    for k in D.OUTPUT_KEYS:
+        got = torch.cat([out[k] for out, _, _ in shards])
+        assert torch.equal(got, want[k]), (k, (got - want[k]).abs().max().item())
+
+
+def _fine_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from thermo_nerf_amd import distributed as D
+        from thermo_nerf_amd.engine import RayRenderEngine
+
+        model, _, _ = _model()
+        o3, d3 = _frame_rays(55)
+        eng = RayRenderEngine(model, chunk=CHUNK)
+        got = D.render_frame_sharded_fine(eng, o3, d3, device=torch.device(DEV))
+        torch.cuda.synchronize()
+        res = {}
+        if rank == 0:
+            want = eng.render(o3.reshape(-1, 3).contiguous(), d3.reshape(-1, 3).contiguous())
+            torch.cuda.synchronize()
+            for k in D.OUTPUT_KEYS:
+                res[k] = bool(torch.equal(got[k].reshape(want[k].shape), want[k]))
+        dist.barrier()
+        q.put((rank, res, None))
+    except Exception:  # pragma: no cover - surfaced by the parent
+        import traceback
+
+        q.put((rank, {}, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_fine_sharded_frame_three_ranks_sharing_the_gpu():
+    """render_frame_sharded_fine end to end: three gloo ranks on the one GPU render 691 200 rays each of a 1080p frame (10.5
+    chunks: every rank boundary falls inside a chunk), exchange the chunk bounds with one all-reduce and all-gather the pixels;
+    every rank's frame equals the unsharded one bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fine_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, r, err in res:
+        assert err is None, f"rank {rank}:\n{err}"
+    r0 = [r for rank, r, _ in res if rank == 0][0]
+    assert r0 and all(r0.values()), r0
 
 
 # ---- BASELINE config 5: per-GPU scene assignment = independent training replicas (no collective) ------------------------------------

@@ -653,6 +653,47 @@ def test_step_streams_do_not_change_the_step(update_step):
             assert torch.equal(on[n] == 0, g == 0), n
 
 
+def test_bucketed_proposal_grid_on_the_third_stream():
+    """A proposal grid large enough for the bucketed scatter (2^21 entries per level, max_res 256: level 4 = 128 table slices;
+    the reference's 2^17-entry grids never qualify) on an update step: its backward is queued on the step's third stream, where
+    the record workspace is a main-stream allocation that must outlive the call (it is handed to the caller's
+    ``keep`` list until the join).  Same gradients as the one-stream step, same table entries touched."""
+    from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+
+    nets = [{"hidden_dim": 16, "log2_hashmap_size": 21, "num_levels": 5, "max_res": 128, "use_linear": False},
+            {"hidden_dim": 16, "log2_hashmap_size": 21, "num_levels": 5, "max_res": 256, "use_linear": False}]
+    o, d = helpers.rays(16, 16, view=3)
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(3)
+    jit = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    cam = torch.randint(0, 8, (R, 1), generator=g)
+    batch = {"image": torch.rand(R, 3, generator=g), "thermal": torch.rand(R, 1, generator=g)}
+    got = {}
+    for overlap in (True, False):
+        cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=48, log2_hashmap_size=15, proposal_net_args_list=[dict(a) for a in nets],
+                                     camera_optimizer_mode="off", overlap_table_scatter=overlap)
+        gm = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
+        synthetic.fill_model_(gm, "scene")
+        gm = gm.to(DEV).train()
+        lib = _hip.load()
+        assert lib.tn_hash_encode_bwd_sorted_first_level(gm.proposal_networks[1].c_struct(dense=False).grid, R * 96) == 4
+        assert lib.tn_hash_encode_bwd_sorted_first_level(gm.proposal_networks[0].c_struct(dense=False).grid, R * 256) == -1
+        for _ in range(2):
+            gm.proposal_sampler._steps_since_update = 0
+            out, _ = _gpu_step(gm, o, d, jit, cam, batch)
+        assert out["weights_list"][1].requires_grad
+        torch.cuda.synchronize()
+        got[overlap] = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+        del gm
+        torch.cuda.empty_cache()
+    on, off = got[True], got[False]
+    assert set(on) == set(off) and "proposal_networks.1.mlp_base.encoder.hash_table" in on
+    for n, gr in off.items():
+        assert rel(on[n], gr) <= 1e-5, (n, rel(on[n], gr))
+        if n.endswith("hash_table"):
+            assert float(gr.abs().sum()) > 0 and torch.equal(on[n] == 0, gr == 0), n
+
+
 def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_dir):
     """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of the
     CPU reference path (torch autograd over the oracle; tests/test_config1_cpu.py runs them live, tools/make_config1_golden.py
@@ -1252,17 +1293,34 @@ def test_regularisers_launched_by_the_forward_equal_the_ones_launched_on_demand(
         else:
             assert torch.allclose(g0[n], g1[n], rtol=2e-5, atol=1e-9), n
 
-    # a forward whose regularisers are asked for with a different multiplier / different tensors: computed afresh, same numbers
+    # a forward whose regularisers are asked for with a different multiplier / different tensors: computed afresh, same
+    # numbers, and the forward's launch stays for a caller it does match
+    gm.config.overlap_regularisers = True
     rb = gm.collider(RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV)))
     out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
     assert TR._REG_PRE
+    entry = next(iter(TR._REG_PRE.values()))
     other = TR.distortion_loss(out["weights_list"], out["ray_samples_list"], mult=0.5 * gm.config.distortion_loss_mult)
-    assert "dist" not in next(iter(TR._REG_PRE.values()))  # consumed, not used
-    gm.config.overlap_regularisers = False
-    want = TR.distortion_loss(out["weights_list"], out["ray_samples_list"], mult=0.5 * gm.config.distortion_loss_mult)
-    assert torch.allclose(other, want, rtol=2e-6, atol=0)
+    assert "dist" in entry  # another multiplier: not served, not dropped
     clone = [w.clone() for w in out["weights_list"]]
     a = TR.interlevel_loss(clone, out["ray_samples_list"], mult=gm.config.interlevel_loss_mult)
-    assert not TR._REG_PRE  # the forward's launch was for other tensors: dropped
+    assert "inter" in entry  # other tensors: the same
     b = TR.interlevel_loss(out["weights_list"], out["ray_samples_list"], mult=gm.config.interlevel_loss_mult)
+    assert "inter" not in entry  # the forward's own tensors: served
     assert torch.allclose(a, b, rtol=2e-6, atol=0)
+    # an in-place edit between the forward and the losses.  The weights are views returned by the step's
+    # autograd Function: torch itself refuses to use them after an in-place edit.  The bins are plain outputs: their version
+    # counter is part of the key, so the distortion term is computed from the edited values, not served from the forward's launch
+    with torch.no_grad():
+        out["ray_samples_list"][-1].spacing_bins.mul_(0.5)
+    edited = TR.distortion_loss(out["weights_list"], out["ray_samples_list"], mult=gm.config.distortion_loss_mult)
+    assert "dist" in entry
+    gm.config.overlap_regularisers = False
+    want = TR.distortion_loss([w.clone() for w in out["weights_list"]], out["ray_samples_list"], mult=gm.config.distortion_loss_mult)
+    assert torch.allclose(edited, want, rtol=2e-6, atol=0)
+    fresh = TR.distortion_loss(out["weights_list"], out["ray_samples_list"], mult=0.5 * gm.config.distortion_loss_mult)
+    assert not torch.allclose(fresh, other, rtol=1e-3, atol=0)  # (the halved bins do change the term)
+    # what nobody collected is dropped (its side stream joined) by the backward of that forward, or by the next forward
+    assert TR._REG_PRE
+    (out["rgb"].sum() + out["thermal"].sum()).backward()
+    assert not TR._REG_PRE

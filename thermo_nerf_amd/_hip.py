@@ -179,6 +179,13 @@ SIGNATURES = {
         [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), C.POINTER(tn_render_inputs),
          C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
     ),
+    "tn_depth_bound_slots": (_i64, [_i64, _i64, _i64]),
+    "tn_field_render_chunked_fwd": (
+        C.c_int,
+        [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), C.POINTER(tn_render_inputs),
+         C.POINTER(tn_render_outputs), _i64, _vp, _sz, _i64, _i64, _vp, _i32, _vp],
+    ),
+    "tn_expected_depth_clip_chunked": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tn_hashgrid_prepare_bytes": (_sz, [C.POINTER(tn_hashgrid), _i64]),
     "tn_hashgrid_prepare": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_hashgrid), _vp, _sz, _vp]),
     "tn_field_prepare_bytes": (_sz, [C.POINTER(tn_thermal_field)]),

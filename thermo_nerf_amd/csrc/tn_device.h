@@ -454,6 +454,42 @@ __device__ __forceinline__ void position_grad_finish(const Space &sp, float x, f
     }
 }
 
+// ---- the expected-depth clip's running [min, max] of the sample mid-points ------------------------------------------
+// monotone float <-> uint key, so unsigned atomicMin / atomicMax order floats
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// Which [min, max] key pair a ray of a call belongs to.  DepthRenderer("expected") clips to the bounds of its CALL, which in the
+// reference is one eval_num_rays_per_chunk chunk of the frame; a launch that covers several such chunks (or parts of them:
+// tn_field_render_chunked_fwd) keeps one pair per chunk: chunk = (first_ray + ray) / chunk_rays, slot 0 = the call's first chunk.
+// chunk_rays == 0: one pair for the whole call.
+struct DepthSlots {
+    unsigned *keys;
+    long long first_ray, chunk_rays;
+    __device__ __forceinline__ long long slot(long long ray) const {
+        return chunk_rays > 0 ? (first_ray + ray) / chunk_rays - first_ray / chunk_rays : 0;
+    }
+};
+// wave-reduce the lanes' running bounds into the pair of `slot` (ONE atomic pair per wave and slot: per-ray atomics on one
+// address serialise in L2 at ~10 ns each) and restart them.  Every lane of the wave must be active.
+__device__ __forceinline__ void depth_bounds_flush(const DepthSlots &m, long long slot, float &smin, float &smax, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        smin = fminf(smin, __shfl_xor(smin, o, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0 && smin <= smax) {
+        atomicMin(&m.keys[2 * slot], f2key(smin));
+        atomicMax(&m.keys[2 * slot + 1], f2key(smax));
+    }
+    smin = INFINITY;
+    smax = -INFINITY;
+}
+
 // ---- wave64 collectives ------------------------------------------------------------------------------
 #ifndef TN_WAVE_SCAN_DPP
 #define TN_WAVE_SCAN_DPP 1
@@ -482,6 +518,9 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
 #endif
     return v;
 }
+// PRECONDITION (DPP form): every lane of the wave is active — lane 63 in particular, whose scan value is read back; a
+// caller inside divergent control flow must hoist the call out of it (all ~40 call sites sit at wave-uniform points: the
+// per-ray kernels run one ray per FULL wave and mask lanes by value, not by branch).
 __device__ __forceinline__ float wave_sum(float v) {
 #if TN_WAVE_SCAN_DPP
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_scan(v, 0)), 63));

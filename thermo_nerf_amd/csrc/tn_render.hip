@@ -26,11 +26,11 @@ using namespace tn;
 namespace tn {
 // implemented in tn_render_mfma.hip
 int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
-                     const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                     const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
                      hipStream_t stream);
 // implemented in tn_render_h3.hip
 int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
-                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
                    hipStream_t stream);
 }
 
@@ -564,16 +564,9 @@ struct MainArgs {
     int S, training, lin;
     float *rgb, *acc, *depth, *expected, *thermal;
     float *out_w;  // optional [R,S]
-    unsigned *minmax;
+    DepthSlots minmax;  // expected-depth clip bounds: one key pair per call, or per reference chunk of the frame
 };
 
-__device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
 
 constexpr int GF = 15;  // geo_feat_dim supported by the fused path
 
@@ -589,7 +582,12 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
     const int S = a.S, A = a.heads.app_dim;
     const long long stride = (long long)gridDim.x * kWaves;
     float smin = INFINITY, smax = -INFINITY;  // running over every ray this wave renders
+    long long mm_slot = 0;
     for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
+        if (a.minmax.chunk_rays > 0 && a.minmax.slot(r) != mm_slot) {  // (a wave's rays ascend: at most one change per chunk)
+            depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
+            mm_slot = a.minmax.slot(r);
+        }
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
         const float s_near = spacing_fn(a.nears[r], lin), s_far = spacing_fn(a.fars[r], lin);
@@ -674,15 +672,7 @@ __global__ void __launch_bounds__(kBlock) main_valu_kernel(MainArgs a) {
         }
     }
     // one atomic pair per wave (see main_mfma_kernel): per-ray returned atomics on one address serialise in L2
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        smin = fminf(smin, __shfl_xor(smin, o, 64));
-        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-    }
-    if (lane == 0 && smin <= smax) {
-        atomicMin(&a.minmax[0], f2key(smin));
-        atomicMax(&a.minmax[1], f2key(smax));
-    }
+    depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
 }
 
 __global__ void depth_clip_kernel(float *__restrict__ expected, long long num_rays, const unsigned *mm) {
@@ -690,6 +680,28 @@ __global__ void depth_clip_kernel(float *__restrict__ expected, long long num_ra
     if (r >= num_rays) return;
     const float lo = key2f(mm[0]), hi = key2f(mm[1]);
     expected[r] = fminf(fmaxf(expected[r], lo), hi);
+}
+
+// per-chunk key pairs of a chunked call (tn_field_render_chunked_fwd): reset | keys -> floats in place | clip by the ray's chunk
+__global__ void depth_slots_init_kernel(unsigned *keys, int slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < slots) {
+        keys[2 * i] = 0xffffffffu;
+        keys[2 * i + 1] = 0u;
+    }
+}
+
+__global__ void depth_slots_export_kernel(unsigned *keys, int slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * slots) keys[i] = __float_as_uint(key2f(keys[i]));  // (every slot holds at least one ray of the call)
+}
+
+__global__ void depth_clip_chunked_kernel(float *__restrict__ expected, long long num_rays, long long first_ray, long long chunk_rays,
+                                          const float *__restrict__ bounds) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rays) return;
+    const long long slot = (first_ray + r) / chunk_rays - first_ray / chunk_rays;
+    expected[r] = fminf(fmaxf(expected[r], bounds[2 * slot]), bounds[2 * slot + 1]);
 }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -819,9 +831,11 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
     return TN_OK;
 }
 
-int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
-                        const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
-                        void *stream) {
+// depth_bounds == nullptr: the call is one chunk (bounds in the workspace, clip applied).  Otherwise [slots, 2] device floats
+// that receive, per reference chunk the call touches, the [min, max] of this call's sample mid-points in it; clip: apply them.
+static int field_render_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                            const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
+                            int64_t first_ray, int64_t chunk_rays, float *depth_bounds, int clip, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!field || !in || !out) return TN_ERR_NULL;
     TN_TRY(check_render_common(cfg, num_rays, workspace, workspace_bytes));
@@ -833,7 +847,16 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
     const int S = cfg->num_nerf_samples;
     hipStream_t s = (hipStream_t)stream;
     const float *ws_spacing = reinterpret_cast<const float *>(workspace);
-    unsigned *minmax = ws_minmax(workspace, num_rays, S);
+    DepthSlots minmax{ws_minmax(workspace, num_rays, S), 0, 0};
+    int slots = 1;
+    if (depth_bounds) {
+        if (chunk_rays < 64 || chunk_rays % 64 != 0 || first_ray < 0 || first_ray % 64 != 0) return TN_ERR_UNSUPPORTED;
+        const int64_t n_slots = (first_ray + num_rays - 1) / chunk_rays - first_ray / chunk_rays + 1;
+        if (n_slots > (1 << 20)) return TN_ERR_SHAPE;
+        slots = (int)n_slots;
+        minmax = DepthSlots{reinterpret_cast<unsigned *>(depth_bounds), (long long)first_ray, (long long)chunk_rays};
+        hipLaunchKernelGGL(depth_slots_init_kernel, dim3((slots + 255) / 256), dim3(256), 0, s, minmax.keys, slots);
+    }
     // minmax was reset by tn_proposal_sample_fwd, which filled this workspace; the bounds are a function of the edges in
     // it alone, so re-running the field kernel on the same workspace re-derives the same two values (atomic min/max)
     // the split-precision kernel only exists in the lane = ray form: small calls take the exact-fp32 ray-per-wave kernel
@@ -861,8 +884,45 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
         hipLaunchKernelGGL(main_valu_kernel, dim3(ray_grid(num_rays, 2)), dim3(kBlock), main_smem, s, ma);
         TN_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(depth_clip_kernel, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, s, out->expected_depth,
-                       (long long)num_rays, minmax);
+    if (depth_bounds) {
+        hipLaunchKernelGGL(depth_slots_export_kernel, dim3((2 * slots + 255) / 256), dim3(256), 0, s, minmax.keys, slots);
+        if (clip)  // the call covers its chunks wholly; otherwise the clip waits for the other parts' bounds
+            hipLaunchKernelGGL(depth_clip_chunked_kernel, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, s,
+                               out->expected_depth, (long long)num_rays, (long long)first_ray, (long long)chunk_rays, depth_bounds);
+    } else {
+        hipLaunchKernelGGL(depth_clip_kernel, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, s, out->expected_depth,
+                           (long long)num_rays, minmax.keys);
+    }
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                        const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+    return field_render_fwd(field, cfg, in, out, num_rays, workspace, workspace_bytes, 0, 0, nullptr, 1, stream);
+}
+
+int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays) {
+    if (num_rays <= 0 || chunk_rays <= 0 || first_ray < 0) return 0;
+    return (first_ray + num_rays - 1) / chunk_rays - first_ray / chunk_rays + 1;
+}
+
+int tn_field_render_chunked_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                                const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
+                                int64_t first_ray, int64_t chunk_rays, float *depth_bounds, int32_t clip, void *stream) {
+    if (!depth_bounds) return TN_ERR_NULL;
+    return field_render_fwd(field, cfg, in, out, num_rays, workspace, workspace_bytes, first_ray, chunk_rays, depth_bounds,
+                            clip, stream);
+}
+
+int tn_expected_depth_clip_chunked(float *expected_depth, int64_t num_rays, int64_t first_ray, int64_t chunk_rays,
+                                   const float *depth_bounds, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!expected_depth || !depth_bounds) return TN_ERR_NULL;
+    if (num_rays < 0 || chunk_rays < 1 || first_ray < 0) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(depth_clip_chunked_kernel, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       expected_depth, (long long)num_rays, (long long)first_ray, (long long)chunk_rays, depth_bounds);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

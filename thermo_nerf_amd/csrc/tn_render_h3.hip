@@ -246,10 +246,6 @@ __device__ __forceinline__ float combine_halves(float2 p) {
     return lo + hi;
 }
 
-__device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
 
 struct H3Args {
     Grid g;
@@ -262,7 +258,7 @@ struct H3Args {
     long long R;
     int S, lin;
     float *rgb, *acc, *depth, *expected, *thermal;
-    unsigned *minmax;
+    DepthSlots minmax;  // expected-depth clip bounds: one key pair per call, or per reference chunk of the frame
     float early_eps;  // 0 = never stop early
 };
 
@@ -281,7 +277,13 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
     const long long groups = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
     float smin = INFINITY, smax = -INFINITY;
+    long long mm_slot = 0;
     for (long long grp = (long long)blockIdx.x * kWaves + wave; grp < groups; grp += stride) {
+        // (a tile never straddles two chunks: first_ray and chunk_rays are multiples of 64; a wave's tiles ascend)
+        if (a.minmax.chunk_rays > 0 && a.minmax.slot(grp * 64) != mm_slot) {
+            depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
+            mm_slot = a.minmax.slot(grp * 64);
+        }
         const long long r = grp * 64 + lane;
         const bool live = r < a.R;
         const long long rc = live ? r : a.R - 1;
@@ -461,15 +463,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        smin = fminf(smin, __shfl_xor(smin, o, 64));
-        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-    }
-    if (lane == 0 && smin <= smax) {
-        atomicMin(&a.minmax[0], f2key(smin));
-        atomicMax(&a.minmax[1], f2key(smax));
-    }
+    depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
 }
 
 inline bool h3_supported(const tn_thermal_field *f) {
@@ -481,7 +475,7 @@ inline bool h3_supported(const tn_thermal_field *f) {
 namespace tn {
 
 int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
-                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
                    hipStream_t stream) {
     if (!h3_supported(field) || !field->prepared_f16x3 || cfg->training) return TN_ERR_UNSUPPORTED;
     H3Args a;

@@ -150,7 +150,7 @@ struct MfmaArgs {
     int S, training, lin;
     float *rgb, *acc, *depth, *expected, *thermal;
     float *out_w;
-    unsigned *minmax;
+    DepthSlots minmax;  // expected-depth clip bounds: one key pair per call, or per reference chunk of the frame
     float early_eps;  // eval only; 0 = never stop early
 };
 
@@ -294,10 +294,6 @@ __device__ __forceinline__ float combine_halves(float2 p) {
     return lo + hi;
 }
 
-__device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
 
 __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -315,7 +311,12 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
     const int S = a.S;
     const long long stride = (long long)gridDim.x * kWaves;
     float smin = INFINITY, smax = -INFINITY;  // running over every ray this wave renders
+    long long mm_slot = 0;
     for (long long r = (long long)blockIdx.x * kWaves + wave; r < a.R; r += stride) {
+        if (a.minmax.chunk_rays > 0 && a.minmax.slot(r) != mm_slot) {  // (a wave's rays ascend: at most one change per chunk)
+            depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
+            mm_slot = a.minmax.slot(r);
+        }
         const float ox = a.origins[r * 3], oy = a.origins[r * 3 + 1], oz = a.origins[r * 3 + 2];
         const float dx = a.dirs[r * 3], dy = a.dirs[r * 3 + 1], dz = a.dirs[r * 3 + 2];
         const float s_near = spacing_fn(a.nears[r], lin), s_far = spacing_fn(a.fars[r], lin);
@@ -466,15 +467,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_kernel(MfmaArgs a) {
     }
     // call-global [min, max] of the sample mid-points (DepthRenderer "expected" clip): ONE atomic pair per wave for
     // all its rays.  (A returned atomic per ray on one address serialises at ~12 ns each in L2: 1.5 ms / 64k rays.)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        smin = fminf(smin, __shfl_xor(smin, o, 64));
-        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-    }
-    if (lane == 0 && smin <= smax) {
-        atomicMin(&a.minmax[0], f2key(smin));
-        atomicMax(&a.minmax[1], f2key(smax));
-    }
+    depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -530,7 +523,13 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
     const long long groups = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
     float smin = INFINITY, smax = -INFINITY;
+    long long mm_slot = 0;
     for (long long grp = (long long)blockIdx.x * kWaves + wave; grp < groups; grp += stride) {
+        // (a tile never straddles two chunks: first_ray and chunk_rays are multiples of 64; a wave's tiles ascend)
+        if (a.minmax.chunk_rays > 0 && a.minmax.slot(grp * 64) != mm_slot) {
+            depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
+            mm_slot = a.minmax.slot(grp * 64);
+        }
         const long long r = grp * 64 + lane;
         const bool live = r < a.R;
         const long long rc = live ? r : a.R - 1;  // idle lanes shadow the last ray (stores masked)
@@ -657,15 +656,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        smin = fminf(smin, __shfl_xor(smin, o, 64));
-        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-    }
-    if (lane == 0 && smin <= smax) {
-        atomicMin(&a.minmax[0], f2key(smin));
-        atomicMax(&a.minmax[1], f2key(smax));
-    }
+    depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
 }
 
 
@@ -927,7 +918,7 @@ inline bool mfma_supported(const tn_thermal_field *f) {
 namespace tn {
 
 int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
-                     const tn_render_outputs *out, long long num_rays, const float *spacing_ws, unsigned *minmax,
+                     const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
                      hipStream_t stream) {
     if (!mfma_supported(field) || !field->prepared) return TN_ERR_UNSUPPORTED;
     MfmaArgs a;

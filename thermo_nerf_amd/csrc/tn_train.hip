@@ -78,7 +78,9 @@ __device__ __forceinline__ void seg_scan_step(int &f, float (&v)[NV]) {
         f = fu;
     }
 }
-// f: 1 on the first lane of a run (lane 0 included), 0 elsewhere; v: per-lane values -> per-lane sums over the run up to the lane
+// f: 1 on the first lane of a run (lane 0 included), 0 elsewhere; v: per-lane values -> per-lane sums over the run up to the lane.
+// gfx9 DPP controls (row_shr, row_bcast:15 / :31; wave_shr / wave_shl in the neighbour moves): this library targets gfx950
+// only (no other target is built), and like tn_device.h's wave scans it needs every lane of the wave active at the call.
 template <int NV>
 __device__ __forceinline__ void seg_scan_wave(int f, float (&v)[NV]) {
     seg_scan_step<0x111, 0xf>(f, v);  // row_shr:1

@@ -119,6 +119,41 @@ def render_frame_sharded(render_fn: Callable[[Tensor, Tensor], Dict[str, Tensor]
     return gather_frame(local, h, w, group=group, counts=counts)
 
 
+def ray_block(num_rays: int, rank: int, world: int, align: int = 64) -> Tuple[int, int]:
+    """Rays [start, end) of a row-major frame owned by ``rank`` when the frame is cut into ``world`` contiguous runs whose
+    boundaries are multiples of ``align`` rays (64 = one wavefront tile of the lane = ray kernels): counts differ by at most one tile
+    ``align``, whatever the reference's chunk size — 10 chunks over 8 ranks are 80 000 rays each, not 2, 2, 1, 1, 1, 1, 1, 1 chunks."""
+    tiles = (num_rays + align - 1) // align
+    t0, t1 = row_block(tiles, rank, world)
+    return min(t0 * align, num_rays), min(t1 * align, num_rays)
+
+
+def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group=None, device: Optional[torch.device] = None,
+                              align: int = 64) -> Dict[str, Tensor]:
+    """``render_frame_sharded`` with EVEN shards (``ray_block``) that still reproduces the single-device frame bit for bit.  The
+    one cross-ray quantity — the expected-depth clip to the [min, max] sample mid-point of each ``engine.chunk``-ray chunk of
+    the frame — is restored by exchanging the per-chunk bounds: a rank renders the pieces of the chunks its run overlaps
+    (``engine.render_shard``), ONE all-reduce(min) of 2 floats per chunk of the frame (max as min of the negation) joins the
+    bounds of chunks split between ranks, ``engine.apply_depth_bounds`` clips, and the pixels are all-gathered as before.
+    ``engine``: a RayRenderEngine (or anything with its ``render_shard`` / ``apply_depth_bounds``)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    h, w = origins.shape[:2]
+    n = h * w
+    r0, r1 = ray_block(n, rank, world, align)
+    o = origins.reshape(-1, 3)[r0:r1].contiguous()
+    d = directions.reshape(-1, 3)[r0:r1].contiguous()
+    if device is not None:
+        o, d = o.to(device), d.to(device)
+    local, bounds = engine.render_shard(o, d, r0, n)
+    if world > 1:
+        key = torch.stack([bounds[:, 0], -bounds[:, 1]], dim=1).contiguous()
+        dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
+        bounds = torch.stack([key[:, 0], -key[:, 1]], dim=1).contiguous()
+    engine.apply_depth_bounds(local, r0, bounds)
+    counts = [ray_block(n, r, world, align)[1] - ray_block(n, r, world, align)[0] for r in range(world)]
+    return gather_frame(local, h, w, group=group, counts=counts)
+
+
 class PipelinedFrameGather:
     """Double-buffered asynchronous all-gather of whole rendered frames (weak scaling: every rank renders its own frame).
 

@@ -163,7 +163,9 @@ class HashMLPDensityField(nn.Module):
         plist = self.__dict__.get("_tn_plist")
         if plist is None:
             plist = self.__dict__["_tn_plist"] = list(self.parameters())
-        ptrs = tuple([p.data_ptr() for p in plist]) + (float(self.average_init_density),)
+        # (the struct holds the scene box by VALUE: an in-place change of the buffer must rebuild it)
+        ptrs = tuple([p.data_ptr() for p in plist]) + (self.aabb.data_ptr(), self.aabb._version, self.spatial_distortion is not None,
+                                                        float(self.average_init_density))
         hit = self.__dict__.get("_tn_train_struct")
         if hit is None or hit[0] != ptrs:
             hit = self.__dict__["_tn_train_struct"] = (ptrs, self.c_struct(dense=False))

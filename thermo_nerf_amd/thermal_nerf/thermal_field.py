@@ -147,7 +147,9 @@ class ThermalNerfactoTField(nn.Module):
         plist = self.__dict__.get("_tn_plist")
         if plist is None:
             plist = self.__dict__["_tn_plist"] = list(self.parameters())
-        ptrs = tuple([p.data_ptr() for p in plist]) + (self.sh_input, float(self.average_init_density),
+        # (the struct holds the scene box by VALUE: an in-place change of the buffer — a checkpoint with another box — must rebuild it)
+        ptrs = tuple([p.data_ptr() for p in plist]) + (self.aabb.data_ptr(), self.aabb._version, self.spatial_distortion is not None,
+                                                        self.sh_input, float(self.average_init_density),
                                                         bool(self.use_average_appearance_embedding),
                                                         _hip.current_stream() if prepare else 0)
         hit = self.__dict__.get("_tn_train_struct")

@@ -101,7 +101,7 @@ def _step_streams(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch
 
 
 def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True,
-                    overlap: bool = False, side_work=None) -> None:
+                    overlap: bool = False, side_work=None, keep: Optional[list] = None) -> None:
     """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
     ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 200, enough table slices: the
     field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
@@ -112,9 +112,11 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
     memory-side atomic unit / LDS + streaming), so the bucketed part runs on a second stream beside the atomic part; the
     calling stream continues when both are done.  ``side_work``: a callable with more launches that depend on neither part
     (the step's ray-level adjoints): queued on the calling stream behind the atomic part, before the join — the bucketed part
-    on the second stream is the longer of the two."""
+    on the second stream is the longer of the two.  ``keep``: the caller queues this call on another stream than the
+    allocator's (_STREAM_OVERRIDE) and holds the temporaries appended here — the record workspace — until it has joined that
+    stream (freed on return, the block could be handed to the main stream while the side stream still works in it)."""
     if side_work is not None and not overlap:
-        hash_encode_bwd(grid, space, pos, d_enc, d_table, bucketed, spread)
+        hash_encode_bwd(grid, space, pos, d_enc, d_table, bucketed, spread, keep=keep)
         side_work()
         return
     lib = _hip.load()
@@ -132,6 +134,8 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
         return
     try:
         ws = torch.empty(need, dtype=torch.uint8, device=pos.device)  # 25 B per (sample, level, corner pair): 0.14-0.6 GB, from torch's caching allocator
+        if keep is not None:
+            keep.append(ws)
     except torch.cuda.OutOfMemoryError:  # no room for the records: the same sums through the global atomics
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
         _hip.check(lib.tn_hash_encode_bwd_levels(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
@@ -387,7 +391,7 @@ def _proposal_level_bwd(net_struct, t: _LevelTape, g_w: Tensor, grads: Dict[str,
             g_hid = _f32((n, H), g_w.device)
             linear_bwd(t.hid, 0, H, None, g_raw, 1, net_struct.l1, ACT_NONE, n, g_hid, 0, H, False, grads[names[3]], grads[names[4]])
             linear_bwd(t.enc, 0, E, t.hid, g_hid, H, net_struct.l0, ACT_RELU, n, g_enc, 0, E, False, grads[names[1]], grads[names[2]])
-    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed, spread)
+    hash_encode_bwd(net_struct.grid, net_struct.space, t.pos, g_enc, grads[names[0]], bucketed, spread, keep=keep)
     if ray_grads is not None:
         _ray_grads_from_enc(net_struct.grid, net_struct.space, t, g_enc, *ray_grads, keep=keep)
 
@@ -568,6 +572,7 @@ class RenderTrain(torch.autograd.Function):
         model, f = ctx.model, ctx.field_tape
         cfg = model.config
         dev = ctx.o.device
+        _drop_precomputed((dev, _hip.current_stream()))  # side-stream regularisers of this forward that no loss collected
         h1, bo, cin, c1, c2, rgb_s, t1, t2, th_s = ctx.acts
         R, S = f.weights.shape
         N = R * S
@@ -808,11 +813,29 @@ def _interlevel_run(mult: float, w2: Tensor, c2: Tensor, levels: Sequence[Tuple[
 _REG_PRE: Dict = {}
 
 
+def _tensor_key(t: Tensor) -> Tuple[int, int, Tuple[int, ...]]:
+    """address, in-place version counter (shared by a tensor and its views) and shape: an in-place edit between the forward and
+    the loss changes the key, and the side-stream result is not served for it"""
+    return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _drop_precomputed(slot) -> None:
+    """forget a slot's side-stream results; the calling stream first joins the streams that write them (their outputs are the
+    main stream's allocations: released unjoined, the allocator could hand them out while a side kernel is still pending)"""
+    entry = _REG_PRE.pop(slot, None)
+    if entry is None:
+        return
+    main = _step_streams(slot[0])[0]
+    for which in ("dist", "inter"):
+        if which in entry:
+            main.wait_stream(entry[which][2])
+
+
 def _precompute_regularisers(model, w_levels: Sequence[Tensor], c_levels: Sequence[Tensor]) -> None:
     cfg = model.config
     dev = w_levels[-1].device
     slot = (dev, _hip.current_stream())
-    _REG_PRE.pop(slot, None)
+    _drop_precomputed(slot)  # an earlier forward's results nobody collected (an exception, a forward without losses)
     want = getattr(cfg, "overlap_regularisers", "auto")
     if want == "auto":
         # the side launches cost the host four stream joins (~40 us): they pay once the step's device time is well above its
@@ -825,26 +848,25 @@ def _precompute_regularisers(model, w_levels: Sequence[Tensor], c_levels: Sequen
     entry = {"hold": (list(w_levels), list(c_levels))}  # the inputs stay alive (and their addresses theirs) while the entry exists
     mult_d = float(cfg.distortion_loss_mult)
     if mult_d:
-        entry["dist"] = ((w2.data_ptr(), tuple(w2.shape), c2.data_ptr(), mult_d), _distortion_run(w2, c2, mult_d, second), second)
+        entry["dist"] = ((_tensor_key(w2), _tensor_key(c2), mult_d), _distortion_run(w2, c2, mult_d, second), second)
     mult_i = float(cfg.interlevel_loss_mult)
     levels = list(zip(w_levels[:-1], c_levels[:-1]))
-    key = (w2.data_ptr(), tuple(w2.shape), c2.data_ptr(), mult_i) + tuple((wp.data_ptr(), cp.data_ptr()) for wp, cp in levels)
+    key = (_tensor_key(w2), _tensor_key(c2), mult_i) + tuple((_tensor_key(wp), _tensor_key(cp)) for wp, cp in levels)
     entry["inter"] = (key, _interlevel_run(mult_i, w2, c2, levels, third), third)
     _REG_PRE[slot] = entry
 
 
 def _take_precomputed(dev, which: str, key):
-    """the side-stream result of this step's forward for exactly these inputs, joined into the calling stream — or None"""
+    """the side-stream result of this step's forward for exactly these inputs (same storage, shape, in-place version and
+    multiplier), joined into the calling stream — or None, and then the entry stays for a caller it does match"""
     slot = (dev, _hip.current_stream())
     entry = _REG_PRE.get(slot)
-    if entry is None or which not in entry:
+    if entry is None or which not in entry or entry[which][0] != key:
         return None
-    k, result, side = entry.pop(which)
+    _, result, side = entry.pop(which)
+    _step_streams(dev)[0].wait_stream(side)
     if not any(x in entry for x in ("dist", "inter")):
         _REG_PRE.pop(slot, None)
-    if k != key:
-        return None  # other tensors or another multiplier: computed afresh by the caller (the side launch is simply dropped)
-    _step_streams(dev)[0].wait_stream(side)
     return result
 
 
@@ -857,7 +879,7 @@ class _Distortion(torch.autograd.Function):
         R, n = weights.shape[0], weights.shape[1]
         w = _hip.require_device_tensor(weights.reshape(R, n), "weights")
         b = _hip.require_device_tensor(spacing_bins, "spacing_bins")
-        pre = _take_precomputed(w.device, "dist", (w.data_ptr(), (R, n), b.data_ptr(), float(mult)))
+        pre = _take_precomputed(w.device, "dist", (_tensor_key(w), _tensor_key(b), float(mult)))
         loss, g = pre if pre is not None else _distortion_run(w, b, mult)
         ctx.g, ctx.shape, ctx.mult = g, weights.shape, mult
         ctx.set_materialize_grads(False)
@@ -887,7 +909,7 @@ class _Interlevel(torch.autograd.Function):
             pairs.append((_hip.require_device_tensor(wp.reshape(R, wp.shape[1]), "proposal weights"),
                           _hip.require_device_tensor(cp, "proposal bins")))
             ctx.shapes.append(wp.shape)
-        key = (w2.data_ptr(), (R, n), c2.data_ptr(), float(mult)) + tuple((wp2.data_ptr(), cp2.data_ptr()) for wp2, cp2 in pairs)
+        key = (_tensor_key(w2), _tensor_key(c2), float(mult)) + tuple((_tensor_key(wp2), _tensor_key(cp2)) for wp2, cp2 in pairs)
         pre = _take_precomputed(w2.device, "inter", key)
         # both levels in one launch (they are independent and each is latency-bound), each scaled by mult / (R n)
         loss, ctx.g = pre if pre is not None else _interlevel_run(mult, w2, c2, pairs)
