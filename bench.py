@@ -42,7 +42,6 @@ FIELD_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 63 * 64 + 64 * 64 + 64 * 3 + 1
 PROP_FLOPS_PER_SAMPLE = 2 * (10 * 16 + 16)  # 352
 P0, P1 = 256, 96
 ATOMIC_SCATTER = False  # --atomic-scatter: config.bucketed_table_scatter = False in the train-step variants (A/B)
-ATOMIC_PEAK_GTPS = 21.0  # measured on MI355X: scattered fp32 atomic adds, transactions (64-byte lines) per second (tools/micro/atomics.hip)
 REF_CHUNK = 1 << 16  # REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:30
 
 
@@ -198,6 +197,28 @@ def load_profile_json(name: str):
     return json.load(open(p)) if os.path.exists(p) else {}
 
 
+def train_roofline_from_profiles(roof: dict, samples: int, step_s: float) -> None:
+    """What the committed accounting of the step (profiles/train_kernels.json: tools/train_account.sh + tools/line_census.py) adds
+    to a training roofline: `traffic` (HBM-side bytes of a whole step from the PMC passes), the critical-path time of every phase
+    (a step's kernels run on three streams: no sum of concurrent durations), and the SERIAL-PHASE view — the step is a chain of
+    phases that wait on different units, so each is priced against its own bound (forward: line-granular gathers at the measured
+    random-line rates; backward: 3 x the MLP flops at the fp32-MFMA peak; scatter: line-atomics at the measured atomic rate +
+    the fine levels' records at HBM rate) and the step against their sum.  Every fraction is <= 1 and recomputable from the
+    files named in `sources`."""
+    prof = load_profile_json("train_kernels.json").get("S%d" % samples)
+    if not prof or "critical_path_us_per_step" not in prof:
+        return
+    roof["traffic"] = prof["hbm_bytes_per_step"]
+    roof["traffic_over_algorithmic"] = prof["hbm_bytes_per_step"] / (roof["algorithmic_bytes_per_ray"] * 4096)
+    roof["critical_path_us_per_step"] = prof["critical_path_us_per_step"]
+    roof["serial_phase_view"] = {
+        "phase_bounds_us": prof["phase_bounds_us"], "phase_frac_in_the_profiled_step": prof["phase_frac"],
+        "serial_bound_us": prof["serial_bound_us"], "frac": prof["serial_bound_us"] * 1e-6 / step_s,
+        "dominant_phase": prof["dominant_phase"], "line_census": prof["line_census"]}
+    roof["profile"] = {"period_us": prof["period_us"], "launches_per_step": prof["launches_per_step"], "command": prof["command"],
+                       "commit": prof["commit"], "sources": prof["sources"]}
+
+
 def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, warmup: int = 24, start_step: int = 5000,
                        cpu: bool = True, ray_batch: str = "patch"):
     """Secondary measurement (BASELINE configs 3/5): one optimisation step = train-mode forward (tape-free
@@ -268,17 +289,7 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
                         "mfma_view": {"achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": tfl / MFMA_F32_PEAK_TFLOPS},
                         "kernel": "whole step (all launches between two optimizer steps)"}}
-    # what actually binds the step: the hash-table gradient scatter.  The memory side retires ~21 G atomic transactions per
-    # second, one per 64-byte line an instruction touches (tools/micro/atomics.hip).  Algorithmic transactions = samples x
-    # levels x 4 lines (the two x-neighbour corners of a (y, z) pair share a line); the proposal levels take gradient on one
-    # step in six after warm-up.
-    atom = (R * samples * 16 * 4 + R * (P0 + P1) * 5 * 4 / 6.0) / dt / 1e9
-    res["roofline"]["atomic_view"] = {"achieved": atom, "peak": ATOMIC_PEAK_GTPS, "unit": "G line-transactions/s",
-                                      "frac": atom / ATOMIC_PEAK_GTPS,
-                                      "note": "whole step time; the scatter kernel alone is priced in dominant_kernel"}
-    prof = load_profile_json("train_kernels.json").get("S%d" % samples)
-    if prof:
-        res["roofline"]["dominant_kernel"] = prof
+    train_roofline_from_profiles(res["roofline"], samples, dt)
     if cpu:
         from oracle import training as T
         from tests import helpers
@@ -390,7 +401,9 @@ def measure_train_config3(dev, samples: int = 192, steps: int = 30000, window: i
                      "frac": 3 * b_all * rays / (ms_half * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "mfma_view": {"achieved": 3 * f_all * rays / (ms_half * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": 3 * f_all * rays / (ms_half * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                     "algorithmic_bytes_per_ray": 3 * b_all, "algorithmic_flops_per_ray": 3 * f_all,
                      "kernel": "whole step (all launches between two optimizer steps), last half of the run"}}
+    train_roofline_from_profiles(res_d["roofline"], samples, ms_half * 1e-3)
     if cpu:
         # the trained weights through the default eval kernels against the CPU oracle on a strided sample of a held-out frame
         from oracle import hotpath as H

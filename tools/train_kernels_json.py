@@ -1,45 +1,50 @@
-"""profiles/train_kernels.json from the committed kernel traces of the training step (tools/train_profile.sh):
-usage: python tools/train_kernels_json.py profiles/<tag>_kernel_trace_train_S48.txt profiles/<tag>_kernel_trace_train_S192.txt [steps=42]
-Per configuration: the dominant kernel GROUP (the table-gradient scatter = hash_encode_bwd_kernel + spread_reduce + sort_*),
-its time per step, the tape-free field pair (field_fwd_taped_kernel<false> + field_bwd_fused_kernel<*> + reduce + ray_head_*),
-all kernel time and launches per step."""
-import csv
+"""profiles/train_kernels.json from the per-step accounting of the training step (tools/train_account.sh -> *_train_account_S*.json)
+and the cache-line census of a batch (tools/line_census.py -> *_line_census_S*.json):
+usage: python tools/train_kernels_json.py <account_S48.json> <account_S192.json> <census_S48.json> <census_S192.json>
+Per configuration: the critical-path time of every phase of a step (no double counting of concurrent kernels), the HBM-side bytes
+of a whole step from the PMC passes, and the per-phase bounds a step is priced against in bench.py (`serial_phase_view`):
+  field forward   line-granular gather bound of the census (wave-distinct lines / measured random-line rates)
+  field backward  3 x the field's MLP flops (recompute + dx + dW) at the fp32-MFMA peak
+  table scatter   line-atomics of the coarse levels at the measured atomic rate + the fine levels' records at HBM rate"""
 import json
 import os
-import re
 import sys
 
-
-def rows_of(path):
-    rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#") and l.strip()) if len(r) >= 5 and r[0] != "kernel"]
-    commit = next((l.split("commit", 1)[1].strip() for l in open(path) if l.startswith("# measured at commit")), "unknown")
-    return rows, commit
+MFMA_F32_PEAK = 157.3e12
+FIELD_FLOPS_PER_SAMPLE = 33024
 
 
 def main():
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 42
     out = {}
-    for path in sys.argv[1:3]:
-        S = re.search(r"_S(\d+)\.txt$", path).group(1)
-        rows, commit = rows_of(path)
-        tot = sum(float(r[2]) for r in rows) / steps
-        launches = sum(int(r[1]) for r in rows) / steps
-
-        def group(rx):
-            sel = [r for r in rows if re.search(rx, r[0])]
-            return sum(float(r[2]) for r in sel) / steps, sum(int(r[1]) for r in sel) / steps
-
-        scat_us, scat_calls = group(r"hash_encode_bwd_kernel|spread_reduce_kernel|sort_emit_kernel|sort_owner_kernel")
-        field_us, field_calls = group(r"field_fwd_taped_kernel<false>|field_bwd_fused_kernel|field_bwd_reduce_kernel|ray_head_")
-        out["S" + S] = {
-            "kernel": "table-gradient scatter: hash_encode_bwd_kernel (levels 0-7 + proposal grids; coarsest levels through private "
-                      "dense copies + spread_reduce_kernel) + sort_emit_kernel / sort_owner_kernel (levels 8-15)",
-            "calls_per_step": scat_calls, "avg_us": scat_us / max(scat_calls, 1e-9), "us_per_step": scat_us,
-            "tape_free_field_us_per_step": field_us, "tape_free_field_launches_per_step": field_calls,
-            "all_kernels_us_per_step": tot, "launches_per_step": launches,
-            "bound": "L2 atomic path (~21 G 64-byte-line fp32 atomics/s, ~1 per clock and XCD) for the atomic part; record streaming "
-                     "+ LDS compare-and-swap adds for the bucketed part (tools/micro/atomics*.hip, lds_atomics.hip; profiles/micro/)",
-            "source": path, "commit": commit}
+    for acct_path, census_path in zip(sys.argv[1:3], sys.argv[3:5]):
+        acct, census = json.load(open(acct_path)), json.load(open(census_path))
+        S = acct["samples_per_ray"]
+        assert census["samples_per_ray"] == S
+        cp = acct["phases"]["critical_path_us_per_step"]
+        n = census["samples"]
+        bounds = {"field_forward": census["gather_pass"]["bound_us"],
+                  "field_backward": 3.0 * FIELD_FLOPS_PER_SAMPLE * n / MFMA_F32_PEAK * 1e6,
+                  "table_scatter": census["scatter_pass"]["atomic_bound_us"] + census["scatter_pass"]["bucketed_bytes"] / 8e12 * 1e6}
+        out["S%d" % S] = {
+            "critical_path_us_per_step": cp, "period_us": acct["phases"]["period_us"],
+            "launches_per_step": acct["phases"]["launches_per_step"],
+            "sum_of_kernel_durations_us_per_step": acct["phases"]["sum_of_kernel_durations_us_per_step"],
+            "hbm_bytes_per_step": acct["traffic"]["hbm_bytes_per_step"],
+            "fetch_size_kb_per_step": acct["traffic"]["fetch_size_kb_per_step"],
+            "write_size_kb_per_step": acct["traffic"]["write_size_kb_per_step"],
+            "phase_bounds_us": {k: round(v, 1) for k, v in bounds.items()},
+            "phase_frac": {k: round(bounds[k] / cp[k], 3) for k in bounds},
+            "serial_bound_us": round(sum(bounds.values()), 1),
+            "line_census": {"wave_distinct_lines_per_gather_pass": census["gather_pass"]["wave_distinct_lines"],
+                            "algorithmic_lines_per_pass": census["algorithmic_lines_per_pass"],
+                            "atomic_line_transactions": census["scatter_pass"]["atomic_line_transactions"],
+                            "bucketed_records": census["scatter_pass"]["bucketed_records"],
+                            "rates_lines_per_s": census["rates_lines_per_s"],
+                            "step_line_granular_bound_us": round(census["step_line_granular_bound_us"], 1)},
+            "dominant_phase": max(("field_backward", "field_forward", "table_scatter"), key=lambda k: cp[k]),
+            "command": acct["command"], "commit": acct["commit"],
+            "sources": ["profiles/" + os.path.basename(acct_path), "profiles/" + os.path.basename(census_path)],
+            "method": acct["phases"]["method"] + "; " + acct["traffic"]["method"]}
     dst = os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "train_kernels.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
