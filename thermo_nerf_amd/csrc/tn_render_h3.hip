@@ -121,6 +121,14 @@ struct HL {
 #define MFMAH(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (acc), 0, 0, 0)
 
 __device__ __forceinline__ void mma3(f32x16 &acc, const HL &a, const HL &b) {
+#ifdef TN_H3_PROBE_SIX_PRODUCTS
+    // timing probe only: the matrix-pipe load of a SIX-product split (3 x bf16 pieces per operand) — three more
+    // MFMAs per step that add exact zeros
+    const v8h z = {0, 0, 0, 0, 0, 0, 0, 0};
+    MFMAH(acc, z, b.hi);
+    MFMAH(acc, z, b.lo);
+    MFMAH(acc, z, b.hi);
+#endif
     MFMAH(acc, a.lo, b.hi);
     MFMAH(acc, a.hi, b.lo);
     MFMAH(acc, a.hi, b.hi);
