@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate (= the FP32 vector rate)
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / f16 MFMA (AMD's 5 PF headline includes 2:1 sparsity)
 FIELD_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 63 * 64 + 64 * 64 + 64 * 3 + 15 * 64 + 64 * 64 + 64 * 1)  # 33 024
 PROP_FLOPS_PER_SAMPLE = 2 * (10 * 16 + 16)  # 352
 P0, P1 = 256, 96
@@ -88,8 +89,9 @@ def parse():
     ap.add_argument("--dense-mb", type=int, default=64, help="config.dense_grid_budget_mb (default = the config's default)")
     ap.add_argument("--field-dense-mb", type=int, default=16, help="config.field_dense_grid_budget_mb")
     ap.add_argument("--no-mfma", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
-                    help="MLP product arithmetic of the field kernel (f16x3 = three f16 MFMA products per fp32 product)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "f16x3"],
+                    help="MLP product arithmetic of the field kernel (bf16x6 = six bf16 MFMA products of an exact three-piece split per "
+                         "fp32 product; f16x3 = three f16 products of a two-piece split)")
     ap.add_argument("--early-eps", type=float, default=0.0,
                     help="early ray termination threshold (0 = off = the reference's arithmetic; NOT used for `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -506,7 +508,7 @@ def roofline_of(S, n_rays, steps, prop_ms, main_ms, precision, no_mfma, value_pe
                   "frac": tflops / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_ray": FIELD_FLOPS_PER_SAMPLE * S})
     # HBM-side bytes per launch from the committed rocprofv3 PMC pass of this same command (FETCH_SIZE + WRITE_SIZE of the
     # dominant kernel, scaled to this launch size); see profiles/ for the raw counters
-    t = load_profile_json("pmc_traffic.json").get("%s@S%d%s" % (dominant, S, "" if precision == "f32" else "_f16x3"))
+    t = load_profile_json("pmc_traffic.json").get("%s@S%d%s" % (dominant, S, "" if precision == "f32" else "_" + precision))
     if t:
         r["traffic"] = (t["fetch_kb"] + t["write_kb"]) * 1024.0 * rays_per_launch / t["rays_per_launch"]
         r["traffic_source"] = t["source"]
@@ -808,7 +810,7 @@ def main():
             "metric": "rays/sec (forward-only render) @ %dx%d, %d samples/ray" % (W_, H_, S),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via 3xf16-split MFMA products",
+            "vs_baseline": None, "dtype": {"f32": "f32", "f16x3": "f32 via 3xf16-split MFMA products", "bf16x6": "f32 via 6xbf16-split MFMA products"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "%s: synthetic %dx%d RGB+thermal scene, P=(256,96)+%d samples/ray, chunk %d, "
                                    "forward-only eval, %s weights%s" % (
@@ -847,12 +849,26 @@ def main():
                 torch.cuda.synchronize()
                 return reps * n_rays / (time.perf_counter() - t1)
 
-            # the opt-in split-precision field kernel on the same frame (NOT the headline value)
-            model.config.mlp_precision = "f16x3"
-            v = quick(engine)
-            variants["f16x3"] = {"what": "field MLP products as 3 f16 MFMA products each, fp32 accumulate (mlp_precision=f16x3), "
-                                         "same %d-sample frame" % S, "value": v, "unit": "rays/s"}
-            capture("f16x3", out)
+            # the opt-in split-precision field kernels on the same frame (NOT the headline value)
+            for prec, what in (("bf16x6", "field MLP products as 6 bf16 MFMA products of an exact three-piece (24-bit) operand split each, "
+                                          "fp32 accumulate: 2^-23 relative per product, fp32's own rounding size (mlp_precision=bf16x6)"),
+                               ("f16x3", "field MLP products as 3 f16 MFMA products of a two-piece (22-bit) split each, fp32 accumulate "
+                                         "(mlp_precision=f16x3)")):
+                model.config.mlp_precision = prec
+                quick(engine, 1)
+                e_p, p_p, m_p = timed_frames(engine, o, d, out, 4, 1)
+                products = {"bf16x6": 6, "f16x3": 3}[prec]
+                f_ms = sum(m_p) / len(m_p)
+                tfl = products * FIELD_FLOPS_PER_SAMPLE * S * n_rays / (f_ms * 1e-3) / 1e12
+                variants[prec] = {"what": what + ", same %d-sample frame" % S, "value": n_rays * 4 / e_p, "unit": "rays/s",
+                                  "ms_per_step": e_p / 4 * 1e3, "proposal_ms": sum(p_p) / len(p_p), "field_ms": f_ms,
+                                  "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_16BIT_PEAK_TFLOPS,
+                                               "achieved": tfl, "frac": tfl / MFMA_16BIT_PEAK_TFLOPS,
+                                               "what": "16-bit MFMA flops actually issued by the field kernel: %d piece products per fp32 "
+                                                       "product x the field's %d MLP flops per sample, against the dense bf16 / f16 MFMA peak; "
+                                                       "in fp32-equivalent flops: %.1f TFLOP/s (the exact-fp32 MFMA peak is %.1f)" % (
+                                                           products, FIELD_FLOPS_PER_SAMPLE, tfl / products, MFMA_F32_PEAK_TFLOPS)}}
+                capture(prec, out)
             model.config.mlp_precision = "f32"
             # opt-in early ray termination (wave-wide transmittance vote), exact-fp32 kernels; outputs move by <= eps
             engine.rc.early_stop_transmittance = 1e-3
@@ -918,7 +934,7 @@ def main():
             line["parity"] = {"rgb_mae": rgb_mae, "thermal_mae": th_mae,
                               "rgb_psnr_db_vs_oracle": float(10 * torch.log10(1.0 / ((got_rgb - want["rgb"]) ** 2).mean().clamp_min(1e-20)))}
             line["speedup_vs_cpu"] = value / base["value"]
-            for tag in ("f16x3", "early_termination_1e-3"):
+            for tag in ("bf16x6", "f16x3", "early_termination_1e-3"):
                 if tag in captured and "variants" in line and tag in line["variants"]:
                     line["variants"][tag]["rgb_mae"], line["variants"][tag]["thermal_mae"], _ = err(tag)
         print(json.dumps(line), flush=True)

@@ -105,6 +105,11 @@ typedef struct tn_thermal_field {
      * field kernel can evaluate each fp32 product as three f16 MFMA products accumulated in fp32 (~2^-22 relative
      * product error, needs |activation| < 65504).  Takes precedence over `prepared` for eval calls when non-NULL. */
     const float *prepared_f16x3;
+    /* optional blob produced by tn_field_prepare_bf16x6: every fp32 weight as THREE bf16 pieces (24 significand bits: the split is
+     * exact) so that the eval field kernel can evaluate each fp32 product as the six piece products of order <= 2, accumulated in
+     * fp32: a per-product error of 2^-23 relative — fp32's own rounding size — at the matrix cores' bf16 rate.  Takes precedence
+     * over `prepared_f16x3` and `prepared` for eval calls when non-NULL. */
+    const float *prepared_bf16x6;
 } tn_thermal_field;
 
 /* ------------------------------------------------------------------------------------------------------
@@ -303,9 +308,11 @@ int tn_hashgrid_prepare(const tn_hashgrid *grid_in, tn_hashgrid *grid_out, void 
 size_t tn_field_prepare_bytes(const tn_thermal_field *field);
 int tn_field_prepare(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
 
-/* split-precision variant of the above (see tn_thermal_field.prepared_f16x3). */
+/* split-precision variants of the above (see tn_thermal_field.prepared_f16x3 / prepared_bf16x6). */
 size_t tn_field_prepare_f16x3_bytes(const tn_thermal_field *field);
 int tn_field_prepare_f16x3(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
+size_t tn_field_prepare_bf16x6_bytes(const tn_thermal_field *field);
+int tn_field_prepare_bf16x6(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Training step: forward with a tape of per-sample activations, losses, backward.

@@ -381,26 +381,85 @@ def test_get_outputs_eval(kind, S, impl):
     check_outputs(got, want, f"{kind}/S{S}/fused={fused}")
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("kind", ["init", "stress", "scene"])
 @pytest.mark.parametrize("S", [48, 64, 192])
-def test_get_outputs_eval_f16x3_split(kind, S):
-    """Opt-in split-precision field kernel (each fp32 product = three f16 MFMA products, fp32 accumulate): held to
-    the SAME tolerances as the exact-fp32 kernels, and compared against the fp32 MFMA kernel on the same rays."""
+def test_get_outputs_eval_split_precision(kind, S, precision):
+    """Opt-in split-precision field kernels (f16x3: each fp32 product = three f16 MFMA products of two pieces per operand;
+    bf16x6: six bf16 products of three pieces = an exact 24-bit split; fp32 accumulate): held to the SAME tolerances as the
+    exact-fp32 kernels, and compared against the fp32 MFMA kernel on the same rays."""
     gm, sd, ocfg = gpu_model(kind, S)
-    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f16x3"
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, precision
     _, _, fld = gm._c_structs()
-    assert fld.prepared_f16x3, "tn_field_prepare_f16x3 produced no blob"
+    assert fld.prepared_f16x3 if precision == "f16x3" else fld.prepared_bf16x6, "the split-precision prepare produced no blob"
+    assert not (fld.prepared_f16x3 and fld.prepared_bf16x6)
     o, d = helpers.rays(20, 20, view=(S + 3) % 8)
     want = H.get_outputs(sd, o, d, None, ocfg)
     with torch.no_grad():
         got = gm(bundle(o, d))
         gm.config.mlp_precision = "f32"
         ref = gm(bundle(o, d))
-    check_outputs(got, want, f"f16x3 {kind}/S{S}")
+    check_outputs(got, want, f"{precision} {kind}/S{S}")
     for k in ("rgb", "thermal"):
         d_split = (got[k].cpu() - want[k]).abs().max().item()
         d_f32 = (ref[k].cpu() - want[k]).abs().max().item()
         assert d_split <= max(8 * d_f32, 5e-6), f"{k}: split {d_split:.2e} vs fp32 kernel {d_f32:.2e}"
+
+
+def _to64(sd):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("kind", ["init", "stress", "scene", "trained"])
+def test_bf16x6_is_an_fp32_evaluation_in_another_order(kind):
+    """The claim behind mlp_precision="bf16x6" (DESIGN 5.3): three bf16 pieces hold an fp32 operand exactly and the six products kept
+    leave a per-product error of 2^-23 relative — fp32's own rounding size —, so the kernel is AN fp32 evaluation of the field, as
+    far from the exact (fp64) value as any other summation order.  Yardstick: the oracle run in fp64 on the same weights and rays.
+    The bf16x6 frame's mean distance from it must not exceed the exact-fp32-MFMA kernel's own distance by more than a quarter
+    (both are rounding noise of the same size; f16x3, with 22-bit operands, is reported beside them), on the three synthetic fills
+    and on TRAINED weights: the 1000-iteration config-1 problem (tests/helpers.py), trained here on the HIP path."""
+    S = 24 if kind == "trained" else 64
+    if kind == "trained":
+        from thermo_nerf_amd import training as TR
+
+        prob = helpers.config1_problem()
+        gm = copy.deepcopy(prob["model"]).to(DEV).train()
+        ocfg, sd0 = prob["ocfg"], prob["sd"]
+        params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
+        opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, fused=True)
+        o_all, d_all, cam_all = prob["o"].to(DEV), prob["d"].to(DEV), prob["cam"].to(DEV)
+        img, th, idx = prob["image"].to(DEV), prob["thermal"].to(DEV), prob["idx"].to(DEV)
+        jitter = prob["jitter"].squeeze(-1).to(DEV)
+        for i in range(400):
+            gm.set_step(i)
+            ix = idx[i]
+            rb = gm.collider(RayBundle(origins=o_all[ix], directions=d_all[ix], camera_indices=cam_all[ix]))
+            out = TR.get_outputs_train(gm, rb, jitter=jitter[i].contiguous())
+            b = {"image": img[ix], "thermal": th[ix]}
+            loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        gm.eval()
+        gm.config.kernel_family = "lane_ray"
+        gm.invalidate_prepared()
+        sd = {**sd0, **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in sd0}}
+        o, d = prob["held_out"]["o"], prob["held_out"]["d"]
+        anneal = float(gm.proposal_sampler._anneal)
+    else:
+        gm, sd, ocfg = gpu_model(kind, S)
+        o, d = helpers.rays(24, 24, view=5)
+        anneal = 1.0
+    want64 = H.get_outputs(_to64(sd), o.double(), d.double(), None, ocfg, anneal=anneal)
+    dist = {}
+    for precision in ("f32", "bf16x6", "f16x3"):
+        gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, precision
+        with torch.no_grad():
+            got = gm(bundle(o, d))
+        dist[precision] = {k: (got[k].cpu().double().reshape(-1) - want64[k].reshape(-1)).abs().mean().item() for k in ("rgb", "thermal")}
+    print(f"{kind}: mean |x - fp64 oracle|  " + "  ".join(f"{p}: rgb {v['rgb']:.2e} thermal {v['thermal']:.2e}" for p, v in dist.items()))
+    for k in ("rgb", "thermal"):
+        assert dist["bf16x6"][k] <= 1.25 * dist["f32"][k] + 2e-8, (kind, k, dist)
 
 
 @pytest.mark.parametrize("impl", list(IMPLS))
@@ -523,12 +582,12 @@ VARIANTS = {
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-@pytest.mark.parametrize("impl", ["mfma", "f16x3", "modular"])
+@pytest.mark.parametrize("impl", ["mfma", "f16x3", "bf16x6", "modular"])
 def test_config_variants(variant, impl):
     S = 40 if variant == "other_sample_counts" else 48
     gm, sd, ocfg = gpu_model("stress", S, **VARIANTS[variant])
-    if impl == "f16x3":
-        gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f16x3"
+    if impl in ("f16x3", "bf16x6"):
+        gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, impl
     else:
         gm.config.fused, gm.config.use_mfma = IMPLS[impl]
         gm.config.mlp_precision = "f32"
@@ -544,7 +603,7 @@ def test_config_variants(variant, impl):
 # --------------------------------------------------------------------------------------------------
 # early ray termination (opt-in; the reference has none, so 0 must be exact and eps > 0 bounded by eps)
 # --------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x6"])
 def test_early_ray_termination_is_bounded_by_eps(precision):
     gm, _, _ = gpu_model("scene", 64)
     gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, precision
@@ -574,7 +633,7 @@ def test_early_ray_termination_is_bounded_by_eps(precision):
         assert torch.equal(early[k], exact[k]), k
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x6"])
 def test_checkpoint_load_invalidates_prepared_weights(tmp_path, precision):
     """Render, load a nerfstudio-layout checkpoint holding other weights into the SAME device model, render again:
     the prepared MFMA blobs must be rebuilt (outputs follow the oracle on the new weights)."""

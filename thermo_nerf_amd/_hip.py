@@ -100,6 +100,7 @@ class tn_thermal_field(C.Structure):
         ("average_init_density", C.c_float),
         ("prepared", C.c_void_p),
         ("prepared_f16x3", C.c_void_p),
+        ("prepared_bf16x6", C.c_void_p),
     ]
 
 
@@ -192,6 +193,8 @@ SIGNATURES = {
     "tn_field_prepare": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _sz, _vp]),
     "tn_field_prepare_f16x3_bytes": (_sz, [C.POINTER(tn_thermal_field)]),
     "tn_field_prepare_f16x3": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _sz, _vp]),
+    "tn_field_prepare_bf16x6_bytes": (_sz, [C.POINTER(tn_thermal_field)]),
+    "tn_field_prepare_bf16x6": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _sz, _vp]),
     # training step
     "tn_hash_encode_fwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _i64, _vp, _vp, _vp]),
     "tn_hash_encode_bwd": (C.c_int, [C.POINTER(tn_hashgrid), C.POINTER(tn_space), _vp, _vp, _i64, _vp, _vp]),

@@ -28,7 +28,10 @@ namespace tn {
 int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                      const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
                      hipStream_t stream);
-// implemented in tn_render_h3.hip
+// implemented in tn_render_h3.hip (the two split-precision policies of one kernel)
+int launch_main_b6(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
+                   hipStream_t stream);
 int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                    const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
                    hipStream_t stream);
@@ -860,8 +863,10 @@ static int field_render_fwd(const tn_thermal_field *field, const tn_render_confi
     // minmax was reset by tn_proposal_sample_fwd, which filled this workspace; the bounds are a function of the edges in
     // it alone, so re-running the field kernel on the same workspace re-derives the same two values (atomic min/max)
     // the split-precision kernel only exists in the lane = ray form: small calls take the exact-fp32 ray-per-wave kernel
-    if (field->prepared_f16x3 && !cfg->training && !out->weights[2] && cfg->kernel_family != 2 &&
-        (num_rays >= 40960 || cfg->kernel_family == 1)) {
+    const bool split_ok = !cfg->training && !out->weights[2] && cfg->kernel_family != 2 && (num_rays >= 40960 || cfg->kernel_family == 1);
+    if (field->prepared_bf16x6 && split_ok) {
+        TN_TRY(launch_main_b6(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
+    } else if (field->prepared_f16x3 && split_ok) {
         TN_TRY(launch_main_h3(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
     } else if (field->prepared) {
         TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));

@@ -1,5 +1,12 @@
-// main_h3_rays_kernel — the eval field kernel (lane = ray, see tn_render_mfma.hip) with every fp32 product of the
-// five MLP layers evaluated as THREE f16 MFMA products, accumulated in fp32:
+// main_split_rays_kernel<P> — the eval field kernel (lane = ray, see tn_render_mfma.hip) with every fp32 product of the five MLP
+// layers evaluated as a few low-precision MFMA products of operand PIECES, accumulated in fp32.  Two policies:
+//
+//   BF16x6 (mlp_precision = "bf16x6", round 4): a = p1 + p2 + p3 EXACTLY (three bf16 pieces = 24 significand bits, fp32's exponent
+//     range: p1 = bf16(a), p2 = bf16(a - p1), p3 = bf16(a - p1 - p2); every residual is exact in fp32), and likewise w; of the
+//     nine piece products the six of order <= 2 are kept: p1q1 + p1q2 + p2q1 + p2q2 + p1q3 + p3q1.  Each piece product is exact
+//     in fp32 (8 x 8 bits); the dropped p2q3, p3q2, p3q3 are <= (2 + 2^-8) 2^-24 |a w|: a per-product error of 2^-23 relative, the
+//     size of fp32's own rounding of that product — an fp32 dot product in another summation order, not a reduced-precision net.
+//   F16x3 (mlp_precision = "f16x3", round 1): THREE f16 MFMA products of two f16 pieces per operand (22 of the 24 bits):
 //
 //     a = a_h + a_l,  w = w_h + w_l   (a_h = f16(a), a_l = f16(a - a_h); weights split once in tn_field_prepare_f16x3)
 //     a.w ~= a_h.w_h + a_l.w_h + a_h.w_l            (the dropped a_l.w_l term is <= 2^-22 |a.w|)
@@ -20,27 +27,98 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / TN_WAVE;
 constexpr int GF = 15, APP = 32, L16 = 16, IN0 = 16 + GF + APP;
 constexpr int LG = 4;
 
+// ---- the two splits ------------------------------------------------------------------------------------------------------------
+// piece 0 is the leading one.  A block's LDS holds the A fragments of all 30 (layer, tile, k-step) combos: 16 B per lane, combo
+// and piece.  F16x3: 64 KB, two 256-thread blocks per CU; BF16x6: 96 KB, ONE 512-thread block per CU (both: two waves per SIMD).
+struct F16x3 {
+    static constexpr int NP = 2, kBlock = 256, kBlocksPerCU = 2;
+    static constexpr bool kShInLds = false;  // SH(dir) operand of a tile's rays: 16 VGPRs held over the sample loop
+    typedef _Float16 elem;
+    typedef v8h vec;
+    static __device__ __forceinline__ void split(float v, elem (&p)[NP]) {
+        p[0] = (elem)v;
+        p[1] = (elem)(v - (float)p[0]);
+    }
+    // two values -> per piece one dword holding the pair (x0 in the low half): the unit the MFMA operands are assembled from
+    static __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&pk)[NP]) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+        pk[0] = __builtin_bit_cast(unsigned, h2{h0, h1});
+        pk[1] = __builtin_bit_cast(unsigned, h2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)});
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const vec (&a)[NP], const vec (&b)[NP]) {
+#ifdef TN_H3_PROBE_SIX_PRODUCTS
+        // timing probe only: the matrix-pipe load of a SIX-product split — three more MFMAs per step that add zeros
+        const v8h z = {0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, b[0], acc, 0, 0, 0);
+#endif
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+struct BF16x6 {
+    static constexpr int NP = 3, kBlock = 512, kBlocksPerCU = 1;
+    // SH(dir) operand of a tile's rays (24 VGPRs, constant over the sample loop) parked in LDS: 6 KB per wave behind the blob
+    static constexpr bool kShInLds = true;
+    typedef __bf16 elem;
+    typedef v8bf vec;
+    static __device__ __forceinline__ void split(float v, elem (&p)[NP]) {
+        p[0] = (elem)v;
+        const float r1 = v - (float)p[0];  // exact: |r1| <= half a bf16 ulp of v, 16 bits
+        p[1] = (elem)r1;
+        p[2] = (elem)(r1 - (float)p[1]);   // exact, and exactly representable: 8 bits are left
+    }
+    // as pairs: one v_cvt_pk_bf16_f32 rounds two values (RNE — truncation would leave |p2| < 2^-7 |a| and the dropped products at
+    // 2^-20), the pair's floats come back as a shift and a mask, the residuals are exact subtractions: 11 instructions per pair
+    static __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&pk)[NP]) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const f2 v = {x0, x1};
+        const b2 p1 = __builtin_convertvector(v, b2);
+        pk[0] = __builtin_bit_cast(unsigned, p1);
+        // (scalar subtractions: as one v_pk_add_f32 per pair the kernel took 23.2 instead of 21.5 ms — aligned register pairs, more spills)
+        const f2 r1 = {x0 - __uint_as_float(pk[0] << 16), x1 - __uint_as_float(pk[0] & 0xffff0000u)};
+        const b2 p2 = __builtin_convertvector(r1, b2);
+        pk[1] = __builtin_bit_cast(unsigned, p2);
+        const f2 r2 = {r1[0] - __uint_as_float(pk[1] << 16), r1[1] - __uint_as_float(pk[1] & 0xffff0000u)};
+        pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const vec (&a)[NP], const vec (&b)[NP]) {
+        // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
 // ---- blob / LDS layout ------------------------------------------------------------------------------------
-// A fragments: [30 combos][64 lanes][hi: 8 x f16 | lo: 8 x f16] = 32 B per lane
+// A fragments: [30 combos][64 lanes][NP pieces][8 elements] = 16 NP bytes per lane and combo; then the fp32 biases / output rows
 constexpr int C_BASE1 = 0, C_BASE2 = 4, C_C1 = 8, C_T1 = 12, C_C2 = 14, C_T2 = 22, N_COMBOS = 30;
-constexpr int H_A_FLOATS = N_COMBOS * 64 * 8;  // 32 B = 8 floats per lane
-constexpr int HOFF_B_BASE1 = H_A_FLOATS;        // [64]
-constexpr int HOFF_B_BASE2 = HOFF_B_BASE1 + 64; // [32]
-constexpr int HOFF_B_C1 = HOFF_B_BASE2 + 32;    // [64] eval bias incl. the folded appearance term
-constexpr int HOFF_B_T1 = HOFF_B_C1 + 64;
-constexpr int HOFF_B_C2 = HOFF_B_T1 + 64;
-constexpr int HOFF_B_T2 = HOFF_B_C2 + 64;
-constexpr int HOFF_W3 = HOFF_B_T2 + 64;         // [3][64] + [4]
-constexpr int HOFF_WTH = HOFF_W3 + 196;         // [64] + [4]
-constexpr int H_BLOB_FLOATS = HOFF_WTH + 68;    // 15976 floats = 63 904 B
-static_assert(H_BLOB_FLOATS % 4 == 0, "blob must be float4-copyable");
+template <int NP>
+struct Lay {
+    static constexpr int A_FLOATS = N_COMBOS * 64 * 4 * NP;
+    static constexpr int B_BASE1 = A_FLOATS;      // [64]
+    static constexpr int B_BASE2 = B_BASE1 + 64;  // [32]
+    static constexpr int B_C1 = B_BASE2 + 32;     // [64] eval bias incl. the folded appearance term
+    static constexpr int B_T1 = B_C1 + 64;
+    static constexpr int B_C2 = B_T1 + 64;
+    static constexpr int B_T2 = B_C2 + 64;
+    static constexpr int W3 = B_T2 + 64;          // [3][64] + [4]
+    static constexpr int WTH = W3 + 196;          // [64] + [4]
+    static constexpr int BLOB_FLOATS = WTH + 68;  // NP = 2: 15 976 floats = 63 904 B; NP = 3: 23 656 floats = 94 624 B
+    static_assert(BLOB_FLOATS % 4 == 0, "blob must be float4-copyable");
+};
 
 __host__ __device__ inline int krow(int q, int e, int h) { return 16 * q + (e & 3) + 8 * (e >> 2) + 4 * h; }
 
@@ -77,25 +155,26 @@ __device__ __forceinline__ float frag_weight(const RawField &w, int combo, int i
     return m[(i + 32 * mt) * 64 + 32 * (ks >> 1) + krow(ks & 1, e, h)];
 }
 
-__global__ void field_prepare_h3_kernel(RawField w, float *__restrict__ blob) {
+template <class P>
+__global__ void field_prepare_split_kernel(RawField w, float *__restrict__ blob) {
+    typedef Lay<P::NP> LY;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < N_COMBOS * 64 * 8) {  // one thread per (combo, lane, e): writes the hi and the lo half
+    if (idx < N_COMBOS * 64 * 8) {  // one thread per (combo, lane, e): writes that element of every piece
         const int e = idx & 7, lane = (idx >> 3) & 63, combo = idx >> 9;
-        const float v = frag_weight(w, combo, lane & 31, lane >> 5, e);
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
-        _Float16 *dst = reinterpret_cast<_Float16 *>(blob) + ((size_t)(combo * 64 + lane)) * 16;
-        dst[e] = hi;
-        dst[8 + e] = lo;
+        typename P::elem pc[P::NP];
+        P::split(frag_weight(w, combo, lane & 31, lane >> 5, e), pc);
+        typename P::elem *dst = reinterpret_cast<typename P::elem *>(blob) + ((size_t)(combo * 64 + lane)) * 8 * P::NP;
+#pragma unroll
+        for (int k = 0; k < P::NP; ++k) dst[8 * k + e] = pc[k];
         return;
     }
-    const int j = idx - N_COMBOS * 64 * 8 + H_A_FLOATS;
-    if (j >= H_BLOB_FLOATS) return;
+    const int j = idx - N_COMBOS * 64 * 8 + LY::A_FLOATS;
+    if (j >= LY::BLOB_FLOATS) return;
     float v = 0.0f;
-    if (j < HOFF_B_BASE2) v = w.b0b[j - HOFF_B_BASE1];
-    else if (j < HOFF_B_C1) { const int f = j - HOFF_B_BASE2; v = f < 1 + GF ? w.b1b[f] : 0.0f; }
-    else if (j < HOFF_B_T1) {
-        const int f = j - HOFF_B_C1;
+    if (j < LY::B_BASE2) v = w.b0b[j - LY::B_BASE1];
+    else if (j < LY::B_C1) { const int f = j - LY::B_BASE2; v = f < 1 + GF ? w.b1b[f] : 0.0f; }
+    else if (j < LY::B_T1) {
+        const int f = j - LY::B_C1;
         v = w.h0b[f];
         if (w.use_avg) {  // REF thermal_field.py:128-132
             for (int k = 0; k < APP; ++k) {
@@ -105,54 +184,52 @@ __global__ void field_prepare_h3_kernel(RawField w, float *__restrict__ blob) {
             }
         }
     }
-    else if (j < HOFF_B_C2) v = w.t0b[j - HOFF_B_T1];
-    else if (j < HOFF_B_T2) v = w.h1b[j - HOFF_B_C2];
-    else if (j < HOFF_W3) v = w.t1b[j - HOFF_B_T2];
-    else if (j < HOFF_WTH) { const int e = j - HOFF_W3; v = e < 192 ? w.h2w[e] : (e < 195 ? w.h2b[e - 192] : 0.0f); }
-    else { const int e = j - HOFF_WTH; v = e < 64 ? w.thw[e] : (e == 64 ? w.thb[0] : 0.0f); }
+    else if (j < LY::B_C2) v = w.t0b[j - LY::B_T1];
+    else if (j < LY::B_T2) v = w.h1b[j - LY::B_C2];
+    else if (j < LY::W3) v = w.t1b[j - LY::B_T2];
+    else if (j < LY::WTH) { const int e = j - LY::W3; v = e < 192 ? w.h2w[e] : (e < 195 ? w.h2b[e - 192] : 0.0f); }
+    else { const int e = j - LY::WTH; v = e < 64 ? w.thw[e] : (e == 64 ? w.thb[0] : 0.0f); }
     blob[j] = v;
 }
 
 // ---- device helpers ------------------------------------------------------------------------------------------
-struct HL {
-    v8h hi, lo;
+template <class P>
+struct Pieces {  // one MFMA operand (A: 8 k-values of a weight row, B: of a ray's activations) as NP vectors of 8 elements
+    typename P::vec p[P::NP];
 };
 
-#define MFMAH(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (acc), 0, 0, 0)
-
-__device__ __forceinline__ void mma3(f32x16 &acc, const HL &a, const HL &b) {
-#ifdef TN_H3_PROBE_SIX_PRODUCTS
-    // timing probe only: the matrix-pipe load of a SIX-product split (3 x bf16 pieces per operand) — three more
-    // MFMAs per step that add exact zeros
-    const v8h z = {0, 0, 0, 0, 0, 0, 0, 0};
-    MFMAH(acc, z, b.hi);
-    MFMAH(acc, z, b.lo);
-    MFMAH(acc, z, b.hi);
-#endif
-    MFMAH(acc, a.lo, b.hi);
-    MFMAH(acc, a.hi, b.lo);
-    MFMAH(acc, a.hi, b.hi);
+template <class P>
+__device__ __forceinline__ void mma(f32x16 &acc, const Pieces<P> &a, const Pieces<P> &b) {
+    P::mma(acc, a.p, b.p);
 }
 
-__device__ __forceinline__ HL load_a(const float *lds, int combo, int lane) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(lds) + (size_t)(combo * 64 + lane) * 2;
-    HL a;
-    a.hi = __builtin_bit_cast(v8h, p[0]);
-    a.lo = __builtin_bit_cast(v8h, p[1]);
+template <class P>
+__device__ __forceinline__ Pieces<P> load_a(const float *lds, int combo, int lane) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(lds) + (size_t)(combo * 64 + lane) * P::NP;
+    Pieces<P> a;
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) a.p[k] = __builtin_bit_cast(typename P::vec, q[k]);
     return a;
 }
 
-template <bool RELU>
-__device__ __forceinline__ HL split8(const f32x16 &x, int q) {
-    HL r;
+template <class P, bool RELU>
+__device__ __forceinline__ Pieces<P> split8(const f32x16 &x, int q) {
+    unsigned pk[P::NP][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = x[8 * q + e];
-        if (RELU) v = relu_bits(v);
-        const _Float16 hh = (_Float16)v;
-        r.hi[e] = hh;
-        r.lo[e] = (_Float16)(v - (float)hh);
+    for (int m = 0; m < 4; ++m) {
+        float v0 = x[8 * q + 2 * m], v1 = x[8 * q + 2 * m + 1];
+        if (RELU) {
+            v0 = relu_bits(v0);
+            v1 = relu_bits(v1);
+        }
+        unsigned pr[P::NP];
+        P::split_pair(v0, v1, pr);
+#pragma unroll
+        for (int k = 0; k < P::NP; ++k) pk[k][m] = pr[k];
     }
+    Pieces<P> r;
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) r.p[k] = __builtin_bit_cast(typename P::vec, uint4{pk[k][0], pk[k][1], pk[k][2], pk[k][3]});
     return r;
 }
 
@@ -183,28 +260,29 @@ __device__ __forceinline__ void swap32(float a, float b, float &lo, float &hi) {
 
 // 16 per-lane values (this lane's ray) -> B operands of one K=16 step for both N tiles.
 // in: natural order v[0..15]; lane (j,h) of tile t ends up holding v[8h + e] of ray (32t + j).
-__device__ __forceinline__ void pack_step(const float (&v)[16], HL &t0, HL &t1) {
-    unsigned ph[8], pl[8];
+template <class P>
+__device__ __forceinline__ void pack_step(const float (&v)[16], Pieces<P> &t0, Pieces<P> &t1) {
+    unsigned pk[P::NP][8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const _Float16 h0 = (_Float16)v[2 * m], h1 = (_Float16)v[2 * m + 1];
-        const _Float16 l0 = (_Float16)(v[2 * m] - (float)h0), l1 = (_Float16)(v[2 * m + 1] - (float)h1);
-        ph[m] = __builtin_bit_cast(unsigned, v2h{h0, h1});
-        pl[m] = __builtin_bit_cast(unsigned, v2h{l0, l1});
-    }
-    unsigned a0[4], a1[4], b0[4], b1[4];
+        unsigned pr[P::NP];
+        P::split_pair(v[2 * m], v[2 * m + 1], pr);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // lower half keeps packs 0..3 (features 0..7), upper half gets packs 4..7 (8..15)
-        swap32u(ph[q], ph[4 + q], a0[q], a1[q]);
-        swap32u(pl[q], pl[4 + q], b0[q], b1[q]);
+        for (int k = 0; k < P::NP; ++k) pk[k][m] = pr[k];
     }
-    t0.hi = __builtin_bit_cast(v8h, uint4{a0[0], a0[1], a0[2], a0[3]});
-    t1.hi = __builtin_bit_cast(v8h, uint4{a1[0], a1[1], a1[2], a1[3]});
-    t0.lo = __builtin_bit_cast(v8h, uint4{b0[0], b0[1], b0[2], b0[3]});
-    t1.lo = __builtin_bit_cast(v8h, uint4{b1[0], b1[1], b1[2], b1[3]});
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) {
+        unsigned a0[4], a1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)  // lower half keeps packs 0..3 (features 0..7), upper half gets packs 4..7 (8..15)
+            swap32u(pk[k][q], pk[k][4 + q], a0[q], a1[q]);
+        t0.p[k] = __builtin_bit_cast(typename P::vec, uint4{a0[0], a0[1], a0[2], a0[3]});
+        t1.p[k] = __builtin_bit_cast(typename P::vec, uint4{a1[0], a1[1], a1[2], a1[3]});
+    }
 }
 
 // one 64 -> 64 layer from relu(in): out[mt][nt] = bias + sum_ks A[mt][ks] x B[nt][ks]
+template <class P>
 __device__ __forceinline__ void layer64(const float *lds, int combo0, const float *bias, int lane, int h,
                                         const f32x16 (&in)[2][2], f32x16 (&out)[2][2]) {
 #pragma unroll
@@ -214,12 +292,12 @@ __device__ __forceinline__ void layer64(const float *lds, int combo0, const floa
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const HL b0 = split8<true>(in[ks >> 1][0], ks & 1), b1 = split8<true>(in[ks >> 1][1], ks & 1);
+        const Pieces<P> b0 = split8<P, true>(in[ks >> 1][0], ks & 1), b1 = split8<P, true>(in[ks >> 1][1], ks & 1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const HL a = load_a(lds, combo0 + mt * 4 + ks, lane);
-            mma3(out[mt][0], a, b0);
-            mma3(out[mt][1], a, b1);
+            const Pieces<P> a = load_a<P>(lds, combo0 + mt * 4 + ks, lane);
+            mma<P>(out[mt][0], a, b0);
+            mma<P>(out[mt][1], a, b1);
         }
     }
 }
@@ -270,12 +348,16 @@ struct H3Args {
     float early_eps;  // 0 = never stop early
 };
 
-__global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
+template <class P>
+__global__ void __launch_bounds__(P::kBlock, P::kBlocksPerCU) main_split_rays_kernel(H3Args a) {
+    typedef Lay<P::NP> LY;
+    typedef Pieces<P> HL;
+    constexpr int kBlock = P::kBlock, kWaves = P::kBlock / TN_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.blob);
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < H_BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];
+        for (int i = threadIdx.x; i < LY::BLOB_FLOATS / 4; i += kBlock) dst[i] = src[i];
     }
     __syncthreads();
     const Space sp = make_space(a.space);
@@ -300,6 +382,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
         const float s_near = spacing_fn(a.nears[rc], lin), s_far = spacing_fn(a.fars[rc], lin);
         const float *tb = a.spacing + tn_ws_bin(grp * 64, 0, S) + (rc - grp * 64);
         HL sh0, sh1;  // SH(dir) of this lane's ray as the K=16 step of the colour layer (constant over samples)
+        uint4 *sh_lds = reinterpret_cast<uint4 *>(lds + LY::BLOB_FLOATS) + (size_t)wave * 64 * 2 * P::NP + lane;  // [2 tiles][NP][64 lanes]
         {
             float sx = dx, sy = dy, sz = dz;
             if (a.sh_shifted) {
@@ -307,7 +390,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
             }
             float c[16];
             sh16(sx, sy, sz, c);
-            pack_step(c, sh0, sh1);
+            pack_step<P>(c, sh0, sh1);
+            if (P::kShInLds) {  // wave-private, written and read by the same lane: no barrier
+#pragma unroll
+                for (int k = 0; k < P::NP; ++k) {
+                    sh_lds[(size_t)k * 64] = __builtin_bit_cast(uint4, sh0.p[k]);
+                    sh_lds[(size_t)(P::NP + k) * 64] = __builtin_bit_cast(uint4, sh1.p[k]);
+                }
+            }
         }
         float en = spacing_to_eucl<true>(tb[0], s_near, s_far, lin);
         float accum = 0.0f, cum_w = 0.0f;
@@ -333,12 +423,12 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                     v[2 * l] = f.x;
                     v[2 * l + 1] = f.y;
                 }, 0);
-                pack_step(v, e0[0], e1[0]);
+                pack_step<P>(v, e0[0], e1[0]);
                 hash_encode_pipelined<8, 2>(a.g, px, py, pz, [&](int l, float2 f) {
                     v[2 * l] = f.x;
                     v[2 * l + 1] = f.y;
                 }, 8);
-                pack_step(v, e0[1], e1[1]);
+                pack_step<P>(v, e0[1], e1[1]);
             } else if (a.g.num_dense == 0) {
                 // hashed levels: index arithmetic | gathers | interpolation in explicit stages; two groups of 2 levels (2 x 16
                 // gathers) in flight — this kernel has ~30 fewer free VGPRs than the fp32 one
@@ -349,7 +439,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                         v[2 * l] = f.x;
                         v[2 * l + 1] = f.y;
                     }, 8 * ks);
-                    pack_step(v, e0[ks], e1[ks]);
+                    pack_step<P>(v, e0[ks], e1[ks]);
                 }
             } else {
 #pragma unroll
@@ -367,53 +457,64 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    pack_step(v, e0[ks], e1[ks]);
+                    pack_step<P>(v, e0[ks], e1[ks]);
                 }
             }
             // ---- mlp_base layer 0: 32 -> 64 ---------------------------------------------------------------
             f32x16 h1[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                h1[mt][0] = bias_frag(lds + HOFF_B_BASE1, mt, h);
+                h1[mt][0] = bias_frag(lds + LY::B_BASE1, mt, h);
                 h1[mt][1] = h1[mt][0];
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const HL aw = load_a(lds, C_BASE1 + mt * 2 + ks, lane);
-                    mma3(h1[mt][0], aw, e0[ks]);
-                    mma3(h1[mt][1], aw, e1[ks]);
+                    const HL aw = load_a<P>(lds, C_BASE1 + mt * 2 + ks, lane);
+                    mma<P>(h1[mt][0], aw, e0[ks]);
+                    mma<P>(h1[mt][1], aw, e1[ks]);
                 }
             }
             // ---- mlp_base layer 1: 64 -> 16 ---------------------------------------------------------------
             f32x16 g[2];
-            g[0] = bias_frag(lds + HOFF_B_BASE2, 0, h);
+            g[0] = bias_frag(lds + LY::B_BASE2, 0, h);
             g[1] = g[0];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const HL aw = load_a(lds, C_BASE2 + ks, lane);
-                mma3(g[0], aw, split8<true>(h1[ks >> 1][0], ks & 1));
-                mma3(g[1], aw, split8<true>(h1[ks >> 1][1], ks & 1));
+                const HL aw = load_a<P>(lds, C_BASE2 + ks, lane);
+                mma<P>(g[0], aw, split8<P, true>(h1[ks >> 1][0], ks & 1));
+                mma<P>(g[1], aw, split8<P, true>(h1[ks >> 1][1], ks & 1));
             }
             float raw, unused;
             swap32(g[0][0], g[1][0], raw, unused);
             const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
-            const HL g0 = split8<false>(g[0], 0), g1 = split8<false>(g[1], 0);  // geo rows (row 0 has zero weight)
+            const HL g0 = split8<P, false>(g[0], 0), g1 = split8<P, false>(g[1], 0);  // geo rows (row 0 has zero weight)
             {   // colour: [geo | SH] -> 64 -> 64 -> 3
                 f32x16 x1[2][2], x2[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    x1[mt][0] = bias_frag(lds + HOFF_B_C1, mt, h);
+                    x1[mt][0] = bias_frag(lds + LY::B_C1, mt, h);
                     x1[mt][1] = x1[mt][0];
-                    const HL ag = load_a(lds, C_C1 + mt * 2, lane), as = load_a(lds, C_C1 + mt * 2 + 1, lane);
-                    mma3(x1[mt][0], ag, g0);
-                    mma3(x1[mt][1], ag, g1);
-                    mma3(x1[mt][0], as, sh0);
-                    mma3(x1[mt][1], as, sh1);
+                    const HL ag = load_a<P>(lds, C_C1 + mt * 2, lane), as = load_a<P>(lds, C_C1 + mt * 2 + 1, lane);
+                    mma<P>(x1[mt][0], ag, g0);
+                    mma<P>(x1[mt][1], ag, g1);
+                    if (P::kShInLds) {
+                        HL s0, s1;
+#pragma unroll
+                        for (int k = 0; k < P::NP; ++k) {
+                            s0.p[k] = __builtin_bit_cast(typename P::vec, sh_lds[(size_t)k * 64]);
+                            s1.p[k] = __builtin_bit_cast(typename P::vec, sh_lds[(size_t)(P::NP + k) * 64]);
+                        }
+                        mma<P>(x1[mt][0], as, s0);
+                        mma<P>(x1[mt][1], as, s1);
+                    } else {
+                        mma<P>(x1[mt][0], as, sh0);
+                        mma<P>(x1[mt][1], as, sh1);
+                    }
                 }
-                layer64(lds, C_C2, lds + HOFF_B_C2, lane, h, x1, x2);
-                const float *w3 = lds + HOFF_W3;
+                layer64<P>(lds, C_C2, lds + LY::B_C2, lane, h, x1, x2);
+                const float *w3 = lds + LY::W3;
                 cr = fast_sigmoid(combine_halves(out_dot_fast<0>(w3, h, x2)) + w3[192]);
                 cg = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 64, h, x2)) + w3[193]);
                 cb = fast_sigmoid(combine_halves(out_dot_fast<0>(w3 + 128, h, x2)) + w3[194]);
@@ -422,14 +523,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_h3_rays_kernel(H3Args a) {
                 f32x16 x1[2][2], x2[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    x1[mt][0] = bias_frag(lds + HOFF_B_T1, mt, h);
+                    x1[mt][0] = bias_frag(lds + LY::B_T1, mt, h);
                     x1[mt][1] = x1[mt][0];
-                    const HL ag = load_a(lds, C_T1 + mt, lane);
-                    mma3(x1[mt][0], ag, g0);
-                    mma3(x1[mt][1], ag, g1);
+                    const HL ag = load_a<P>(lds, C_T1 + mt, lane);
+                    mma<P>(x1[mt][0], ag, g0);
+                    mma<P>(x1[mt][1], ag, g1);
                 }
-                layer64(lds, C_T2, lds + HOFF_B_T2, lane, h, x1, x2);
-                const float *wt = lds + HOFF_WTH;
+                layer64<P>(lds, C_T2, lds + LY::B_T2, lane, h, x1, x2);
+                const float *wt = lds + LY::WTH;
                 th = combine_halves(out_dot_fast<1>(wt, h, x2)) + wt[64];
             }
             cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);
@@ -482,14 +583,15 @@ inline bool h3_supported(const tn_thermal_field *f) {
 
 namespace tn {
 
-int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
-                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
-                   hipStream_t stream) {
-    if (!h3_supported(field) || !field->prepared_f16x3 || cfg->training) return TN_ERR_UNSUPPORTED;
+template <class P>
+static int launch_main_split(const tn_thermal_field *field, const float *blob, const tn_render_config *cfg, const tn_render_inputs *in,
+                             const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
+                             hipStream_t stream) {
+    if (!h3_supported(field) || !blob || cfg->training) return TN_ERR_UNSUPPORTED;
     H3Args a;
     a.g = tn_make_grid(field->grid);
     a.space = field->space;
-    a.blob = field->prepared_f16x3;
+    a.blob = blob;
     a.avg = field->average_init_density;
     a.sh_shifted = field->sh_shifted;
     a.origins = in->origins; a.dirs = in->directions; a.nears = in->nears; a.fars = in->fars;
@@ -498,13 +600,46 @@ int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, c
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.minmax = minmax;
     a.early_eps = fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
-    const size_t smem = (size_t)H_BLOB_FLOATS * sizeof(float);
-    if (!tn_ensure_dynamic_lds<main_h3_rays_kernel>(smem)) return TN_ERR_LAUNCH;
+    constexpr int kWaves = P::kBlock / TN_WAVE;
+    const size_t smem = (size_t)Lay<P::NP>::BLOB_FLOATS * sizeof(float) + (P::kShInLds ? (size_t)kWaves * 64 * 2 * P::NP * 16 : 0);
+    if (!tn_ensure_dynamic_lds<main_split_rays_kernel<P>>(smem)) return TN_ERR_LAUNCH;
     const long long groups = (num_rays + 63) / 64;
     const long long need = (groups + kWaves - 1) / kWaves;
-    const long long cap = 256LL * 2;
+    const long long cap = 256LL * P::kBlocksPerCU;
     const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
-    hipLaunchKernelGGL(main_h3_rays_kernel, dim3(grid), dim3(kBlock), smem, stream, a);
+    hipLaunchKernelGGL(main_split_rays_kernel<P>, dim3(grid), dim3(P::kBlock), smem, stream, a);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
+int launch_main_h3(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
+                   hipStream_t stream) {
+    return launch_main_split<F16x3>(field, field ? field->prepared_f16x3 : nullptr, cfg, in, out, num_rays, spacing_ws, minmax, stream);
+}
+
+int launch_main_b6(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
+                   const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
+                   hipStream_t stream) {
+    return launch_main_split<BF16x6>(field, field ? field->prepared_bf16x6 : nullptr, cfg, in, out, num_rays, spacing_ws, minmax, stream);
+}
+
+template <class P>
+static int field_prepare_split(const tn_thermal_field *f, void *prepared_dev, size_t bytes, void *stream) {
+    typedef Lay<P::NP> LY;
+    if (!f || !prepared_dev) return TN_ERR_NULL;
+    TN_TRY(tn_check_thermal_field(f));
+    if (!h3_supported(f)) return TN_ERR_UNSUPPORTED;
+    if (bytes < (size_t)LY::BLOB_FLOATS * sizeof(float)) return TN_ERR_WORKSPACE;
+    RawField w;
+    w.b0w = f->base0.weight; w.b0b = f->base0.bias; w.b1w = f->base1.weight; w.b1b = f->base1.bias;
+    w.h0w = f->head0.weight; w.h0b = f->head0.bias; w.h1w = f->head1.weight; w.h1b = f->head1.bias;
+    w.h2w = f->head2.weight; w.h2b = f->head2.bias; w.t0w = f->th0.weight; w.t0b = f->th0.bias;
+    w.t1w = f->th1.weight; w.t1b = f->th1.bias; w.thw = f->thead.weight; w.thb = f->thead.bias;
+    w.appearance = f->appearance; w.num_images = f->num_images; w.use_avg = f->use_average_appearance;
+    const int threads = N_COMBOS * 64 * 8 + (LY::BLOB_FLOATS - LY::A_FLOATS);
+    hipLaunchKernelGGL(field_prepare_split_kernel<P>, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<float *>(prepared_dev));
     if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
     return TN_OK;
 }
@@ -515,25 +650,20 @@ extern "C" {
 
 size_t tn_field_prepare_f16x3_bytes(const tn_thermal_field *field) {
     if (!h3_supported(field) || tn_check_thermal_field(field) != TN_OK) return 0;
-    return (size_t)H_BLOB_FLOATS * sizeof(float);
+    return (size_t)Lay<F16x3::NP>::BLOB_FLOATS * sizeof(float);
 }
 
 int tn_field_prepare_f16x3(const tn_thermal_field *f, void *prepared_dev, size_t bytes, void *stream) {
-    if (!f || !prepared_dev) return TN_ERR_NULL;
-    TN_TRY(tn_check_thermal_field(f));
-    if (!h3_supported(f)) return TN_ERR_UNSUPPORTED;
-    if (bytes < (size_t)H_BLOB_FLOATS * sizeof(float)) return TN_ERR_WORKSPACE;
-    RawField w;
-    w.b0w = f->base0.weight; w.b0b = f->base0.bias; w.b1w = f->base1.weight; w.b1b = f->base1.bias;
-    w.h0w = f->head0.weight; w.h0b = f->head0.bias; w.h1w = f->head1.weight; w.h1b = f->head1.bias;
-    w.h2w = f->head2.weight; w.h2b = f->head2.bias; w.t0w = f->th0.weight; w.t0b = f->th0.bias;
-    w.t1w = f->th1.weight; w.t1b = f->th1.bias; w.thw = f->thead.weight; w.thb = f->thead.bias;
-    w.appearance = f->appearance; w.num_images = f->num_images; w.use_avg = f->use_average_appearance;
-    const int threads = N_COMBOS * 64 * 8 + (H_BLOB_FLOATS - H_A_FLOATS);
-    hipLaunchKernelGGL(field_prepare_h3_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<float *>(prepared_dev));
-    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
-    return TN_OK;
+    return tn::field_prepare_split<F16x3>(f, prepared_dev, bytes, stream);
+}
+
+size_t tn_field_prepare_bf16x6_bytes(const tn_thermal_field *field) {
+    if (!h3_supported(field) || tn_check_thermal_field(field) != TN_OK) return 0;
+    return (size_t)Lay<BF16x6::NP>::BLOB_FLOATS * sizeof(float);
+}
+
+int tn_field_prepare_bf16x6(const tn_thermal_field *f, void *prepared_dev, size_t bytes, void *stream) {
+    return tn::field_prepare_split<BF16x6>(f, prepared_dev, bytes, stream);
 }
 
 }  // extern "C"

@@ -129,9 +129,11 @@ class NerfactoModelConfig:
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""
-    mlp_precision: Literal["f32", "f16x3"] = "f32"
-    """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "f16x3": eval-only, every fp32 product evaluated as three f16
-    MFMA products accumulated in fp32 (~2^-22 relative product error; activations must stay below 65504)."""
+    mlp_precision: Literal["f32", "bf16x6", "f16x3"] = "f32"
+    """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  Eval-only alternatives on the matrix cores' 16-bit rate, fp32 accumulate:
+    "bf16x6" — every fp32 operand as three bf16 pieces (24 bits: an exact split), six piece products per fp32 product, 2^-23
+    relative per-product error = the size of fp32's own rounding (an fp32 dot product in another order); "f16x3" — two f16
+    pieces (22 bits), three products, ~2^-22 (activations must stay below 65504)."""
 
     def setup(self, **kwargs) -> Any:
         return self._target(self, **kwargs)

@@ -89,6 +89,7 @@ class ThermalNerfactoTField(nn.Module):
         self.dense_budget_bytes = 0
         self._prepared: Optional[Tensor] = None
         self._prepared_h3: Optional[Tensor] = None
+        self._prepared_b6: Optional[Tensor] = None
         self._prepared_key = None
 
     # ------------------------------------------------------------------------------------------------
@@ -114,6 +115,7 @@ class ThermalNerfactoTField(nn.Module):
         f.average_init_density = float(self.average_init_density)
         f.prepared = None
         f.prepared_f16x3 = None
+        f.prepared_bf16x6 = None
         if prepare:
             lib = _hip.load()
             plist = self.__dict__.get("_tn_plist")
@@ -121,7 +123,7 @@ class ThermalNerfactoTField(nn.Module):
                 plist = self.__dict__["_tn_plist"] = list(self.parameters())
             key = tuple([(p.data_ptr(), p._version) for p in plist])
             if self._prepared_key != key:
-                self._prepared, self._prepared_h3 = None, None
+                self._prepared, self._prepared_h3, self._prepared_b6 = None, None, None
                 nbytes = lib.tn_field_prepare_bytes(f)
                 if nbytes > 0:
                     self._prepared = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
@@ -137,6 +139,16 @@ class ThermalNerfactoTField(nn.Module):
                         _hip.check(lib.tn_field_prepare_f16x3(f, self._prepared_h3.data_ptr(), nbytes, _hip.current_stream()),
                                    "tn_field_prepare_f16x3")
                 f.prepared_f16x3 = None if self._prepared_h3 is None else self._prepared_h3.data_ptr()
+            elif precision == "bf16x6":
+                if self._prepared_b6 is None:
+                    nbytes = lib.tn_field_prepare_bf16x6_bytes(f)
+                    if nbytes > 0:
+                        self._prepared_b6 = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
+                        _hip.check(lib.tn_field_prepare_bf16x6(f, self._prepared_b6.data_ptr(), nbytes, _hip.current_stream()),
+                                   "tn_field_prepare_bf16x6")
+                f.prepared_bf16x6 = None if self._prepared_b6 is None else self._prepared_b6.data_ptr()
+            elif precision != "f32":
+                raise ValueError(f"mlp_precision {precision!r}: expected 'f32', 'bf16x6' or 'f16x3'")
         return f
 
     def train_struct(self, prepare: bool = False) -> Optional[_hip.tn_thermal_field]:

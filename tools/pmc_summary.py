@@ -15,8 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
-KEEP = ("main_mfma_rays_kernel", "main_h3_rays_kernel", "proposal_rays_kernel", "main_mfma_kernel", "proposal_kernel")
-KEY = {"main_mfma_rays_kernel": "field_render", "main_h3_rays_kernel": "field_render", "proposal_rays_kernel": "proposal_sample"}
+KEEP = ("main_mfma_rays_kernel", "main_split_rays_kernel", "main_h3_rays_kernel", "proposal_rays_kernel", "main_mfma_kernel", "proposal_kernel")
+KEY = {"main_mfma_rays_kernel": "field_render", "main_split_rays_kernel": "field_render", "main_h3_rays_kernel": "field_render",
+       "proposal_rays_kernel": "proposal_sample"}
 
 
 def short(name):
@@ -68,7 +69,7 @@ def main():
     for k, name in KEY.items():
         f, w = acc.get((k, "FETCH_SIZE")), acc.get((k, "WRITE_SIZE"))
         if f and w:
-            traffic[name + "@S%d" % S + ("" if prec == "f32" else "_f16x3")] = {
+            traffic[name + "@S%d" % S + ("" if prec == "f32" else "_" + prec)] = {
                 "fetch_kb": 2.0 * sum(f) / len(f), "write_kb": sum(w) / len(w), "rays_per_launch": 640000,
                 "commit": head_stamp(),
                 "source": f"profiles/{os.path.basename(dst)} (2 x FETCH_SIZE per the MI355X_MICROARCH.md gfx950 note + "
