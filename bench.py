@@ -428,6 +428,20 @@ def measure_train_config3(dev, samples: int = 192, steps: int = 30000, window: i
             "what": "HIP eval render (default lane = ray fp32 kernels) of the trained model vs the CPU oracle on the same weights, "
                     "%d rays strided over held-out view 0" % oracle_rays,
             "rgb_mae": e_rgb, "thermal_mae": e_th, "thermal_mae_degC": e_th * (t_max - t_min), "tolerance": 1e-4}
+        # the same frame through the opt-in bf16x6 field kernel (exact three-piece split, six products): against the oracle, and
+        # against the exact-fp32 kernel's frame
+        model.config.mlp_precision = "bf16x6"
+        model.invalidate_prepared()
+        with torch.no_grad():
+            got6 = render_view(model, test_cams, 0, dev)
+        model.config.mlp_precision = "f32"
+        res_d["trained_weights_parity"]["bf16x6"] = {
+            "rgb_mae": float((got6["rgb"].reshape(-1, 3)[idx].cpu() - want["rgb"]).abs().mean()),
+            "thermal_mae": float((got6["thermal"].reshape(-1, 1)[idx].cpu() - want["thermal"]).abs().mean()),
+            "max_abs_vs_fp32_kernel_rgb": float((got6["rgb"] - got["rgb"]).abs().max()),
+            "max_abs_vs_fp32_kernel_thermal": float((got6["thermal"] - got["thermal"]).abs().max()),
+            "held_out_rgb_psnr_db": frame_metrics(got6, held[0][0], held[0][1], t_max, t_min)["psnr"],
+            "held_out_rgb_psnr_db_fp32_kernel": frame_metrics(got, held[0][0], held[0][1], t_max, t_min)["psnr"]}
     del tr, model, ds
     torch.cuda.empty_cache()
     return res_d
