@@ -24,6 +24,16 @@
 //   16x16 C/D -> 32x32x2 B:  swap16(G_2n[q], G_2n+1[q]) = rows (q | 8+q) and (4+q | 12+q) of the 32 samples of tile n in the
 //                            lower | upper 32 lanes = two k-steps of the geo -> hidden layers
 #include "tn_field_eval.h"
+// s_setprio of a wave while it is in its matrix-rich MLP block (0 = none).  Two waves share a SIMD: with both at priority 0 the
+// issue arbitration goes by age, and the partner's hash block (index arithmetic, gathers) holds up the first MFMAs of a sample's
+// chain; at priority 1 the MLP block goes first and the partner's vector work fills in behind it.  main_mfma_rays_kernel: 31.9 ->
+// 30.4 ms per 640 k-ray launch at S=192, 10.7 -> 10.1 at S=64 (A/B on one box, both orders; outputs bit-identical).
+#ifndef TN_MFMA_MLP_PRIO
+#define TN_MFMA_MLP_PRIO 1
+#endif
+#ifndef TN_TRAIN_FWD_PRIO
+#define TN_TRAIN_FWD_PRIO 0
+#endif
 
 using namespace tn;
 
@@ -570,6 +580,9 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             // kFieldDense levels come from the dense re-layout (4 aligned 16-byte gathers per level instead of 8 8-byte ones)
             hash_encode_pipelined<L16, LG, DENSE ? kFieldDense : 0>(a.g, px, py, pz,
                                                                     [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });
+#if TN_MFMA_MLP_PRIO
+            __builtin_amdgcn_s_setprio(TN_MFMA_MLP_PRIO);
+#endif
             f32x16 h1[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -615,6 +628,9 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
                 const float *wt = lds + OFF_WTH;
                 th = combine_halves(out_dot_fast<1>(wt, h, x2)) + wt[64];
             }
+#if TN_MFMA_MLP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);  // eval renderers
             // ---- per-lane compositing: NS get_weights + renderers, sequential along the ray ----------------
             const float dd = mul_rn(sub_rn(en, st), dens);
@@ -760,6 +776,9 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         }
         if (live) a.sel[ic] = sel;
         // ---- mlp_base layer 0 -------------------------------------------------------------------------------------------
+#if TN_TRAIN_FWD_PRIO
+        __builtin_amdgcn_s_setprio(TN_TRAIN_FWD_PRIO);
+#endif
         f32x16 h1[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -906,6 +925,9 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
             const float th = combine_halves(make_float2(p0, p1)) + wt[64];
             if (live) a.thermal[ic] = th;
         }
+#if TN_TRAIN_FWD_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 
