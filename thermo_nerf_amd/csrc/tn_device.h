@@ -348,7 +348,9 @@ __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f
 // emit(level - base, features) is called in level order.  Values are those of encode_level<false, true>, bit for bit.
 // ND > 0 (with base == 0): levels 0 .. ND-1 are read from the dense re-layout (a compile-time split: a run-time branch between
 // the stages would cost the exact wait counts the pipelining lives on).
-template <int NL, int LG, int ND = 0, typename G, typename Emit>
+// GP > 0: s_setprio(GP) while a group's indices are computed and its gathers issued, s_setprio(0) for the interpolation (a caller's
+// A/B switch: the wave whose memory requests can go out ahead of its SIMD partners' arithmetic).
+template <int NL, int LG, int ND = 0, int GP = 0, typename G, typename Emit>
 __device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, float py, float pz, Emit emit, int base = 0) {
     static_assert(NL % LG == 0 && 16 * LG <= 64, "two groups of 8*LG gathers must fit the 6-bit vmcnt counter");
     constexpr int NG = NL / LG;
@@ -360,6 +362,7 @@ __device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, floa
     auto gather_of = [&](int lvl, const HashTaps &t, float2 (&f)[8]) {
         if (lvl < ND) dense_gather(g, lvl, t, f); else hash_gather(g, base + lvl, t, f);
     };
+    if (GP > 0) __builtin_amdgcn_s_setprio(GP);
 #pragma unroll
     for (int q = 0; q < LG; ++q) taps_of(q, taps[0][q]);
     TN_STAGE_FENCE();
@@ -378,9 +381,11 @@ __device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, floa
         }
 #pragma unroll
         for (int q = 0; q < LG; ++q) hash_hold(taps[cur][q]);  // group gi is interpolated below group gi+1's gathers
+        if (GP > 0) __builtin_amdgcn_s_setprio(0);
         TN_STAGE_FENCE();
 #pragma unroll
         for (int q = 0; q < LG; ++q) emit(gi * LG + q, hash_blend(taps[cur][q], fv[cur][q]));
+        if (GP > 0 && gi + 1 < NG) __builtin_amdgcn_s_setprio(GP);
         TN_STAGE_FENCE();
     }
 }

@@ -31,6 +31,16 @@
 #ifndef TN_MFMA_MLP_PRIO
 #define TN_MFMA_MLP_PRIO 1
 #endif
+// priority of a wave while it computes a level group's hash indices and issues its gathers (hash_encode_pipelined's GP).  Eval
+// frame (coherent rays, the kernel waits for the matrix pipe): 1 beside MLP priority 1 costs 3 % (31.4 against 30.6 ms), beside
+// MLP priority 2 nothing: off.  Training forward (incoherent rays, the kernel waits for its gathers): the step 2.49-2.51 ->
+// 2.43-2.46 ms at S=192 (tools/ab_train.sh, two interleaved repetitions): on.
+#ifndef TN_EVAL_GATHER_PRIO
+#define TN_EVAL_GATHER_PRIO 0
+#endif
+#ifndef TN_TRAIN_GATHER_PRIO
+#define TN_TRAIN_GATHER_PRIO 1
+#endif
 #ifndef TN_TRAIN_FWD_PRIO
 #define TN_TRAIN_FWD_PRIO 0
 #endif
@@ -578,7 +588,7 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             float bt0[16], bt1[16];
             // index arithmetic | gathers | interpolation in explicit stages, two groups of LG levels in flight; DENSE: the first
             // kFieldDense levels come from the dense re-layout (4 aligned 16-byte gathers per level instead of 8 8-byte ones)
-            hash_encode_pipelined<L16, LG, DENSE ? kFieldDense : 0>(a.g, px, py, pz,
+            hash_encode_pipelined<L16, LG, DENSE ? kFieldDense : 0, TN_EVAL_GATHER_PRIO>(a.g, px, py, pz,
                                                                     [&](int l, float2 f) { swap32(f.x, f.y, bt0[l], bt1[l]); });
 #if TN_MFMA_MLP_PRIO
             __builtin_amdgcn_s_setprio(TN_MFMA_MLP_PRIO);
@@ -757,7 +767,7 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
             // the hash features in pass tiles [pass][level][64 samples][2]: every store instruction writes 512 contiguous bytes
             // (row-major [N,32] rows put 8 bytes of each of 64 lines on a store); tn_field_bwd_fused reads the same tiling
             float2 *et = reinterpret_cast<float2 *>(a.enc) + ps * (16 * 64) + lane;
-            hash_encode_pipelined<L16, LG>(a.g, px, py, pz, [&](int l, float2 f) {
+            hash_encode_pipelined<L16, LG, 0, TN_TRAIN_GATHER_PRIO>(a.g, px, py, pz, [&](int l, float2 f) {
                 et[l * 64] = f;
                 swap32(f.x, f.y, bt0[l], bt1[l]);
             });
