@@ -1013,7 +1013,12 @@ def test_config3_step_size_fresh_batches_against_the_atomic_single_stream_taped_
                 continue
             worst[n] = rel(g1[n], g)
             if n.endswith("hash_table"):
-                assert torch.equal(g1[n] == 0, g == 0), n  # the same table entries touched
+                # the same table entries touched.  (Up to a handful of entries whose contributions cancel to exactly 0 in one
+                # summation order and to a denormal-sized rest in the other: 786 k samples x 8 corners meet in few coarse entries.)
+                differ = (g1[n] == 0) != (g == 0)
+                assert int(differ.sum()) <= 16, (n, int(differ.sum()))
+                if differ.any():
+                    assert float(torch.maximum(g1[n].abs(), g.abs())[differ].max()) <= 1e-9 * float(g.abs().max()), n
         print(f"step {step}: worst relative gradient difference " + ", ".join(f"{n.split('.')[-3:]}: {v:.1e}" for n, v in
               sorted(worst.items(), key=lambda kv: -kv[1])[:4]))
         for n, v in worst.items():
