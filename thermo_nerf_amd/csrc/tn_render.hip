@@ -24,6 +24,11 @@
 // s_setprio of a proposal wave while it computes a level group's indices and issues its gathers (0 = none): four waves share a
 // SIMD, and the one whose memory requests can go out goes ahead of the others' interpolation / MLP arithmetic —
 // proposal_rays_kernel 2.93 -> 2.89 ms per 640 k rays at S=192, 2.82 -> 2.76 at S=64 (round 4, A/B both orders; same bits).
+// the same for the PDF walks' block loads of weights and edges: 2.88 -> 2.865 ms at S=192, 2.76 -> 2.735 at S=64 (gather priority 2
+// beside it: worse)
+#ifndef TN_PDF_LOAD_PRIO
+#define TN_PDF_LOAD_PRIO 1
+#endif
 #ifndef TN_PROP_GATHER_PRIO
 #define TN_PROP_GATHER_PRIO 1
 #endif
@@ -386,12 +391,18 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     constexpr int WB = TN_PDF_WALK_BLOCK;
     for (int i0 = 0; i0 < n_in; i0 += WB) {
         float wv[WB], ev[WB];
+#if TN_PDF_LOAD_PRIO
+        __builtin_amdgcn_s_setprio(TN_PDF_LOAD_PRIO);
+#endif
 #pragma unroll
         for (int k = 0; k < WB; ++k) {
             const int i = i0 + k < n_in ? i0 + k : n_in - 1;
             wv[k] = w[(size_t)i * 64];
             ev[k] = edge(i + 1);
         }
+#if TN_PDF_LOAD_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int k = 0; k < WB; ++k) {
             if (i0 + k >= n_in) break;
