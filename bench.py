@@ -8,8 +8,11 @@ Default workload = the configuration BASELINE.json's `metric` is quoted on: a sy
 proposal sampling 256+96 -> hash-grid+MLP field at S samples/ray -> alpha-composited RGB + thermal + depths), rendered
 with eval_num_rays_per_chunk = the frame (one proposal + one field launch per frame).  Rays and weights are resident in
 HBM before the timed region.  On rank 0 at N = 1 the line also carries, under `variants`, BASELINE config 2 (S = 64), the
-reference config's chunking (eval_num_rays_per_chunk = 65 536, REF config_thermal_nerf.py:30), the opt-in f16x3 and
-early-termination forms, and the training step at S = 48 and S = 192 — each its own measurement, none of them `value`.
+reference config's chunking (eval_num_rays_per_chunk = 65 536, REF config_thermal_nerf.py:30), the opt-in split-precision
+(bf16x6, f16x3) and early-termination forms, BASELINE config 4 end to end (the reference's 96-pose 1080p camera path), a
+single-GPU proxy of strong scaling over ray shards, BASELINE config 3 as the reference defines it (30 000 consecutive Trainer
+iterations on fresh batches, held-out PSNR / thermal MAE, parity on the trained weights) and the fixed-batch training step at
+S = 48 and S = 192 — each its own measurement, none of them `value`.
 
 N ranks (--shard weak, default): every rank renders its own frame (view = rank; rays shard with no data-path dependency)
 and the rendered pixels (36 B/ray) are all-gathered over RCCL inside the timed region, asynchronously.
