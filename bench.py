@@ -715,6 +715,145 @@ def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None):
                      "kernel": "whole path, all ranks", "path_bytes_per_ray": b_all}}
 
 
+LINE_LIMIT = 4096  # bytes: the driver reads the LAST stdout line; round 4's 20.6 KB line did not parse
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the detail file keeps the full ones); everything else unchanged"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _variant_frac(v: dict):
+    """the one fraction a variant is judged by: its serial-phase fraction (training), else its roofline's binding fraction"""
+    roof = v.get("roofline") or {}
+    if "serial_phase_view" in roof:
+        return roof["serial_phase_view"].get("frac")
+    if "path" in roof and "path_frac_of_binding_ceiling" in roof["path"]:
+        return roof["path"]["path_frac_of_binding_ceiling"]
+    return roof.get("frac")
+
+
+def compact_line(full: dict, detail_file: str = "bench_detail.json") -> dict:
+    """The ONE line the driver parses: flat, numbers only where numbers do, <= LINE_LIMIT bytes.  Everything `full` holds beyond it
+    (the `what` texts, per-window tables, nested samples, censuses) goes to bench_detail.json and to an earlier stdout line.
+    tests/test_bench_line.py holds this function to the limit and to a strict-JSON round trip on canned measurements."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: _r(full[k]) for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "rays_per_step_per_gpu", "rays_per_step", "parallelism") if k in cfg}
+    line["config"]["workload"] = str(line["config"].get("workload", ""))[:300]
+    roof = full.get("roofline") or {}
+    r = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "rays_per_launch",
+                                      "algorithmic_flops_per_ray", "algorithmic_bytes_per_ray", "traffic")}
+    r["traffic_source"] = str(roof["traffic_source"]).split(" ")[0] if roof.get("traffic_source") else None
+    if "path" in roof:
+        r["path_frac_of_binding_ceiling"] = _r(roof["path"].get("path_frac_of_binding_ceiling"))
+    if "hbm" in roof:
+        r["hbm_frac"] = _r(roof["hbm"].get("frac"))
+    if "serial_phase_view" in roof:
+        r["serial_phase_frac"] = _r(roof["serial_phase_view"].get("frac"))
+    for k in ("proposal_ms", "field_ms"):
+        if k in roof:
+            r[k] = _r(roof[k])
+    line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {
+            "value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "cpu_model": cb.get("cpu_model"),
+            "single_thread": _r((cb.get("single_thread") or {}).get("value")),
+            "physical_cores": (cb.get("physical_cores") or {}).get("cores"),
+            "physical_cores_value": _r((cb.get("physical_cores") or {}).get("value")),
+            "sample": str(cb.get("sample", ""))[:160]}
+    if "parity" in full:
+        line["parity"] = {k: _r(v, 4) for k, v in full["parity"].items() if k in ("rgb_mae", "thermal_mae")}
+    if "speedup_vs_cpu" in full:
+        line["speedup_vs_cpu"] = _r(full["speedup_vs_cpu"])
+    for k in ("held_out", "trained_weights_parity"):  # --mode train lines
+        if k in full:
+            line[k] = {a: _r(b, 4) for a, b in full[k].items() if isinstance(b, (int, float))}
+    if "rccl" in full:
+        info = full["rccl"]
+        devs = info.get("devices") or []
+        line["rccl"] = {"backend": info.get("backend"), "world_size": info.get("world_size"), "rccl_version": info.get("rccl_version"),
+                        "devices": sorted({str(d).split(" (cuda")[0] for d in devs}), "device_ids": [
+                            int(str(d).split("cuda:")[1].rstrip(")")) for d in devs if "cuda:" in str(d)]}
+    variants = {}
+    for name, v in (full.get("variants") or {}).items():
+        if name == "shard_proxy":  # strong scaling predicted on one GPU: efficiency of the N = 8 shard per frame
+            for tag, rows in v.get("frames", {}).items():
+                variants["shard_proxy_" + tag] = {"n8_shard_ms": _r(rows["N8"]["shard_ms"], 4), "n8_efficiency": _r(rows["N8"]["implied_efficiency"], 4),
+                                                  "n4_efficiency": _r(rows["N4"]["implied_efficiency"], 4)}
+            continue
+        ms = v.get("ms_per_step", v.get("ms_per_frame", v.get("frame_ms_p50")))
+        c = {"value": _r(v.get("value"), 5), "ms_per_step": _r(ms, 5)}
+        frac = _variant_frac(v)
+        if frac is not None:
+            c["frac"] = _r(frac, 4)
+        if "held_out" in v:  # config 3's quantities: sustained step, held-out quality, parity on the trained weights
+            c["steps"] = v.get("steps")
+            c["rgb_psnr_db"] = _r(v["held_out"].get("rgb_psnr_db"), 4)
+            c["thermal_mae_degC"] = _r(v["held_out"].get("thermal_mae_degC"), 4)
+            if "trained_weights_parity" in v:
+                c["parity_rgb_mae"] = _r(v["trained_weights_parity"].get("rgb_mae"), 3)
+                c["parity_thermal_mae"] = _r(v["trained_weights_parity"].get("thermal_mae"), 3)
+        for k in ("rgb_mae", "thermal_mae"):
+            if k in v:
+                c[k] = _r(v[k], 3)
+        if "n_gpus" in v:  # the strong-scaling frame measured by the same ranks (N > 1)
+            c["n_gpus"], c["scaling"] = v["n_gpus"], v.get("scaling")
+        variants[name] = c
+    if variants:
+        line["variants"] = variants
+    line["detail"] = detail_file
+    # the limit is a contract, not a hope: shed the optional parts, least important first, until the line fits
+    def fits():
+        return len(json.dumps(line, allow_nan=False)) <= LINE_LIMIT
+
+    def shed_variant_fields():
+        line["variants"] = {k: {"value": c.get("value")} for k, c in line.get("variants", {}).items()}
+
+    for shed in (lambda: line.get("rccl", {}).pop("device_ids", None), lambda: line.get("cpu_baseline", {}).pop("sample", None),
+                 lambda: line["config"].update(workload=line["config"]["workload"][:120]), shed_variant_fields,
+                 lambda: line.update(variants={"dropped": len(line.get("variants", {}))})):
+        if fits():
+            break
+        shed()
+    return line
+
+
+def _strict(x):
+    """NaN / +-inf are not JSON: null them, recursively (a consumer's strict parser must never be the thing that fails)"""
+    if isinstance(x, float):
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {str(k): _strict(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict(v) for v in x]
+    return x
+
+
+def emit(full: dict) -> None:
+    """bench_detail.json (next to bench.py and, on a gpurun box, under gpurun_out/ so that it travels back) + the full tree as an
+    EARLIER stdout line + the compact line LAST."""
+    full = _strict(full)
+    text = json.dumps(full, allow_nan=False)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
+    print(json.dumps({"bench_detail": full}, allow_nan=False), flush=True)
+    line = compact_line(full)
+    out = json.dumps(line, allow_nan=False)
+    assert len(out) <= LINE_LIMIT and json.loads(out) == line, len(out)
+    print(out, flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -765,7 +904,7 @@ def main():
                     "roofline": res["roofline"]}
             if "cpu_baseline" in res:
                 line["cpu_baseline"] = res["cpu_baseline"]
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -777,7 +916,7 @@ def main():
         info = rccl_info(dist, world, dev)
         if rank == 0:
             line["rccl"] = info
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -892,7 +1031,7 @@ def main():
             v = quick(engine)
             variants["early_termination_1e-3"] = {
                 "what": "early_termination_eps=1e-3 (a 64-ray tile stops once every ray's transmittance is below it), same "
-                        "%d-sample frame" % S, "value": v, "unit": "rays/s"}
+                        "%d-sample frame" % S, "value": v, "unit": "rays/s", "ms_per_step": n_rays / v * 1e3}
             capture("early_termination_1e-3", out)
             engine.rc.early_stop_transmittance = 0.0
             # the reference config's chunking: eval_num_rays_per_chunk = 65 536 (two HIP streams alternate the chunks)
@@ -954,7 +1093,7 @@ def main():
             for tag in ("bf16x6", "f16x3", "early_termination_1e-3"):
                 if tag in captured and "variants" in line and tag in line["variants"]:
                     line["variants"][tag]["rgb_mae"], line["variants"][tag]["thermal_mae"], _ = err(tag)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 
