@@ -22,6 +22,7 @@ DEV = "cuda:0"
 RGB_MAE = 1e-4
 THERMAL_MAE = 1e-4
 DEPTH_REL = 1e-4
+MEDIAN_TIE = 1e-5  # |cumulative weight - 0.5| at the oracle's median index below which an index flip counts as a tie
 
 
 def gpu_model(kind="stress", S=48, small=True, family="lane_ray", **over):
@@ -354,10 +355,27 @@ def check_outputs(got, want, tag):
     assert (got["rgb"].cpu() - want["rgb"]).abs().max().item() <= 20 * RGB_MAE, f"{tag}: rgb max"
     assert_close(got["accumulation"], want["accumulation"], 2e-5, 0, f"{tag}: accumulation")
     assert_close(got["expected_depth"], want["expected_depth"], 1e-6, DEPTH_REL, f"{tag}: expected_depth")
+    # median depths [NS DepthRenderer("median"), REF thermal_nerf_model.py:238-239,267-270]: a ray may differ from the oracle only
+    # where the oracle's cumulative weight sits within MEDIAN_TIE of the 0.5 split next to its median index (a genuine tie, which
+    # rounding may resolve either way) AND the answer is the neighbouring step on that side; every other ray meets DEPTH_REL.
+    ties = getattr(want, "median_ties", None)
+    assert ties is not None, f"{tag}: the oracle outputs carry no median_ties (use H.get_outputs / H.Outputs)"
     for k in ("depth", "prop_depth_0", "prop_depth_1"):
-        rel = ((got[k].cpu() - want[k]).abs() / want[k].abs().clamp_min(1e-6))
-        bad = (rel > DEPTH_REL).float().mean().item()
-        assert bad <= 0.02, f"{tag}: {k} mismatch fraction {bad} (median index flips only)"
+        if k not in want:
+            continue
+        g, w, t = got[k].cpu(), want[k], ties[k]
+        rel_to = lambda ref: (g - ref).abs() / ref.abs().clamp_min(1e-6)
+        ok = rel_to(w) <= DEPTH_REL
+        tie_up = (rel_to(t["above"].reshape(w.shape)) <= DEPTH_REL) & (t["margin_above"].reshape(w.shape) <= MEDIAN_TIE)
+        tie_dn = (rel_to(t["below"].reshape(w.shape)) <= DEPTH_REL) & (t["margin_below"].reshape(w.shape) <= MEDIAN_TIE)
+        bad = ~(ok | tie_up | tie_dn)
+        if bad.any():
+            i = int(bad.reshape(-1).nonzero()[0])
+            raise AssertionError(
+                f"{tag}: {k}: {int(bad.sum())} of {bad.numel()} rays differ from the oracle's median depth without a tie; first: ray {i} "
+                f"got {g.reshape(-1)[i]:.7g} want {w.reshape(-1)[i]:.7g} (neighbours {t['below'].reshape(-1)[i]:.7g} / {t['above'].reshape(-1)[i]:.7g}, "
+                f"|cw-0.5| below {t['margin_below'].reshape(-1)[i]:.3g} above {t['margin_above'].reshape(-1)[i]:.3g})")
+        assert (~ok).float().mean().item() <= 0.02, f"{tag}: {k}: {(~ok).float().mean().item()} of the rays sit on a median tie"
     assert set(k for k, v in want.items() if isinstance(v, torch.Tensor)) <= set(got)
 
 
@@ -523,7 +541,9 @@ def test_camera_ray_bundle_chunking_matches_single_call():
     got = gm.get_outputs_for_camera_ray_bundle(RayBundle(origins=o, directions=d))
     assert got["rgb"].shape == (15, 17, 3) and got["thermal"].shape == (15, 17, 1)
     flat = lambda t: {k: v.reshape(-1, v.shape[-1]) for k, v in t.items()}
-    check_outputs(flat(got), flat(want), "chunked")
+    flat_want = H.Outputs(flat(want))
+    flat_want.median_ties = {k: flat(t) for k, t in want.median_ties.items()}
+    check_outputs(flat(got), flat_want, "chunked")
 
 
 def test_camera_ray_bundle_keeps_planes_already_on_the_bundle():
