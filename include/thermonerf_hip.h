@@ -108,7 +108,13 @@ typedef struct tn_thermal_field {
     /* optional blob produced by tn_field_prepare_bf16x6: every fp32 weight as THREE bf16 pieces (24 significand bits: the split is
      * exact) so that the eval field kernel can evaluate each fp32 product as the six piece products of order <= 2, accumulated in
      * fp32: a per-product error of 2^-23 relative — fp32's own rounding size — at the matrix cores' bf16 rate.  Takes precedence
-     * over `prepared_f16x3` and `prepared` for eval calls when non-NULL. */
+     * over `prepared_f16x3` and `prepared` for eval calls when non-NULL.
+     * ABI NOTE (round 4 appended this member): ZERO-INITIALISE the struct (`tn_thermal_field f = {0};` / memset) before filling it
+     * — the three `prepared*` pointers are optional and a non-NULL one is dereferenced; a caller compiled against the older,
+     * shorter struct must be recompiled.  RANGE NOTE: the split is exact while the smallest piece stays a normal bf16, i.e. for
+     * |x| >= 2^-110 (below that the third piece is subnormal or zero and the product degrades gracefully towards two-piece
+     * accuracy, 2^-16 relative OF A VALUE BELOW 1e-33 — absolute error < 1e-38); gfx950's bf16 MFMA does not flush subnormal
+     * inputs, so pieces down to 2^-133 still contribute (tests/test_gpu_parity.py::test_bf16x6_split_*). */
     const float *prepared_bf16x6;
 } tn_thermal_field;
 
@@ -289,6 +295,15 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
  * first_ray and chunk_rays must be multiples of 64 (a 64-ray wavefront tile never straddles two chunks): TN_ERR_UNSUPPORTED
  * otherwise.  Same workspace precondition as tn_field_render_fwd. */
 int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays);
+
+/* Which kernel form a call of num_rays rays takes under cfg->kernel_family (0 = by call size): 1 = lane = ray (a wavefront marches
+ * 64 consecutive rays), 2 = one ray per wavefront.  pass 0: tn_proposal_sample_fwd; pass 1: tn_field_render_fwd /
+ * tn_field_render_chunked_fwd on `field` (may be NULL = no split-precision blob: those kernels only exist in form 1 and are chosen
+ * from a smaller call size; a form-2 call with a split-precision blob runs the exact-fp32 ray-per-wave kernel).  The two forms sum in
+ * different orders, so a caller that renders PART of a launch (ray shards of one frame, thermo_nerf_amd/engine.py::render_shard)
+ * and wants the whole launch's bits asks for the whole launch's form here and passes it as cfg->kernel_family.  No reference
+ * counterpart (the reference has one code path, REF render/renderer.py:182-187); 0 on a NULL cfg. */
+int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass);
 int tn_field_render_chunked_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                                 const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
                                 int64_t first_ray, int64_t chunk_rays, float *depth_bounds, int32_t clip, void *stream);

@@ -239,6 +239,112 @@ def test_sub_chunk_shards_reproduce_the_unsharded_frame(h, w, chunk, world):
         assert torch.equal(got, want[k]), (k, (got - want[k]).abs().max().item())
 
 
+def _shards_against_the_frame(eng, o, d, n, world, nears=None, fars=None):
+    """every rank's render_shard + the reduced bounds, concatenated, against eng.render of the whole frame: bit for bit"""
+    from thermo_nerf_amd import distributed as D
+
+    want = {k: v.clone() for k, v in eng.render(o, d, nears=nears, fars=fars).items()}
+    shards = []
+    for r in range(world):
+        a, b = D.ray_block(n, r, world)
+        kw = {} if nears is None else {"nears": nears[a:b].contiguous(), "fars": fars[a:b].contiguous()}
+        out, bounds = eng.render_shard(o[a:b].contiguous(), d[a:b].contiguous(), a, n, **kw)
+        shards.append(({k: v.clone() for k, v in out.items()}, a, bounds.clone()))
+    lo = torch.stack([b[:, 0] for _, _, b in shards]).min(dim=0).values
+    hi = torch.stack([b[:, 1] for _, _, b in shards]).max(dim=0).values
+    bounds = torch.stack([lo, hi], dim=1).contiguous()
+    for out, a, _ in shards:
+        eng.apply_depth_bounds(out, a, bounds)
+    torch.cuda.synchronize()
+    for k in D.OUTPUT_KEYS:
+        got = torch.cat([out[k] for out, _, _ in shards])
+        assert torch.equal(got, want[k]), (k, (got - want[k]).abs().max().item())
+    return want
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("h,w", [(200, 250), (180, 250), (250, 400)])
+def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, precision):
+    """The kernel form of a launch is the LIBRARY's decision (tn_render_kernel_form): with a split-precision blob the field pass
+    runs lane = ray from 40 960 rays per call, with exact fp32 from 57 344, the proposal pass from 81 920 — frames of 45 000,
+    50 000 and 100 000 rays sit between / above them.  A shard (1/4 of the frame: below every threshold) must run the form of
+    the unsharded launch, in every precision (the engine used to re-derive the fp32 thresholds in Python)."""
+    from thermo_nerf_amd import _hip, synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    model, _, _ = _model()
+    model.config.mlp_precision = precision
+    model.invalidate_prepared()
+    n = h * w
+    o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=2)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    eng = RayRenderEngine(model, chunk=CHUNK)
+    _, _, fld = model._c_structs()
+    eng.rc.kernel_family = 0
+    form = eng.lib.tn_render_kernel_form(fld, eng.rc, n, 1)
+    assert form == (1 if n >= (57344 if precision == "f32" else 40960) else 2)
+    assert eng.lib.tn_render_kernel_form(fld, eng.rc, n, 0) == (1 if n >= 81920 else 2)
+    assert eng._forms(fld, n, 0) == (eng.lib.tn_render_kernel_form(None, eng.rc, n, 0), form)
+    _shards_against_the_frame(eng, o, d, n, 4)
+    assert eng.rc.kernel_family == 0  # render_shard leaves the engine's setting alone
+
+
+def test_shards_of_a_frame_cut_into_several_launches_on_one_stream():
+    """A frame longer than the workspace budget: equal runs of whole chunks (frame_launch_rays), the LAST launch shorter and —
+    here — below the lane = ray threshold while the others are above it; a shard's pieces take the form of the launch that
+    holds them, on one stream as on two."""
+    from thermo_nerf_amd import synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    model, _, _ = _model()
+    h, w = 300, 620  # 186 000 rays, chunk 8192: 23 chunks
+    n = h * w
+    o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=6)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    for streams in (1, 2):
+        eng = RayRenderEngine(model, chunk=8192, streams=streams, max_workspace_bytes=streams * 150 << 20)
+        L = eng.frame_launch_rays(n)
+        assert L % 8192 == 0 and L < n
+        pieces = eng._launch_pieces(0, n, n)
+        assert len(pieces) >= 2 and pieces[-1][1] == n and all(j - i == L for i, j in pieces[:-1])
+        assert eng.lib.tn_render_workspace_bytes(eng.rc, max(j - i for i, j in pieces)) <= 150 << 20  # a launch fits its slot's share
+        _shards_against_the_frame(eng, o, d, n, 3)
+        # the 1080p frame of config 4 under the default budget: 4 launches of 8 chunks, 2 slots
+    eng = RayRenderEngine(model, chunk=CHUNK)
+    assert eng.frame_launch_rays(1080 * 1920) == 8 * CHUNK and eng.frame_launch_rays(800 * 800) == 10 * CHUNK
+
+
+def test_more_ranks_than_tiles_and_planes_on_the_bundle():
+    """(a) 130 rays over 8 ranks = 3 tiles: five ranks own EMPTY runs that start at the frame's end (130: not a multiple of 64) —
+    render_shard returns empty outputs and neutral bounds instead of raising while its peers wait in the all-reduce.
+    (b) per-ray near / far planes already on the bundle reach the shards as they reach the unsharded frame."""
+    from thermo_nerf_amd import distributed as D
+    from thermo_nerf_amd import synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    model, _, _ = _model()
+    eng = RayRenderEngine(model, chunk=CHUNK)
+    o3, d3, _ = synthetic.orbit_camera_rays(10, 13, view=1)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    blocks = [D.ray_block(130, r, 8) for r in range(8)]
+    assert sum(1 for a, b in blocks if b == a) == 5 and blocks[-1] == (130, 130)
+    out, bounds = eng.render_shard(o[130:], d[130:], 130, 130)
+    assert out["rgb"].shape == (0, 3) and bool(torch.isinf(bounds).all())
+    _shards_against_the_frame(eng, o, d, 130, 8)
+    h, w = 120, 500
+    n = h * w
+    o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=4)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    g = torch.Generator().manual_seed(3)
+    nears = (0.05 + 0.2 * torch.rand(n, generator=g)).to(DEV)
+    fars = (2.0 + 3.0 * torch.rand(n, generator=g)).to(DEV)
+    with_planes = _shards_against_the_frame(eng, o, d, n, 5, nears, fars)
+    plain = eng.render(o, d)
+    assert not torch.equal(with_planes["depth"], plain["depth"])  # the planes were used
+    with pytest.raises(ValueError):
+        eng.render_shard(o[:64], d[:64], 0, n, nears=nears[:64])
+
+
 def _fine_worker(rank, world, port, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -701,8 +701,8 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     same 1000 steps on the HIP path: same batches, jitter draws, anneal and proposal-update schedule.  Trajectories of a
     1000-step Adam run separate chaotically at the fp32 rounding level (two CPU runs do), so the claim is: step for step over
     the first 20 steps (2e-3 relative), the 100-step means of the two loss curves within 50 % of each other over the descent
-    (600 steps), both staying converged after it, and the same final quality on an unseen view (2 dB, 0.05 of the normalised
-    thermal range: the spread of the CPU runs among themselves)."""
+    (600 steps), both staying converged after it, and the same final quality on held-out pixels (1.5 dB, 0.02 of the normalised
+    thermal range, both improving on the initial thermal MAE by 2.5x)."""
     import os
 
     import numpy as np
@@ -746,11 +746,12 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     assert (gw[6:] < gw[1]).all() and (ww[6:] < ww[1]).all(), (gw, ww)
     # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
     sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
-    p_hip, m_hip = helpers.held_out_quality(prob, sd_hip)
-    # CPU runs that differ only in thread count / host end between 15.9 and 17.1 dB (0.208 ... 0.221 thermal MAE) after the
-    # wandering late stage (0.19 ... 0.225 thermal MAE); the HIP runs seen so far: 16.0 ... 16.3 dB
-    assert abs(p_cpu - p_hip) <= 2.0, (p_cpu, p_hip)
-    assert abs(m_cpu - m_hip) <= 0.05, (m_cpu, m_hip)
+    p_hip, m_hip, hit_hip = helpers.held_out_quality(prob, sd_hip)
+    # held-out pixels of a training view (helpers.config1_problem): the CPU run ends at 16.6 dB, thermal MAE 0.044 (0.047 on the
+    # sphere's rays) from 12.8 dB / 0.255 / 0.227; the late stage of a 64-ray-batch run wanders, hence bands not equalities
+    assert abs(p_cpu - p_hip) <= 1.5, (p_cpu, p_hip)
+    assert abs(m_cpu - m_hip) <= 0.02 and abs(float(gold["mae_hit"]) - hit_hip) <= 0.025, (m_cpu, m_hip, hit_hip)
+    assert m_hip < 0.4 * float(gold["mae_initial"]) and hit_hip < 0.4 * float(gold["mae_hit_initial"])
     # and the HIP eval render of the HIP-trained model agrees with the oracle on the same weights (eval after 1000 fused steps)
     gm.eval()
     h = prob["held_out"]

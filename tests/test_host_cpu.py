@@ -126,3 +126,45 @@ def test_oracle_uniform_initial_sampler_is_linear_in_distance():
     # the piecewise default is NOT linear: half of the spacing range covers [0, 1]
     q = H.sample_initial(torch.zeros(1, 1), torch.full((1, 1), 1000.0), 8, None)
     assert abs(float(q.ends[0, 3, 0]) - 1.0) < 2e-3
+
+
+def test_kernel_form_query_and_the_engine_launch_plan():
+    """tn_render_kernel_form is the ONE place the call-size thresholds live (no compute call: runs without a GPU), and
+    RayRenderEngine.frame_launch_rays cuts a frame into equal runs of whole chunks under a TOTAL workspace budget."""
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    lib = _hip.load()
+    rc = _hip.tn_render_config()
+    rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = 256, 96, 48
+    fld = _hip.tn_thermal_field()
+    blob = (ctypes.c_float * 4)()
+    for fam in (0, 1, 2):
+        rc.kernel_family = fam
+        for n in (1, 40959, 40960, 57343, 57344, 81919, 81920, 1 << 21):
+            want_prop = fam or (1 if n >= 81920 else 2)
+            want_f32 = fam or (1 if n >= 57344 else 2)
+            want_split = fam or (1 if n >= 40960 else 2)
+            assert lib.tn_render_kernel_form(None, rc, n, 0) == want_prop
+            assert lib.tn_render_kernel_form(None, rc, n, 1) == want_f32
+            fld.prepared_bf16x6 = None
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_f32
+            fld.prepared_bf16x6 = ctypes.addressof(blob)
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_split
+            rc.training = 1  # (the split kernels are eval-only)
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_f32
+            rc.training = 0
+    assert lib.tn_render_kernel_form(None, None, 100, 0) == 0
+    model, _, _ = helpers.build("init", 48)
+    model.eval()
+    eng = RayRenderEngine(model, chunk=1 << 16)  # default budget 2 GiB in total, two stream slots
+    per_ray = 4 * (48 + 1 + 256 + 97)
+    assert lib.tn_render_workspace_bytes(eng.rc, 1 << 16) // (1 << 16) == per_ray
+    assert eng.frame_launch_rays(800 * 800) == 10 << 16  # fits: one launch pair
+    assert eng.frame_launch_rays(1080 * 1920) == 8 << 16  # 32 chunks: 4 equal launches of 8 (not 20 + 12)
+    assert [j - i for i, j in eng._launch_pieces(0, 1080 * 1920, 1080 * 1920)] == [8 << 16] * 3 + [1080 * 1920 - (24 << 16)]
+    assert eng._launch_pieces(500000, 600000, 1080 * 1920) == [(500000, 8 << 16), (8 << 16, 600000)]
+    assert eng._launch_pieces(7, 7, 100) == []
+    peak = 2 * lib.tn_render_workspace_bytes(eng.rc, 8 << 16)
+    assert peak <= 2 << 30
+    one = RayRenderEngine(model, chunk=800 * 800, max_workspace_bytes=1 << 20)  # a chunk larger than the budget: still one chunk per launch
+    assert one.frame_launch_rays(800 * 800) == 800 * 800 and one.frame_launch_rays(3 * 800 * 800) == 800 * 800

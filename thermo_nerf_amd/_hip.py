@@ -181,6 +181,7 @@ SIGNATURES = {
          C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
     ),
     "tn_depth_bound_slots": (_i64, [_i64, _i64, _i64]),
+    "tn_render_kernel_form": (C.c_int32, [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), _i64, C.c_int32]),
     "tn_field_render_chunked_fwd": (
         C.c_int,
         [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), C.POINTER(tn_render_inputs),

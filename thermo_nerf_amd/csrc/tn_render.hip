@@ -817,7 +817,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
                            ws_minmax(workspace, num_rays, S));
         pa.wk = wk;
     }
-    const bool small_call = cfg->kernel_family == 2 || (cfg->kernel_family == 0 && num_rays < 81920);
+    const bool small_call = tn_render_kernel_form(nullptr, cfg, num_rays, 0) == 2;
     if (!small_call) {
         // lane = ray
         PropRaysArgs ra;
@@ -886,7 +886,8 @@ static int field_render_fwd(const tn_thermal_field *field, const tn_render_confi
     // minmax was reset by tn_proposal_sample_fwd, which filled this workspace; the bounds are a function of the edges in
     // it alone, so re-running the field kernel on the same workspace re-derives the same two values (atomic min/max)
     // the split-precision kernel only exists in the lane = ray form: small calls take the exact-fp32 ray-per-wave kernel
-    const bool split_ok = !cfg->training && !out->weights[2] && cfg->kernel_family != 2 && (num_rays >= 40960 || cfg->kernel_family == 1);
+    const bool split_ok = !out->weights[2] && tn_render_kernel_form(field, cfg, num_rays, 1) == 1 &&
+                          (field->prepared_bf16x6 || field->prepared_f16x3);
     if (field->prepared_bf16x6 && split_ok) {
         TN_TRY(launch_main_b6(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
     } else if (field->prepared_f16x3 && split_ok) {
@@ -929,6 +930,15 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
                         const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
                         void *stream) {
     return field_render_fwd(field, cfg, in, out, num_rays, workspace, workspace_bytes, 0, 0, nullptr, 1, stream);
+}
+
+int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass) {
+    if (!cfg) return 0;
+    if (cfg->kernel_family == 1 || cfg->kernel_family == 2) return cfg->kernel_family;
+    if (pass == 0) return num_rays < 81920 ? 2 : 1;  // proposal pass: 1250 tiles fill the chip (see tn_proposal_sample_fwd)
+    // field pass: the split-precision kernels exist in the lane = ray form only and pay from 640 tiles; the exact-fp32 one from 896
+    const bool split = field && !cfg->training && (field->prepared_bf16x6 || field->prepared_f16x3);
+    return num_rays < (split ? 40960 : 57344) ? 2 : 1;
 }
 
 int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays) {

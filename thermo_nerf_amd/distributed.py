@@ -129,12 +129,14 @@ def ray_block(num_rays: int, rank: int, world: int, align: int = 64) -> Tuple[in
 
 
 def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group=None, device: Optional[torch.device] = None,
-                              align: int = 64) -> Dict[str, Tensor]:
+                              align: int = 64, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """``render_frame_sharded`` with EVEN shards (``ray_block``) that still reproduces the single-device frame bit for bit.  The
     one cross-ray quantity — the expected-depth clip to the [min, max] sample mid-point of each ``engine.chunk``-ray chunk of
     the frame — is restored by exchanging the per-chunk bounds: a rank renders the pieces of the chunks its run overlaps
     (``engine.render_shard``), ONE all-reduce(min) of 2 floats per chunk of the frame (max as min of the negation) joins the
     bounds of chunks split between ranks, ``engine.apply_depth_bounds`` clips, and the pixels are all-gathered as before.
+    ``nears`` / ``fars`` [H,W,1] (or [H*W]): per-ray planes the bundle already carries, sliced like the origins (absent: the
+    engine's collider planes, as in ``RayRenderEngine.render``).
     ``engine``: a RayRenderEngine (or anything with its ``render_shard`` / ``apply_depth_bounds``)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     h, w = origins.shape[:2]
@@ -144,7 +146,12 @@ def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group
     d = directions.reshape(-1, 3)[r0:r1].contiguous()
     if device is not None:
         o, d = o.to(device), d.to(device)
-    local, bounds = engine.render_shard(o, d, r0, n)
+    planes = {}
+    if nears is not None or fars is not None:
+        if nears is None or fars is None:
+            raise ValueError("pass both nears and fars, or neither")
+        planes = {"nears": nears.reshape(-1)[r0:r1].contiguous().to(o.device), "fars": fars.reshape(-1)[r0:r1].contiguous().to(o.device)}
+    local, bounds = engine.render_shard(o, d, r0, n, **planes)
     if world > 1:
         key = torch.stack([bounds[:, 0], -bounds[:, 1]], dim=1).contiguous()
         dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)

@@ -25,10 +25,14 @@ class RayRenderEngine:
     def __init__(self, model: ThermalNerfModel, chunk: Optional[int] = None, streams: Optional[int] = None,
                  fuse_chunks: bool = True, max_workspace_bytes: int = 2 << 30) -> None:
         """``chunk``: the reference's ``eval_num_rays_per_chunk`` — the unit DepthRenderer("expected") clips over.
-        ``fuse_chunks`` (default): a frame of several chunks goes through ONE launch pair per ``launch_rays`` rays (as many whole
-        chunks as fit ``max_workspace_bytes`` of bin-edge workspace) that keeps one depth-bound pair per chunk
-        (tn_field_render_chunked_fwd): the reference's chunk-by-chunk result bit for bit, without under-filling the chip with
-        1024-tile launches.  False, or a chunk that is not a multiple of 64 rays: one launch pair per chunk."""
+        ``fuse_chunks`` (default): a frame of several chunks goes through as few launch pairs as ``max_workspace_bytes`` allows,
+        each keeping one depth-bound pair per chunk (tn_field_render_chunked_fwd): the reference's chunk-by-chunk result bit for
+        bit, without under-filling the chip with 1024-tile launches.  False, or a chunk that is not a multiple of 64 rays: one
+        launch pair per chunk.
+        ``max_workspace_bytes`` bounds the engine's TOTAL bin-edge workspace (4 (S+1 + 256 + 97) B per ray in flight, all stream
+        slots together; the peak is that or ONE chunk's workspace, whichever is larger): a frame that fits goes through one launch
+        pair; a larger one is cut into k equal runs of whole chunks, k the smallest count whose run fits the budget divided by
+        the number of streams (``frame_launch_rays``: 1080p at S=48 and the default 2 GiB -> 4 launches of 8 chunks, 1.6 GiB)."""
         if model.training:
             raise RuntimeError("RayRenderEngine renders in eval mode; call model.eval() first")
         self.model = model
@@ -46,17 +50,20 @@ class RayRenderEngine:
         self.rc.kernel_family = 0
         self.rc.initial_sampler = int(model.proposal_sampler.initial_sampler.uniform_spacing)
         self.fuse_chunks = bool(fuse_chunks) and self.chunk % 64 == 0
-        # rays per launch pair: whole chunks, as many as the workspace budget holds (4 (S+1 + 256 + 97) B per ray)
-        self.launch_rays = self.chunk
-        if self.fuse_chunks:
-            per_ray = self.lib.tn_render_workspace_bytes(self.rc, self.chunk) / max(self.chunk, 1)
-            self.launch_rays = max(1, int(max_workspace_bytes / max(per_ray, 1.0)) // self.chunk) * self.chunk
         # launches of 65 536 rays are 1024 waves — one per SIMD, half of what the field kernel needs to hide its gathers —
         # so consecutive launches go to alternating HIP streams (own workspace each) and overlap on the device
         # (default: 2 streams; 4 — the number of hardware queues HIP streams map onto — for small chunks)
         if streams is None:
-            streams = 2 if self.launch_rays >= 32768 else 4
+            streams = 2 if (self.fuse_chunks or self.chunk >= 32768) else 4
         self.num_streams = max(1, int(streams))
+        # whole chunks per launch pair: what the whole budget holds (a frame that fits is ONE launch), and what one stream
+        # slot's share of it holds (a longer frame: equal runs of at most that many chunks)
+        self._chunks_whole = self._chunks_slot = 1
+        if self.fuse_chunks:
+            per_chunk = max(self.lib.tn_render_workspace_bytes(self.rc, self.chunk), 1)
+            self._chunks_whole = max(1, int(max_workspace_bytes) // per_chunk)
+            self._chunks_slot = max(1, int(max_workspace_bytes) // self.num_streams // per_chunk)
+        self.launch_rays = self._chunks_slot * self.chunk  # (the largest launch of a frame that does not fit one)
         self._streams: List[torch.cuda.Stream] = []
         self._ws: Optional[Tensor] = None
         self._ws_rays = 0
@@ -100,10 +107,32 @@ class RayRenderEngine:
         ins.u2 = pdf_positions(self.S + 1, dev, False).data_ptr()
         return ins
 
-    def _launch_pieces(self, start: int, end: int) -> List[Tuple[int, int]]:
-        """[start, end) of a frame cut where the frame's launches are cut (multiples of ``launch_rays``)"""
-        L = self.launch_rays
+    def frame_launch_rays(self, frame_rays: int) -> int:
+        """Rays per launch pair of a ``frame_rays``-ray frame: the frame if its workspace fits the budget, else equal runs of whole
+        chunks (k = the fewest launches whose run fits one stream slot's share of the budget)."""
+        n_chunks = -(-max(int(frame_rays), 1) // self.chunk)
+        if n_chunks <= self._chunks_whole:
+            return n_chunks * self.chunk
+        k = -(-n_chunks // self._chunks_slot)
+        return -(-n_chunks // k) * self.chunk
+
+    def _launch_pieces(self, start: int, end: int, frame_rays: int) -> List[Tuple[int, int]]:
+        """[start, end) of a frame cut where the frame's launches are cut (multiples of ``frame_launch_rays``)"""
+        L = self.frame_launch_rays(frame_rays)
         return [(max(start, k * L), min(end, (k + 1) * L)) for k in range(start // L, (end - 1) // L + 1)] if end > start else []
+
+    def _forms(self, fld, frame_rays: int, piece_start: int) -> Tuple[int, int]:
+        """(proposal, field) kernel forms of the frame launch that holds ray ``piece_start`` — what ``render`` of the WHOLE frame runs
+        there; the decision is the library's (tn_render_kernel_form), never re-derived here."""
+        L = self.frame_launch_rays(frame_rays)
+        family = KERNEL_FAMILY[self.model.config.kernel_family]
+        if family == 0 and self.num_streams > 1 and frame_rays > L and L >= 49152:
+            # launches overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
+            return 1, 1
+        k = piece_start // L
+        whole = min((k + 1) * L, frame_rays) - k * L
+        self.rc.kernel_family = family
+        return (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)), int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
 
     @torch.no_grad()
     def render(self, origins: Tensor, directions: Tensor, out: Optional[Dict[str, Tensor]] = None,
@@ -115,8 +144,8 @@ class RayRenderEngine:
         o = _hip.require_device_tensor(origins, "origins")
         d = _hip.require_device_tensor(directions, "directions")
         n, dev = o.shape[0], o.device
-        pieces = self._launch_pieces(0, n)
-        self._buffers(dev, min(self.launch_rays, max(n, 1)), len(pieces))
+        pieces = self._launch_pieces(0, n, n)
+        self._buffers(dev, max((j - i for i, j in pieces), default=1), len(pieces))
         if out is None:
             out = self.allocate_outputs(n, dev)
         prop0, prop1, fld = self.model._c_structs()
@@ -131,9 +160,7 @@ class RayRenderEngine:
         outs = _hip.tn_render_outputs()
         wsn = self._ws.shape[1]
         multi = self.num_streams > 1 and len(pieces) > 1
-        # launches overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
         family = KERNEL_FAMILY[self.model.config.kernel_family]
-        self.rc.kernel_family = 1 if (family == 0 and multi and self.launch_rays >= 49152) else family
         chunked = self.fuse_chunks and n > self.chunk
         bounds = torch.empty((-(-n // self.chunk), 2), dtype=torch.float32, device=dev) if chunked else None
         current = torch.cuda.current_stream(dev)
@@ -157,10 +184,13 @@ class RayRenderEngine:
             if record_events:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record(st)
+            form_prop, form_field = self._forms(fld, n, i)
+            self.rc.kernel_family = form_prop
             _hip.check(self.lib.tn_proposal_sample_fwd(prop0, prop1, self.rc, ins, outs, r, ws, wsn, stream),
                        "tn_proposal_sample_fwd")
             if record_events:
                 e1.record(st)
+            self.rc.kernel_family = form_field
             if chunked:  # one launch for the piece's chunks, one depth-bound pair per chunk, clipped per chunk
                 _hip.check(self.lib.tn_field_render_chunked_fwd(fld, self.rc, ins, outs, r, ws, wsn, i, self.chunk,
                                                                 bounds.data_ptr() + 8 * (i // self.chunk), 1, stream),
@@ -170,6 +200,7 @@ class RayRenderEngine:
             if record_events:
                 e2.record(st)
                 self.timings.append((e0, e1, e2))
+        self.rc.kernel_family = family
         if multi:
             for st in self._streams:
                 current.wait_stream(st)
@@ -177,45 +208,46 @@ class RayRenderEngine:
 
     @torch.no_grad()
     def render_shard(self, origins: Tensor, directions: Tensor, start: int, frame_rays: int,
-                     out: Optional[Dict[str, Tensor]] = None) -> Tuple[Dict[str, Tensor], Tensor]:
+                     out: Optional[Dict[str, Tensor]] = None, nears: Optional[Tensor] = None,
+                     fars: Optional[Tensor] = None) -> Tuple[Dict[str, Tensor], Tensor]:
         """Rays [start, start + n) of a row-major frame of ``frame_rays`` rays whose reference chunking is this engine's
         ``chunk`` — a shard that need NOT begin or end on a chunk boundary, only on a multiple of 64 rays
         (distributed.render_frame_sharded_fine).  It is rendered by the launches ``render`` would use for that part of the frame,
         in the kernel form ``render`` would pick for the whole frame, so every per-ray output equals the unsharded frame's bit
         for bit; ``expected_depth`` is left UNCLIPPED and ``bounds[c]`` receives this shard's [min, max] of the sample mid-points
         in chunk ``c`` of the frame ((+inf, -inf) for chunks it does not touch).  The caller reduces ``bounds`` over the ranks
-        (min / max) and calls ``apply_depth_bounds``.  Returns (outputs [n,C], bounds [chunks of the frame, 2])."""
+        (min / max) and calls ``apply_depth_bounds``.  ``nears`` / ``fars`` [n] or [n,1]: the shard's slice of per-ray planes a
+        bundle already carries (as in ``render``); absent, the collider's.  An EMPTY shard (more ranks than 64-ray tiles) is valid
+        wherever it starts.  Returns (outputs [n,C], bounds [chunks of the frame, 2])."""
         if not self.fuse_chunks:
             raise RuntimeError("render_shard needs fuse_chunks (a chunk size that is a multiple of 64 rays)")
         o = _hip.require_device_tensor(origins, "origins")
         d = _hip.require_device_tensor(directions, "directions")
         n, dev = o.shape[0], o.device
-        if start < 0 or start + n > frame_rays or start % 64 != 0:
-            raise ValueError("a shard lies inside the frame and starts on a multiple of 64 rays")
-        pieces = self._launch_pieces(start, start + n)
-        self._buffers(dev, max((j - i for i, j in pieces), default=1), len(pieces))
         if out is None:
             out = self.allocate_outputs(n, dev)
         bounds = torch.empty((-(-frame_rays // self.chunk), 2), dtype=torch.float32, device=dev)
         bounds[:, 0] = float("inf")
         bounds[:, 1] = float("-inf")
-        if n == 0:
+        if n == 0:  # (before the alignment check: distributed.ray_block hands a surplus rank [frame_rays, frame_rays))
             return out, bounds
+        if start < 0 or start + n > frame_rays or start % 64 != 0:
+            raise ValueError("a shard lies inside the frame and starts on a multiple of 64 rays")
+        if (nears is None) != (fars is None):
+            raise ValueError("pass both nears and fars, or neither")
+        if nears is not None:
+            nears = _hip.require_device_tensor(nears.reshape(-1), "nears")
+            fars = _hip.require_device_tensor(fars.reshape(-1), "fars")
+            if nears.shape[0] != n or fars.shape[0] != n:
+                raise ValueError("nears/fars must hold one value per ray of the shard")
+        pieces = self._launch_pieces(start, start + n, frame_rays)
+        self._buffers(dev, max((j - i for i, j in pieces), default=1), len(pieces))
         prop0, prop1, fld = self.model._c_structs()
         ins = self._inputs(dev)
         ins.nears, ins.fars = self._nf[0].data_ptr(), self._nf[1].data_ptr()
         outs = _hip.tn_render_outputs()
         wsn = self._ws.shape[1]
         family = KERNEL_FAMILY[self.model.config.kernel_family]
-        frame_launches = -(-frame_rays // self.launch_rays)
-        multi_frame = self.num_streams > 1 and frame_launches > 1  # what render() of the WHOLE frame would decide
-        fam_prop = fam_field = 1 if (family == 0 and multi_frame and self.launch_rays >= 49152) else family
-        if fam_prop == 0:
-            # "auto" is decided by the library from the size of the CALL (tn_render.hip: proposal pass lane = ray from 81 920
-            # rays; tn_render_mfma.hip: field pass from 57 344): a shard runs the form the unsharded launch of the frame would
-            # (tests/test_gpu_distributed.py renders frames on both sides of both thresholds)
-            whole = min(self.launch_rays, frame_rays)
-            fam_prop, fam_field = (1 if whole >= 81920 else 2), (1 if whole >= 57344 else 2)
         current = torch.cuda.current_stream(dev)
         multi = self.num_streams > 1 and len(pieces) > 1
         if multi:
@@ -227,9 +259,14 @@ class RayRenderEngine:
             st = self._streams[slot] if multi else current
             ws = self._ws[slot].data_ptr()
             ins.origins, ins.directions = o.data_ptr() + 12 * i, d.data_ptr() + 12 * i
+            if nears is not None:
+                ins.nears, ins.fars = nears.data_ptr() + 4 * i, fars.data_ptr() + 4 * i
             outs.rgb = out["rgb"].data_ptr() + 12 * i
             for k in OUTPUT_KEYS[1:]:
                 setattr(outs, k, out[k].data_ptr() + 4 * i)
+            # the forms the unsharded frame's launch over these rays runs in (frames on both sides of every threshold, both
+            # precisions: tests/test_gpu_distributed.py)
+            fam_prop, fam_field = self._forms(fld, frame_rays, p0)
             self.rc.kernel_family = fam_prop
             _hip.check(self.lib.tn_proposal_sample_fwd(prop0, prop1, self.rc, ins, outs, r, ws, wsn, st.cuda_stream),
                        "tn_proposal_sample_fwd")
@@ -237,6 +274,7 @@ class RayRenderEngine:
             _hip.check(self.lib.tn_field_render_chunked_fwd(fld, self.rc, ins, outs, r, ws, wsn, p0, self.chunk,
                                                             bounds.data_ptr() + 8 * (p0 // self.chunk), 0, st.cuda_stream),
                        "tn_field_render_chunked_fwd")
+        self.rc.kernel_family = family  # (the per-launch forms above are not the engine's setting)
         if multi:
             for st in self._streams:
                 current.wait_stream(st)
