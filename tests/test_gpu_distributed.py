@@ -302,12 +302,12 @@ def test_shards_of_a_frame_cut_into_several_launches_on_one_stream():
     o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=6)
     o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
     for streams in (1, 2):
-        eng = RayRenderEngine(model, chunk=8192, streams=streams, max_workspace_bytes=streams * 150 << 20)
+        eng = RayRenderEngine(model, chunk=8192, streams=streams, max_workspace_bytes=150 << 20)
         L = eng.frame_launch_rays(n)
         assert L % 8192 == 0 and L < n
         pieces = eng._launch_pieces(0, n, n)
         assert len(pieces) >= 2 and pieces[-1][1] == n and all(j - i == L for i, j in pieces[:-1])
-        assert eng.lib.tn_render_workspace_bytes(eng.rc, max(j - i for i, j in pieces)) <= 150 << 20  # a launch fits its slot's share
+        assert eng.lib.tn_render_workspace_bytes(eng.rc, max(j - i for i, j in pieces)) <= (150 << 20) // streams  # a launch fits its slot's share
         _shards_against_the_frame(eng, o, d, n, 3)
         # the 1080p frame of config 4 under the default budget: 4 launches of 8 chunks, 2 slots
     eng = RayRenderEngine(model, chunk=CHUNK)
