@@ -270,11 +270,20 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
     for i in range(warmup):
         step(start_step + i)
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    for i in range(steps):
-        step(start_step + warmup + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / steps
+    # three consecutive windows of steps / 3, each bracketed by a synchronise; ms_per_step = their MEDIAN (the host cores of a
+    # GPU box are shared: one slow window no longer decides the line), all three reported
+    n_win = 3 if steps >= 30 else 1
+    per = max(steps // n_win, 1)
+    wins, done = [], 0
+    for _ in range(n_win):
+        t = time.perf_counter()
+        for i in range(per):
+            step(start_step + warmup + done + i)
+        torch.cuda.synchronize()
+        wins.append((time.perf_counter() - t) / per)
+        done += per
+    steps = done
+    dt = sorted(wins)[len(wins) // 2]
     torch.set_num_threads(threads)
     _, _, b_all = algorithmic_bytes_per_ray(samples)
     f_all = algorithmic_flops_per_ray(samples)
@@ -289,6 +298,7 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
                        R, "one %dx%d view" % (side, side) if ray_batch == "patch" else "random pixels of 8 800x800 views", samples,
                        start_step),
            "value": R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "ms_per_step_windows": [round(w * 1e3, 4) for w in wins],
            "roofline": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_ray": 3 * b_all, "algorithmic_flops_per_ray": 3 * f_all,
                         "mfma_view": {"achieved": tfl, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -80,7 +80,8 @@ class RayRenderEngine:
             self._ws = None  # (release before growing: two generations of a GB-sized workspace need not coexist)
             self._ws = torch.empty((slots, need), dtype=torch.uint8, device=dev)
         if len(self._streams) < self.num_streams or (self._streams and self._streams[0].device != self._ws.device):
-            self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.num_streams)]
+            # streams on distinct hardware queues (two pool streams may share one and run their launches back to back)
+            self._streams = _hip.concurrent_streams(dev, self.num_streams)
         self._ws_rays = max(self._ws_rays, rays)
         # NS NearFarCollider in eval: near plane reset to 0; keyed on the planes, so a collider edited after
         # the first render is picked up

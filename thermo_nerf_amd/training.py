@@ -96,7 +96,10 @@ def _step_streams(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch
     key = (dev, _hip.current_stream())
     trio = _SIDE_STREAMS.get(key)
     if trio is None:
-        trio = _SIDE_STREAMS[key] = (torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        # (two streams on their own hardware queues: _hip.concurrent_streams — `torch.cuda.Stream()` twice may hand out a pair that
+        # shares a queue with each other or with the main stream, and the step's overlap is gone)
+        side = _hip.concurrent_streams(dev, 2)
+        trio = _SIDE_STREAMS[key] = (torch.cuda.current_stream(dev), side[0], side[1])
     return trio
 
 
