@@ -284,6 +284,27 @@ __device__ __forceinline__ void pack_step(const float (&v)[16], Pieces<P> &t0, P
     }
 }
 
+// Software pipelining of the MLP block (round 5).  Left alone, hipcc emits a layer as bursts of 10-14 back-to-back MFMAs followed by
+// runs of 50-95 split instructions: during a burst the wave is stuck behind its own MFMAs (in-order issue, 32 cycles each), during a
+// run it feeds the matrix pipe nothing, and the pipe is busy 48 % of the time although the SIMD's two waves offer it 11.5 k cycles
+// of work per 24 k-cycle pass.  Here the split of k-step ks + 1 is placed UNDER the MFMAs of k-step ks: one scheduling region per
+// k-step (sched_barrier on both sides) with an explicit issue pattern — one MFMA, then a few vector instructions — so a wave's own
+// vector work rides in its own MFMA shadow and only the first split of a layer is exposed.
+#ifndef TN_SPLIT_PIPELINE
+#define TN_SPLIT_PIPELINE 1
+#endif
+#define TN_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+// the issue pattern of one region: NM MFMAs, each followed by NV vector instructions (the region's own instructions; a group that
+// finds fewer takes what there is)
+template <int NM, int NV>
+__device__ __forceinline__ void mfma_valu_pattern() {
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        TN_SGB(0x008, 1);
+        TN_SGB(0x002, NV);
+    }
+}
+
 // one 64 -> 64 layer from relu(in): out[mt][nt] = bias + sum_ks A[mt][ks] x B[nt][ks]
 template <class P>
 __device__ __forceinline__ void layer64(const float *lds, int combo0, const float *bias, int lane, int h,
@@ -293,6 +314,29 @@ __device__ __forceinline__ void layer64(const float *lds, int combo0, const floa
         out[mt][0] = bias_frag(bias, mt, h);
         out[mt][1] = out[mt][0];
     }
+#if TN_SPLIT_PIPELINE
+    Pieces<P> b0 = split8<P, true>(in[0][0], 0), b1 = split8<P, true>(in[0][1], 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        Pieces<P> nb0 = b0, nb1 = b1;
+        const Pieces<P> a0 = load_a<P>(lds, combo0 + ks, lane), a1 = load_a<P>(lds, combo0 + 4 + ks, lane);
+        mma<P>(out[0][0], a0, b0);
+        mma<P>(out[0][1], a0, b1);
+        mma<P>(out[1][0], a1, b0);
+        mma<P>(out[1][1], a1, b1);
+        if (ks < 3) {
+            nb0 = split8<P, true>(in[(ks + 1) >> 1][0], (ks + 1) & 1);
+            nb1 = split8<P, true>(in[(ks + 1) >> 1][1], (ks + 1) & 1);
+            TN_SGB(0x100, 2 * P::NP);  // the A fragments first
+            mfma_valu_pattern<4 * P::NP * (P::NP + 1) / 2 - 2, 5>();
+            TN_SGB(0x008, 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = nb0;
+        b1 = nb1;
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const Pieces<P> b0 = split8<P, true>(in[ks >> 1][0], ks & 1), b1 = split8<P, true>(in[ks >> 1][1], ks & 1);
@@ -303,6 +347,7 @@ __device__ __forceinline__ void layer64(const float *lds, int combo0, const floa
             mma<P>(out[mt][1], a, b1);
         }
     }
+#endif
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
