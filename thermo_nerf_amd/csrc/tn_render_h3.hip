@@ -54,6 +54,13 @@ struct F16x3 {
         pk[0] = __builtin_bit_cast(unsigned, h2{h0, h1});
         pk[1] = __builtin_bit_cast(unsigned, h2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)});
     }
+    // the products of one fp32 product as a list (a piece, b piece), in issue order (mma() below = the whole list)
+    static constexpr int NPROD = 3;
+    static __host__ __device__ constexpr int ka(int j) { return j == 0 ? 1 : 0; }
+    static __host__ __device__ constexpr int kb(int j) { return j == 1 ? 1 : 0; }
+    static __device__ __forceinline__ f32x16 mfma(const vec &a, const vec &b, const f32x16 &acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
     static __device__ __forceinline__ void mma(f32x16 &acc, const vec (&a)[NP], const vec (&b)[NP]) {
 #ifdef TN_H3_PROBE_SIX_PRODUCTS
         // timing probe only: the matrix-pipe load of a SIX-product split — three more MFMAs per step that add zeros
@@ -93,6 +100,12 @@ struct BF16x6 {
         pk[1] = __builtin_bit_cast(unsigned, p2);
         const f2 r2 = {r1[0] - __uint_as_float(pk[1] << 16), r1[1] - __uint_as_float(pk[1] & 0xffff0000u)};
         pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
+    }
+    static constexpr int NPROD = 6;  // (0,2) (2,0) (1,1) (0,1) (1,0) (0,0): small terms first
+    static __host__ __device__ constexpr int ka(int j) { return j == 1 ? 2 : (j == 2 || j == 4) ? 1 : 0; }
+    static __host__ __device__ constexpr int kb(int j) { return j == 0 ? 2 : (j == 2 || j == 3) ? 1 : 0; }
+    static __device__ __forceinline__ f32x16 mfma(const vec &a, const vec &b, const f32x16 &acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
     static __device__ __forceinline__ void mma(f32x16 &acc, const vec (&a)[NP], const vec (&b)[NP]) {
         // small terms first
@@ -215,6 +228,27 @@ __device__ __forceinline__ Pieces<P> load_a(const float *lds, int combo, int lan
     return a;
 }
 
+// one value pair (2 m, 2 m + 1 of the k-step's 8 values) of split8, into dword m of every piece
+template <class P, bool RELU>
+__device__ __forceinline__ void split_pair_of(const f32x16 &x, int q, int m, unsigned (&pk)[P::NP][4]) {
+    float v0 = x[8 * q + 2 * m], v1 = x[8 * q + 2 * m + 1];
+    if (RELU) {
+        v0 = relu_bits(v0);
+        v1 = relu_bits(v1);
+    }
+    unsigned pr[P::NP];
+    P::split_pair(v0, v1, pr);
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) pk[k][m] = pr[k];
+}
+template <class P>
+__device__ __forceinline__ Pieces<P> pieces_of(const unsigned (&pk)[P::NP][4]) {
+    Pieces<P> r;
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) r.p[k] = __builtin_bit_cast(typename P::vec, uint4{pk[k][0], pk[k][1], pk[k][2], pk[k][3]});
+    return r;
+}
+
 template <class P, bool RELU>
 __device__ __forceinline__ Pieces<P> split8(const f32x16 &x, int q) {
     unsigned pk[P::NP][4];
@@ -293,15 +327,39 @@ __device__ __forceinline__ void pack_step(const float (&v)[16], Pieces<P> &t0, P
 #ifndef TN_SPLIT_PIPELINE
 #define TN_SPLIT_PIPELINE 1
 #endif
-#define TN_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
-// the issue pattern of one region: NM MFMAs, each followed by NV vector instructions (the region's own instructions; a group that
-// finds fewer takes what there is)
-template <int NM, int NV>
-__device__ __forceinline__ void mfma_valu_pattern() {
+// A [64 x 64] x relu(in) product, NMT output tiles of 32 features (layer64: 2, mlp_base's second layer: 1), as a software pipeline
+// over (k-step, ray tile): the 2 NMT NPROD ... MFMAs of one (ks, nt) in four chunks, each followed by the split of ONE value pair of the
+// NEXT (ks, nt)'s B operand, a scheduling fence after every chunk — the order below is the order in the binary.  Only the very
+// first B operand (4 pairs) is split in the open; B operands live for one (ks, nt) only (12 + 12 registers instead of 48).
+// A fragments: mt = 0's of the next k-step are requested once this k-step's are dead (tile 1, chunk NMT), mt = 1's at tile 0, chunk 0.
+template <class P, int NMT>
+__device__ __forceinline__ void layer_pipelined(const float *lds, int combo0, int lane, const f32x16 (&in)[2][2], f32x16 (&out)[NMT][2]) {
+    constexpr int NM = NMT * P::NPROD;  // MFMAs per (ks, nt)
+    Pieces<P> bc = split8<P, true>(in[0][0], 0);
+    Pieces<P> a[2];
+    a[0] = load_a<P>(lds, combo0, lane);
+    a[1] = a[0];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        TN_SGB(0x008, 1);
-        TN_SGB(0x002, NV);
+    for (int step = 0; step < 8; ++step) {
+        const int ks = step >> 1, nt = step & 1;
+        const int nks = (step + 1) >> 1, nnt = (step + 1) & 1;
+        const bool has_next = step < 7;
+        unsigned nx[P::NP][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (NMT == 2 && nt == 0 && c == 0) a[1] = load_a<P>(lds, combo0 + 4 + ks, lane);
+#pragma unroll
+            for (int idx = c * NM / 4; idx < (c + 1) * NM / 4; ++idx) {
+                const int mt = idx / P::NPROD, j = idx % P::NPROD;
+                out[mt][nt] = P::mfma(a[mt].p[P::ka(j)], bc.p[P::kb(j)], out[mt][nt]);
+            }
+            // (the last MFMA that reads a[0] of this k-step sits in chunk 4 / NMT - 1 of tile 1)
+            if (nt == 1 && ks < 3 && c == 4 / NMT - 1) a[0] = load_a<P>(lds, combo0 + ks + 1, lane);
+            if (has_next) split_pair_of<P, true>(in[nks >> 1][nnt], nks & 1, c, nx);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (has_next) bc = pieces_of<P>(nx);
     }
 }
 
@@ -315,27 +373,7 @@ __device__ __forceinline__ void layer64(const float *lds, int combo0, const floa
         out[mt][1] = out[mt][0];
     }
 #if TN_SPLIT_PIPELINE
-    Pieces<P> b0 = split8<P, true>(in[0][0], 0), b1 = split8<P, true>(in[0][1], 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        Pieces<P> nb0 = b0, nb1 = b1;
-        const Pieces<P> a0 = load_a<P>(lds, combo0 + ks, lane), a1 = load_a<P>(lds, combo0 + 4 + ks, lane);
-        mma<P>(out[0][0], a0, b0);
-        mma<P>(out[0][1], a0, b1);
-        mma<P>(out[1][0], a1, b0);
-        mma<P>(out[1][1], a1, b1);
-        if (ks < 3) {
-            nb0 = split8<P, true>(in[(ks + 1) >> 1][0], (ks + 1) & 1);
-            nb1 = split8<P, true>(in[(ks + 1) >> 1][1], (ks + 1) & 1);
-            TN_SGB(0x100, 2 * P::NP);  // the A fragments first
-            mfma_valu_pattern<4 * P::NP * (P::NP + 1) / 2 - 2, 5>();
-            TN_SGB(0x008, 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        b0 = nb0;
-        b1 = nb1;
-    }
+    layer_pipelined<P, 2>(lds, combo0, lane, in, out);
 #else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -530,19 +568,23 @@ __global__ void __launch_bounds__(P::kBlock, P::kBlocksPerCU) main_split_rays_ke
                 }
             }
             // ---- mlp_base layer 1: 64 -> 16 ---------------------------------------------------------------
-            f32x16 g[2];
-            g[0] = bias_frag(lds + LY::B_BASE2, 0, h);
-            g[1] = g[0];
+            f32x16 g[1][2];
+            g[0][0] = bias_frag(lds + LY::B_BASE2, 0, h);
+            g[0][1] = g[0][0];
+#if TN_SPLIT_PIPELINE
+            layer_pipelined<P, 1>(lds, C_BASE2, lane, h1, g);
+#else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const HL aw = load_a<P>(lds, C_BASE2 + ks, lane);
-                mma<P>(g[0], aw, split8<P, true>(h1[ks >> 1][0], ks & 1));
-                mma<P>(g[1], aw, split8<P, true>(h1[ks >> 1][1], ks & 1));
+                mma<P>(g[0][0], aw, split8<P, true>(h1[ks >> 1][0], ks & 1));
+                mma<P>(g[0][1], aw, split8<P, true>(h1[ks >> 1][1], ks & 1));
             }
+#endif
             float raw, unused;
-            swap32(g[0][0], g[1][0], raw, unused);
+            swap32(g[0][0][0], g[0][1][0], raw, unused);
             const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
-            const HL g0 = split8<P, false>(g[0], 0), g1 = split8<P, false>(g[1], 0);  // geo rows (row 0 has zero weight)
+            const HL g0 = split8<P, false>(g[0][0], 0), g1 = split8<P, false>(g[0][1], 0);  // geo rows (row 0 has zero weight)
             {   // colour: [geo | SH] -> 64 -> 64 -> 3
                 f32x16 x1[2][2], x2[2][2];
 #pragma unroll
