@@ -613,8 +613,11 @@ def measure_shard_proxy(dev, args, reps: int = 4):
                 oa, da = o[a:b].contiguous(), d[a:b].contiguous()
                 out = engine.allocate_outputs(b - a, dev)
 
-                def once(a=a, oa=oa, da=da, out=out):
-                    _, bounds = engine.render_shard(oa, da, a, n, out=out)
+                # the segments per tile a frame sharded N ways is rendered with (the same on every rank; 1 at N = 1)
+                k_split = engine.shard_sample_split(D.ray_block(n, 0, N)[1]) if N > 1 else 1
+
+                def once(a=a, oa=oa, da=da, out=out, k_split=k_split):
+                    _, bounds = engine.render_shard(oa, da, a, n, out=out, sample_split=k_split)
                     engine.apply_depth_bounds(out, a, bounds)
 
                 once()
@@ -628,7 +631,7 @@ def measure_shard_proxy(dev, args, reps: int = 4):
             gather = 0.0 if N == 1 else shard_rays * 36 / (XGMI_LINK_GBS * 1e9) + 30e-6
             if N == 1:
                 t1 = worst
-            rows["N%d" % N] = {"rays_per_rank": shard_rays, "shard_ms": worst * 1e3, "gather_ms_priced": gather * 1e3,
+            rows["N%d" % N] = {"rays_per_rank": shard_rays, "sample_split": k_split, "shard_ms": worst * 1e3, "gather_ms_priced": gather * 1e3,
                                "frame_rays_per_s": n / (worst + gather), "implied_efficiency": t1 / (N * (worst + gather))}
         res[tag] = rows
         del model, engine
@@ -674,6 +677,8 @@ def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None):
     d = d3.reshape(-1, 3)[r0:r1].contiguous().to(dev)
     out = engine.allocate_outputs(max(r1 - r0, 1), dev)
     frame = [None]
+    # segments per 64-ray tile of the field pass: what suits ONE rank's run, the same on every rank (distributed.render_frame_sharded_fine)
+    k_split = engine.shard_sample_split(counts[0]) if world > 1 else None
 
     def step():
         if world == 1:
@@ -682,7 +687,7 @@ def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None):
             return
         # this rank's pieces of the reference's chunks; the chunk-wide expected-depth bounds joined by one all-reduce of
         # 2 floats per chunk; then the frame exists (on every rank) once the gather is done: inside the step, not pipelined away
-        _, bounds = engine.render_shard(o, d, r0, n_rays, out=out)
+        _, bounds = engine.render_shard(o, d, r0, n_rays, out=out, sample_split=k_split)
         key = torch.stack([bounds[:, 0], -bounds[:, 1]], dim=1).contiguous()
         dist.all_reduce(key, op=dist.ReduceOp.MIN)
         engine.apply_depth_bounds(out, r0, torch.stack([key[:, 0], -key[:, 1]], dim=1).contiguous())

@@ -232,6 +232,15 @@ typedef struct tn_render_config {
     /* ProposalNetworkSampler's initial sampler [REF thermal_nerf_model.py:164-170]: 0 = UniformLinDispPiecewiseSampler
      * ("piecewise", the default), 1 = UniformSampler ("uniform").  Every level's spacing -> euclidean map follows it. */
     int32_t initial_sampler;
+    /* Sample-split tiles of the exact-fp32 lane = ray field kernel (eval; round 5 — APPENDED: zero-initialise the struct, 0 keeps
+     * every older caller's meaning of "the library decides").  A 64-ray tile marches its S samples serially, so a call of T tiles
+     * lasts ceil(T / 2048) marches however few tiles there are; with k segments per tile it lasts ceil(k T / 2048) marches of S / k
+     * samples, each segment composited with its own transmittance and chained by a second pass (w_i = T_j w_i_local: the
+     * reference's weights [NS RaySamples.get_weights, called at REF thermal_nerf_model.py:233] in another association — same
+     * tolerance, other last bits than the serial march).  0 = by call size (tn_render_sample_split; 1 from ~400 k rays up),
+     * 1 = never, k > 1 = k segments (capped so that the records fit the workspace: tn_render_sample_split reports the value used).
+     * Ignored (1) by the training, early-termination, split-precision and one-ray-per-wave kernels. */
+    int32_t sample_split;
 } tn_render_config;
 
 typedef struct tn_render_inputs {
@@ -304,6 +313,10 @@ int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_
  * and wants the whole launch's bits asks for the whole launch's form here and passes it as cfg->kernel_family.  No reference
  * counterpart (the reference has one code path, REF render/renderer.py:182-187); 0 on a NULL cfg. */
 int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass);
+/* The number of sample segments per tile tn_field_render_fwd / _chunked_fwd use for a call of num_rays rays under
+ * cfg->sample_split (see there).  Like the kernel form it is a property of the CALL: a caller that renders part of a launch and
+ * wants the whole launch's bits passes the whole launch's value as cfg->sample_split. */
+int32_t tn_render_sample_split(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays);
 int tn_field_render_chunked_fwd(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                                 const tn_render_outputs *out, int64_t num_rays, void *workspace, size_t workspace_bytes,
                                 int64_t first_ray, int64_t chunk_rays, float *depth_bounds, int32_t clip, void *stream);

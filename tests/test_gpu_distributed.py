@@ -239,15 +239,17 @@ def test_sub_chunk_shards_reproduce_the_unsharded_frame(h, w, chunk, world):
         assert torch.equal(got, want[k]), (k, (got - want[k]).abs().max().item())
 
 
-def _shards_against_the_frame(eng, o, d, n, world, nears=None, fars=None):
+def _shards_against_the_frame(eng, o, d, n, world, nears=None, fars=None, sample_split=None):
     """every rank's render_shard + the reduced bounds, concatenated, against eng.render of the whole frame: bit for bit"""
     from thermo_nerf_amd import distributed as D
 
-    want = {k: v.clone() for k, v in eng.render(o, d, nears=nears, fars=fars).items()}
+    want = {k: v.clone() for k, v in eng.render(o, d, nears=nears, fars=fars, sample_split=sample_split).items()}
     shards = []
     for r in range(world):
         a, b = D.ray_block(n, r, world)
         kw = {} if nears is None else {"nears": nears[a:b].contiguous(), "fars": fars[a:b].contiguous()}
+        if sample_split is not None:
+            kw["sample_split"] = sample_split
         out, bounds = eng.render_shard(o[a:b].contiguous(), d[a:b].contiguous(), a, n, **kw)
         shards.append(({k: v.clone() for k, v in out.items()}, a, bounds.clone()))
     lo = torch.stack([b[:, 0] for _, _, b in shards]).min(dim=0).values
@@ -287,6 +289,30 @@ def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, preci
     assert eng._forms(fld, n, 0) == (eng.lib.tn_render_kernel_form(None, eng.rc, n, 0), form)
     _shards_against_the_frame(eng, o, d, n, 4)
     assert eng.rc.kernel_family == 0  # render_shard leaves the engine's setting alone
+
+
+@pytest.mark.parametrize("h,w,world", [(800, 800, 8), (300, 400, 3)])
+def test_sample_split_shards_reproduce_the_frame_rendered_with_that_split(h, w, world):
+    """Strong scaling of a frame whose per-rank run under-fills the chip (800 x 800 over 8 ranks: 1 250 tiles on 2 048 wave slots):
+    the field pass marches every tile in k segments (engine.shard_sample_split(run size): the same k on every rank).  The split
+    is a property of the FRAME — the shards equal engine.render(frame, sample_split=k) bit for bit, expected depth included — and
+    that frame sits within rounding of the default one."""
+    from thermo_nerf_amd import distributed as D
+    from thermo_nerf_amd import synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    model, _, _ = _model()
+    n = h * w
+    o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=3)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    eng = RayRenderEngine(model, chunk=CHUNK)
+    k = eng.shard_sample_split(D.ray_block(n, 0, world)[1])
+    assert k > 1
+    got = _shards_against_the_frame(eng, o, d, n, world, sample_split=k)
+    plain = eng.render(o, d)
+    for name in ("rgb", "thermal", "accumulation"):
+        assert (got[name] - plain[name]).abs().max().item() <= 3e-6, name
+    assert eng.rc.sample_split == 0 and eng.rc.kernel_family == 0
 
 
 def test_shards_of_a_frame_cut_into_several_launches_on_one_stream():

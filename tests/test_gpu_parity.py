@@ -11,7 +11,7 @@ import torch
 
 from oracle import hotpath as H
 from tests import helpers
-from thermo_nerf_amd import (FieldHeadNames, FieldHeadNamesT, Frustums, RayBundle, RaySamples, ThermalRenderer,
+from thermo_nerf_amd import (FieldHeadNames, FieldHeadNamesT, Frustums, RayBundle, RaySamples, ThermalRenderer, _hip,
                              synthetic)
 from thermo_nerf_amd.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
 from thermo_nerf_amd.samplers import PDFSampler, UniformLinDispPiecewiseSampler, UniformSampler
@@ -397,6 +397,53 @@ def test_get_outputs_eval(kind, S, impl):
     for k in ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal"):
         assert got[k].shape == want[k].shape, k
     check_outputs(got, want, f"{kind}/S{S}/fused={fused}")
+
+
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+@pytest.mark.parametrize("S", [48, 50, 192, 13])
+def test_sample_split_tiles_match_the_oracle_and_the_serial_march(kind, S):
+    """Sample-split tiles (tn_render_config.sample_split; round 5): a tile's march cut into k segments on k waves, chained by
+    segments_combine_kernel — w_i = T_j w_i^local.  Every k is held to the oracle's tolerances (incl. the median's tie gate) and sits
+    within rounding of the serial march (k = 1); S = 50 leaves a ragged last segment, S = 13 is too short to split (the library
+    answers 1).  The small calls of this module run the library's own choice (k = 6 ... 8) everywhere else."""
+    gm, sd, ocfg = gpu_model(kind, S)
+    gm.config.fused, gm.config.use_mfma, gm.config.mlp_precision = True, True, "f32"
+    o, d = helpers.rays(21, 19, view=S % 8)
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    lib = _hip.load()
+    outs = {}
+    for k in (1, 2, 3, 5, 8, 0):
+        gm.config.sample_split = k
+        with torch.no_grad():
+            outs[k] = {n: v.clone() for n, v in gm(bundle(o, d)).items()}
+        check_outputs(outs[k], want, f"{kind}/S{S}/sample_split={k}")
+    gm.config.sample_split = 0
+    for k in (2, 3, 5, 8, 0):
+        for n in ("rgb", "thermal", "accumulation", "expected_depth"):
+            scale = 1.0 if n != "expected_depth" else float(outs[1][n].abs().max())
+            assert (outs[k][n] - outs[1][n]).abs().max().item() <= 3e-6 * scale, (k, n)
+    # what the library reports it used: capped by the scratch (12 k + S floats per ray within 256 + 97) and by 8 samples per segment
+    rc = _hip.tn_render_config()
+    rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = 256, 96, S
+    rc.kernel_family = 1
+    _, _, fld = gm._c_structs()
+    cap = max(min(8, (353 - S) // 12, S // 8), 1)
+    for k in (1, 2, 5, 8, 100):
+        rc.sample_split = k
+        assert lib.tn_render_sample_split(fld, rc, 399) == (1 if cap < 2 else min(k, cap))
+    rc.sample_split = 0
+    auto_small, auto_frame = lib.tn_render_sample_split(fld, rc, 399), lib.tn_render_sample_split(fld, rc, 640000)
+    assert auto_frame == 1 and auto_small == (cap if cap >= 2 else 1)
+    if S == 192:  # an 80 000-ray shard of the metric's frame: 1 250 tiles -> 8 segments; the reference's 65 536-ray chunk at S = 48: 2
+        assert lib.tn_render_sample_split(fld, rc, 80000) == 8 and lib.tn_render_sample_split(fld, rc, 160000) == 4
+    if S == 48:
+        assert lib.tn_render_sample_split(fld, rc, 65536) == 2
+    rc.training = 1
+    assert lib.tn_render_sample_split(fld, rc, 399) == 1
+    rc.training, rc.early_stop_transmittance = 0, 1e-3
+    assert lib.tn_render_sample_split(fld, rc, 399) == 1
+    rc.early_stop_transmittance, rc.kernel_family = 0.0, 2
+    assert lib.tn_render_sample_split(fld, rc, 399) == 1
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])

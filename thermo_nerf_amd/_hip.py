@@ -113,6 +113,7 @@ class tn_render_config(C.Structure):
         ("early_stop_transmittance", C.c_float),
         ("kernel_family", C.c_int32),
         ("initial_sampler", C.c_int32),
+        ("sample_split", C.c_int32),
     ]
 
 
@@ -182,6 +183,7 @@ SIGNATURES = {
     ),
     "tn_depth_bound_slots": (_i64, [_i64, _i64, _i64]),
     "tn_render_kernel_form": (C.c_int32, [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), _i64, C.c_int32]),
+    "tn_render_sample_split": (C.c_int32, [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), _i64]),
     "tn_field_render_chunked_fwd": (
         C.c_int,
         [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), C.POINTER(tn_render_inputs),

@@ -38,7 +38,7 @@ namespace tn {
 // implemented in tn_render_mfma.hip
 int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                      const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
-                     hipStream_t stream);
+                     hipStream_t stream, int split, float *seg_scratch);
 // implemented in tn_render_h3.hip (the two split-precision policies of one kernel)
 int launch_main_b6(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                    const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
@@ -893,7 +893,12 @@ static int field_render_fwd(const tn_thermal_field *field, const tn_render_confi
     } else if (field->prepared_f16x3 && split_ok) {
         TN_TRY(launch_main_h3(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
     } else if (field->prepared) {
-        TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s));
+        // sample-split tiles (tn_render_sample_split): records + per-sample cumulative weights live in the proposal pass's scratch
+        // region of this workspace (dead once the bin edges exist; 12 k + S floats per ray <= its 256 + 97 by the policy's cap)
+        const int split = out->weights[2] ? 1 : tn_render_sample_split(field, cfg, num_rays);
+        float *seg_scratch = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                                       align_up(tn_ws_bin_floats(num_rays, S) * sizeof(float), 256) + kWsMid);
+        TN_TRY(launch_main_mfma(field, cfg, in, out, (long long)num_rays, ws_spacing, minmax, s, split, seg_scratch));
     } else {
         MainArgs ma;
         ma.g = tn_make_grid(field->grid);
@@ -939,6 +944,33 @@ int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_con
     // field pass: the split-precision kernels exist in the lane = ray form only and pay from 640 tiles; the exact-fp32 one from 896
     const bool split = field && !cfg->training && (field->prepared_bf16x6 || field->prepared_f16x3);
     return num_rays < (split ? 40960 : 57344) ? 2 : 1;
+}
+
+int32_t tn_render_sample_split(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays) {
+    if (!cfg || !field || num_rays <= 0 || cfg->sample_split == 1) return 1;
+    // only the exact-fp32 lane = ray eval kernel has the segmented form
+    if (cfg->training || cfg->early_stop_transmittance > 0.0f || !field->prepared || field->prepared_bf16x6 || field->prepared_f16x3) return 1;
+    if (tn_render_kernel_form(field, cfg, num_rays, 1) != 1) return 1;
+    const int S = cfg->num_nerf_samples, P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1];
+    // the records (12 floats per segment) and the per-sample cumulative weights (S floats) of a ray must fit the proposal
+    // scratch of the workspace (max(P0, P1) + P1 + 1 floats per ray); a segment is at least 8 samples
+    const int scratch = (P0 > P1 ? P0 : P1) + P1 + 1;
+    int kmax = (scratch - S) / 12;
+    if (kmax > S / 8) kmax = S / 8;
+    if (kmax > 8) kmax = 8;
+    if (kmax < 2) return 1;
+    if (cfg->sample_split > 1) return cfg->sample_split < kmax ? cfg->sample_split : kmax;
+    // by call size: a call of T tiles lasts ceil(k T / 2048) marches of ceil(S / k) samples (+ ~2 samples' worth of per-segment
+    // set-up: ray loads, SH basis, record); from three full rounds on the tail is not worth the second pass
+    const long long slots = 2048, tiles = (num_rays + 63) / 64;
+    if (tiles >= 3 * slots) return 1;
+    int best = 1;
+    long long best_cost = ((tiles + slots - 1) / slots) * (S + 2);
+    for (int k = 2; k <= kmax; ++k) {
+        const long long cost = ((tiles * k + slots - 1) / slots) * ((S + k - 1) / k + 2);
+        if (cost < best_cost) { best = k; best_cost = cost; }
+    }
+    return best;
 }
 
 int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays) {

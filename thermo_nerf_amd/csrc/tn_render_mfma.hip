@@ -172,7 +172,13 @@ struct MfmaArgs {
     float *out_w;
     DepthSlots minmax;  // expected-depth clip bounds: one key pair per call, or per reference chunk of the frame
     float early_eps;  // eval only; 0 = never stop early
+    // sample-split tiles (main_mfma_rays_kernel<., true>): a tile's S samples as `split` contiguous segments of seg_len, one wave
+    // each; per (tile, segment) a 12-row record [64 lanes] in seg_rec, per (tile, sample) the segment-local cumulative weight in
+    // seg_cum [tile][S][64] — both inside the proposal pass's scratch region of the workspace, which is dead by now
+    int split, seg_len;
+    float *seg_rec, *seg_cum;
 };
+constexpr int SEG_ROWS = 12;  // optical depth | sum w | sum w r,g,b | sum w th | sum w step | last sample's r,g,b,th | last mid-point
 
 #define MFMA32(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (acc), 0, 0, 0)
 #define MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (acc), 0, 0, 0)
@@ -526,7 +532,16 @@ __device__ __forceinline__ float2 out_dot_fast(const float *wrow, int h, const f
     return make_float2(p0, p1);
 }
 
-template <bool DENSE>
+// SPLIT (round 5): the unit of work is a SEGMENT of a tile's sample march (virtual tile = tile * split + segment, neighbours in the
+// grid: a tile's segments run side by side and share its table lines).  A lane = ray tile marches its samples serially, so a call
+// of T tiles lasts ceil(T / 2048 wave slots) full marches whatever T is: 1 250 tiles (an 80 000-ray shard of the metric's frame on
+// 8 GPUs) cost as much as 2 048.  With k segments per tile the same call is ceil(k T / 2048) marches of S / k samples.  A segment
+// composites with its OWN transmittance (starting at 1) and leaves a record; segments_combine_kernel chains the records:
+// w_i = T_j w_i^local with T_j = exp(-(optical depth of the segments before j)) — the reference's weights in another
+// association of the same products (not bit-equal to the unsplit march: same tolerance, and the split count is a property of the
+// CALL, tn_render_sample_split, so parts of a call agree with the whole bit for bit).  The median needs the crossing of 0.5 by
+// the GLOBAL cumulative weight: every sample stores its segment-local one, the combine pass searches the segment that crosses.
+template <bool DENSE, bool SPLIT = false>
 __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -542,9 +557,14 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
     const int S = a.S;
     const long long groups = (a.R + 63) >> 6;
     const long long stride = (long long)gridDim.x * kWaves;
+    const int K = SPLIT ? a.split : 1;
+    const long long vgroups = groups * K;
     float smin = INFINITY, smax = -INFINITY;
     long long mm_slot = 0;
-    for (long long grp = (long long)blockIdx.x * kWaves + wave; grp < groups; grp += stride) {
+    for (long long vg = (long long)blockIdx.x * kWaves + wave; vg < vgroups; vg += stride) {
+        const long long grp = SPLIT ? vg / K : vg;
+        const int s0 = SPLIT ? (int)(vg - grp * K) * a.seg_len : 0;
+        const int s1 = SPLIT ? (s0 + a.seg_len < S ? s0 + a.seg_len : S) : S;
         // (a tile never straddles two chunks: first_ray and chunk_rays are multiples of 64; a wave's tiles ascend)
         if (a.minmax.chunk_rays > 0 && a.minmax.slot(grp * 64) != mm_slot) {
             depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
@@ -569,15 +589,15 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) swap32(c[2 * s], c[2 * s + 1], bs0[s], bs1[s]);
         }
-        float en = spacing_to_eucl<true>(tb[0], s_near, s_far, lin);
+        float en = spacing_to_eucl<true>(tb[(size_t)s0 * 64], s_near, s_far, lin);
         float accum = 0.0f, cum_w = 0.0f;  // sum of delta*sigma before this sample; running sum of weights
         float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
         bool med_found = false;
         // the bin edges come from the workspace (HBM / Infinity Cache): the next one is requested a sample ahead, so that its
         // round trip is not the first thing a sample waits for (field kernel 32.0 -> 31.75 ms per 640 k rays at S=192)
-        float sb_next = tb[64];
-        for (int i = 0; i < S; ++i) {
+        float sb_next = tb[(size_t)(s0 + 1) * 64];
+        for (int i = s0; i < s1; ++i) {
             const float st = en;
             en = spacing_to_eucl<true>(sb_next, s_near, s_far, lin);
             sb_next = tb[(size_t)(i + 2 <= S ? i + 2 : S) * 64];
@@ -659,6 +679,10 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
             wsteps += mul_rn(wi, step);
             smin = fminf(smin, step);
             smax = fmaxf(smax, step);
+            if (SPLIT) {  // (the launch guarantees no weights output and no early termination in this form)
+                a.seg_cum[((size_t)grp * S + i) * 64 + lane] = cum_w;
+                continue;
+            }
             if (a.out_w && live) a.out_w[r * S + i] = wi;
             // early ray termination (eval, opt-in): wave-wide vote on the transmittance left after this sample
             if (a.early_eps > 0.0f && i + 1 < S && __all(__expf(-accum) < a.early_eps)) {
@@ -668,6 +692,13 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
                 smax = fmaxf(smax, add_rn(e0, e1) / 2.0f);
                 break;
             }
+        }
+        if (SPLIT) {
+            float *rec = a.seg_rec + (size_t)vg * SEG_ROWS * 64 + lane;
+            const float row[SEG_ROWS] = {accum, wsum, wr, wg, wbl, wth, wsteps, cr, cg, cb, th, step};
+#pragma unroll
+            for (int k = 0; k < SEG_ROWS; ++k) rec[k * 64] = row[k];
+            continue;
         }
         if (live) {  // cr..th / step now hold the LAST sample: the "last_sample" background
             const float bg = sub_rn(1.0f, wsum);
@@ -683,6 +714,57 @@ __global__ void __launch_bounds__(kBlock, 2) main_mfma_rays_kernel(MfmaArgs a) {
         }
     }
     depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
+}
+
+// The records of a ray's segments chained into the renderers' outputs (one lane per ray; see main_mfma_rays_kernel<., true>).
+// Segment j's samples carry the weights T_j w^local with T_j = exp(-(optical depth before j)); NS get_weights' nan_to_num applies per
+// sample, so a NaN prefix (a NaN density earlier on the ray) zeroes everything behind it, as it does in the serial march.
+__global__ void segments_combine_kernel(MfmaArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    const long long grp = r >> 6;
+    const int lane = (int)(r & 63), S = a.S, K = a.split;
+    const bool lin = a.lin != 0;
+    float depth_so_far = 0.0f;
+    float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f, med = 0.0f;
+    bool med_found = false;
+    const float *rec = a.seg_rec + (size_t)grp * K * SEG_ROWS * 64 + lane;
+    for (int j = 0; j < K; ++j, rec += SEG_ROWS * 64) {
+        float T = __expf(-depth_so_far);
+        T = T == T ? T : 0.0f;
+        const float total = add_rn(wsum, mul_rn(T, rec[1 * 64]));
+        if (!med_found && total >= 0.5f) {  // the crossing lies in this segment: first sample whose global cumulative weight reaches 0.5
+            const int s0 = j * a.seg_len, s1 = s0 + a.seg_len < S ? s0 + a.seg_len : S;
+            const float *cum = a.seg_cum + ((size_t)grp * S + s0) * 64 + lane;
+            int i = s0;
+            for (; i < s1 - 1; ++i, cum += 64)
+                if (add_rn(wsum, mul_rn(T, cum[0])) >= 0.5f) break;
+            const float s_near = spacing_fn(a.nears[r], lin), s_far = spacing_fn(a.fars[r], lin);
+            const float *tb = a.spacing + tn_ws_bin(grp * 64, 0, S) + lane;
+            med = add_rn(spacing_to_eucl<true>(tb[(size_t)i * 64], s_near, s_far, lin),
+                         spacing_to_eucl<true>(tb[(size_t)(i + 1) * 64], s_near, s_far, lin)) / 2.0f;
+            med_found = true;
+        }
+        wsum = total;
+        wr = add_rn(wr, mul_rn(T, rec[2 * 64]));
+        wg = add_rn(wg, mul_rn(T, rec[3 * 64]));
+        wbl = add_rn(wbl, mul_rn(T, rec[4 * 64]));
+        wth = add_rn(wth, mul_rn(T, rec[5 * 64]));
+        wsteps = add_rn(wsteps, mul_rn(T, rec[6 * 64]));
+        depth_so_far += rec[0];
+    }
+    rec -= SEG_ROWS * 64;  // the last segment's last sample: the "last_sample" background and the clamped median
+    const float cr = rec[7 * 64], cg = rec[8 * 64], cb = rec[9 * 64], th = rec[10 * 64], step = rec[11 * 64];
+    const float bg = sub_rn(1.0f, wsum);
+    const float c0 = add_rn(wr, mul_rn(cr, bg)), c1 = add_rn(wg, mul_rn(cg, bg)), c2 = add_rn(wbl, mul_rn(cb, bg));
+    const float ct = add_rn(wth, mul_rn(th, bg));
+    a.rgb[r * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);
+    a.rgb[r * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);
+    a.rgb[r * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);
+    a.thermal[r] = fminf(fmaxf(ct, 0.0f), 1.0f);
+    a.acc[r] = wsum;
+    a.depth[r] = med_found ? med : step;
+    a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
 }
 
 
@@ -951,7 +1033,7 @@ namespace tn {
 
 int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg, const tn_render_inputs *in,
                      const tn_render_outputs *out, long long num_rays, const float *spacing_ws, DepthSlots minmax,
-                     hipStream_t stream) {
+                     hipStream_t stream, int split, float *seg_scratch) {
     if (!mfma_supported(field) || !field->prepared) return TN_ERR_UNSUPPORTED;
     MfmaArgs a;
     a.g = tn_make_grid(field->grid);
@@ -967,6 +1049,7 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.out_w = out->weights[2]; a.minmax = minmax;
     a.early_eps = cfg->training ? 0.0f : fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
+    a.split = 1; a.seg_len = a.S; a.seg_rec = nullptr; a.seg_cum = nullptr;
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
     const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 77 KB each)
     // 1.5 ms floor of the tile march vs 0.16 ms at 4096 rays
@@ -974,6 +1057,25 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     if (!cfg->training && !out->weights[2] && !small_call) {
         // eval: lane = ray (64 consecutive rays per wave), coherent gathers
         const bool dense = a.g.num_dense >= kFieldDense;  // the dense variant reads exactly kFieldDense levels densely
+        if (split > 1 && seg_scratch && a.early_eps == 0.0f) {
+            const long long groups = (num_rays + 63) / 64;
+            a.seg_len = (a.S + split - 1) / split;
+            a.split = (a.S + a.seg_len - 1) / a.seg_len;  // (no empty segment)
+            a.seg_rec = seg_scratch;
+            a.seg_cum = seg_scratch + (size_t)groups * a.split * SEG_ROWS * 64;
+            if (!(dense ? tn_ensure_dynamic_lds<main_mfma_rays_kernel<true, true>>(smem) : tn_ensure_dynamic_lds<main_mfma_rays_kernel<false, true>>(smem)))
+                return TN_ERR_LAUNCH;
+            const long long need = (groups * a.split + kWaves - 1) / kWaves;
+            const unsigned grid = (unsigned)(need < cap ? (need < 1 ? 1 : need) : cap);
+            if (dense)
+                hipLaunchKernelGGL((main_mfma_rays_kernel<true, true>), dim3(grid), dim3(kBlock), smem, stream, a);
+            else
+                hipLaunchKernelGGL((main_mfma_rays_kernel<false, true>), dim3(grid), dim3(kBlock), smem, stream, a);
+            hipLaunchKernelGGL(segments_combine_kernel, dim3((unsigned)((num_rays + 255) / 256)), dim3(256), 0, stream, a);
+            if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+            return TN_OK;
+        }
+        a.split = 1;
         if (!(dense ? tn_ensure_dynamic_lds<main_mfma_rays_kernel<true>>(smem) : tn_ensure_dynamic_lds<main_mfma_rays_kernel<false>>(smem)))
             return TN_ERR_LAUNCH;
         const long long groups = (num_rays + 63) / 64;

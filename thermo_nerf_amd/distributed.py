@@ -129,7 +129,8 @@ def ray_block(num_rays: int, rank: int, world: int, align: int = 64) -> Tuple[in
 
 
 def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group=None, device: Optional[torch.device] = None,
-                              align: int = 64, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                              align: int = 64, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None,
+                              sample_split="shard") -> Dict[str, Tensor]:
     """``render_frame_sharded`` with EVEN shards (``ray_block``) that still reproduces the single-device frame bit for bit.  The
     one cross-ray quantity — the expected-depth clip to the [min, max] sample mid-point of each ``engine.chunk``-ray chunk of
     the frame — is restored by exchanging the per-chunk bounds: a rank renders the pieces of the chunks its run overlaps
@@ -137,11 +138,19 @@ def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group
     bounds of chunks split between ranks, ``engine.apply_depth_bounds`` clips, and the pixels are all-gathered as before.
     ``nears`` / ``fars`` [H,W,1] (or [H*W]): per-ray planes the bundle already carries, sliced like the origins (absent: the
     engine's collider planes, as in ``RayRenderEngine.render``).
+    ``sample_split``: segments per 64-ray tile of the field pass.  "shard" (default): what suits the size of ONE RANK's run
+    (``engine.shard_sample_split``: an 80 000-ray run is 1 250 tiles on 2 048 wave slots — marched whole it lasts as long as 2 048;
+    in 8 segments each it lasts 5 short rounds), the same value on every rank, and the frame equals
+    ``engine.render(frame, sample_split=k)`` bit for bit; None: the unsharded frame's own choice (1: bit-equal to the default
+    single-device frame); k: forced.
     ``engine``: a RayRenderEngine (or anything with its ``render_shard`` / ``apply_depth_bounds``)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     h, w = origins.shape[:2]
     n = h * w
     r0, r1 = ray_block(n, rank, world, align)
+    if sample_split == "shard":
+        pick = getattr(engine, "shard_sample_split", None)
+        sample_split = pick(ray_block(n, 0, world, align)[1]) if pick is not None else None
     o = origins.reshape(-1, 3)[r0:r1].contiguous()
     d = directions.reshape(-1, 3)[r0:r1].contiguous()
     if device is not None:
@@ -151,6 +160,8 @@ def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group
         if nears is None or fars is None:
             raise ValueError("pass both nears and fars, or neither")
         planes = {"nears": nears.reshape(-1)[r0:r1].contiguous().to(o.device), "fars": fars.reshape(-1)[r0:r1].contiguous().to(o.device)}
+    if sample_split is not None:
+        planes["sample_split"] = int(sample_split)
     local, bounds = engine.render_shard(o, d, r0, n, **planes)
     if world > 1:
         key = torch.stack([bounds[:, 0], -bounds[:, 1]], dim=1).contiguous()

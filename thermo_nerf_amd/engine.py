@@ -122,26 +122,37 @@ class RayRenderEngine:
         L = self.frame_launch_rays(frame_rays)
         return [(max(start, k * L), min(end, (k + 1) * L)) for k in range(start // L, (end - 1) // L + 1)] if end > start else []
 
-    def _forms(self, fld, frame_rays: int, piece_start: int) -> Tuple[int, int]:
-        """(proposal, field) kernel forms of the frame launch that holds ray ``piece_start`` — what ``render`` of the WHOLE frame runs
-        there; the decision is the library's (tn_render_kernel_form), never re-derived here."""
+    def _forms(self, fld, frame_rays: int, piece_start: int, sample_split: Optional[int] = None) -> Tuple[int, int, int]:
+        """(proposal form, field form, sample segments per tile) of the frame launch that holds ray ``piece_start`` — what ``render``
+        of the WHOLE frame runs there; the decisions are the library's (tn_render_kernel_form, tn_render_sample_split), never
+        re-derived here.  ``sample_split``: None = the library's choice for that launch's size, k = forced (capped by the library)."""
         L = self.frame_launch_rays(frame_rays)
         family = KERNEL_FAMILY[self.model.config.kernel_family]
-        if family == 0 and self.num_streams > 1 and frame_rays > L and L >= 49152:
-            # launches overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
-            return 1, 1
         k = piece_start // L
         whole = min((k + 1) * L, frame_rays) - k * L
-        self.rc.kernel_family = family
-        return (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)), int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
+        if family == 0 and self.num_streams > 1 and frame_rays > L and L >= 49152:
+            # launches overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
+            prop = field = 1
+        else:
+            self.rc.kernel_family = family
+            prop, field = (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)),
+                           int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
+        self.rc.kernel_family = field
+        self.rc.sample_split = 0 if sample_split is None else max(int(sample_split), 1)
+        split = int(self.lib.tn_render_sample_split(fld, self.rc, whole))
+        self.rc.sample_split = 0
+        return prop, field, split
 
     @torch.no_grad()
     def render(self, origins: Tensor, directions: Tensor, out: Optional[Dict[str, Tensor]] = None,
-               record_events: bool = False, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> Dict[str, Tensor]:
+               record_events: bool = False, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None,
+               sample_split: Optional[int] = None) -> Dict[str, Tensor]:
         """origins/directions [N,3] resident on the device -> dict of [N,C] tensors (keys = OUTPUT_KEYS).  ``nears`` / ``fars``
         [N] or [N,1]: per-ray planes already set on the bundle are honoured (NS SceneCollider.forward keeps them); absent,
         the model's NearFarCollider fills them.  ``expected_depth`` is clipped to the mid-point range of its CHUNK, exactly
-        like the reference's per-chunk forward: it depends on ``chunk`` (the other outputs do not)."""
+        like the reference's per-chunk forward: it depends on ``chunk`` (the other outputs do not).
+        ``sample_split``: segments per 64-ray tile of the field pass (tn_render_config.sample_split): None = the library's choice
+        for each launch's size (1 for frames: a small call is marched in shorter pieces on more waves), k = that many."""
         o = _hip.require_device_tensor(origins, "origins")
         d = _hip.require_device_tensor(directions, "directions")
         n, dev = o.shape[0], o.device
@@ -185,8 +196,8 @@ class RayRenderEngine:
             if record_events:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record(st)
-            form_prop, form_field = self._forms(fld, n, i)
-            self.rc.kernel_family = form_prop
+            form_prop, form_field, split = self._forms(fld, n, i, sample_split)
+            self.rc.kernel_family, self.rc.sample_split = form_prop, split
             _hip.check(self.lib.tn_proposal_sample_fwd(prop0, prop1, self.rc, ins, outs, r, ws, wsn, stream),
                        "tn_proposal_sample_fwd")
             if record_events:
@@ -201,7 +212,7 @@ class RayRenderEngine:
             if record_events:
                 e2.record(st)
                 self.timings.append((e0, e1, e2))
-        self.rc.kernel_family = family
+        self.rc.kernel_family, self.rc.sample_split = family, 0
         if multi:
             for st in self._streams:
                 current.wait_stream(st)
@@ -210,7 +221,7 @@ class RayRenderEngine:
     @torch.no_grad()
     def render_shard(self, origins: Tensor, directions: Tensor, start: int, frame_rays: int,
                      out: Optional[Dict[str, Tensor]] = None, nears: Optional[Tensor] = None,
-                     fars: Optional[Tensor] = None) -> Tuple[Dict[str, Tensor], Tensor]:
+                     fars: Optional[Tensor] = None, sample_split: Optional[int] = None) -> Tuple[Dict[str, Tensor], Tensor]:
         """Rays [start, start + n) of a row-major frame of ``frame_rays`` rays whose reference chunking is this engine's
         ``chunk`` — a shard that need NOT begin or end on a chunk boundary, only on a multiple of 64 rays
         (distributed.render_frame_sharded_fine).  It is rendered by the launches ``render`` would use for that part of the frame,
@@ -219,7 +230,9 @@ class RayRenderEngine:
         in chunk ``c`` of the frame ((+inf, -inf) for chunks it does not touch).  The caller reduces ``bounds`` over the ranks
         (min / max) and calls ``apply_depth_bounds``.  ``nears`` / ``fars`` [n] or [n,1]: the shard's slice of per-ray planes a
         bundle already carries (as in ``render``); absent, the collider's.  An EMPTY shard (more ranks than 64-ray tiles) is valid
-        wherever it starts.  Returns (outputs [n,C], bounds [chunks of the frame, 2])."""
+        wherever it starts.  ``sample_split``: as in ``render`` — None = what the unsharded frame's launches use (1 for a frame: the
+        shard, however small, then marches whole tiles); k = k segments per tile, bit-equal to ``render(frame, sample_split=k)``
+        (``shard_sample_split`` proposes the k that suits a shard's size).  Returns (outputs [n,C], bounds [chunks of the frame, 2])."""
         if not self.fuse_chunks:
             raise RuntimeError("render_shard needs fuse_chunks (a chunk size that is a multiple of 64 rays)")
         o = _hip.require_device_tensor(origins, "origins")
@@ -267,19 +280,30 @@ class RayRenderEngine:
                 setattr(outs, k, out[k].data_ptr() + 4 * i)
             # the forms the unsharded frame's launch over these rays runs in (frames on both sides of every threshold, both
             # precisions: tests/test_gpu_distributed.py)
-            fam_prop, fam_field = self._forms(fld, frame_rays, p0)
-            self.rc.kernel_family = fam_prop
+            fam_prop, fam_field, split = self._forms(fld, frame_rays, p0, sample_split)
+            self.rc.kernel_family, self.rc.sample_split = fam_prop, split
             _hip.check(self.lib.tn_proposal_sample_fwd(prop0, prop1, self.rc, ins, outs, r, ws, wsn, st.cuda_stream),
                        "tn_proposal_sample_fwd")
             self.rc.kernel_family = fam_field
             _hip.check(self.lib.tn_field_render_chunked_fwd(fld, self.rc, ins, outs, r, ws, wsn, p0, self.chunk,
                                                             bounds.data_ptr() + 8 * (p0 // self.chunk), 0, st.cuda_stream),
                        "tn_field_render_chunked_fwd")
-        self.rc.kernel_family = family  # (the per-launch forms above are not the engine's setting)
+        self.rc.kernel_family, self.rc.sample_split = family, 0  # (the per-launch forms above are not the engine's setting)
         if multi:
             for st in self._streams:
                 current.wait_stream(st)
         return out, bounds
+
+    def shard_sample_split(self, shard_rays: int) -> int:
+        """The segments per tile the library would pick for a lane = ray call of ``shard_rays`` rays (tn_render_sample_split): what a
+        caller that cuts a frame into shards of that size passes as ``sample_split`` to ``render_shard`` — and to ``render`` for the
+        unsharded frame it compares with: the split is a property of the frame, the same on every rank."""
+        _, _, fld = self.model._c_structs()
+        saved = self.rc.kernel_family, self.rc.sample_split
+        self.rc.kernel_family, self.rc.sample_split = 1, 0
+        k = int(self.lib.tn_render_sample_split(fld, self.rc, max(int(shard_rays), 1)))
+        self.rc.kernel_family, self.rc.sample_split = saved
+        return k
 
     def apply_depth_bounds(self, out: Dict[str, Tensor], start: int, bounds: Tensor) -> None:
         """the expected-depth clip of a ``render_shard`` result with the per-chunk bounds reduced over all ranks"""

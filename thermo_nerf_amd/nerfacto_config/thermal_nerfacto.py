@@ -129,6 +129,10 @@ class NerfactoModelConfig:
     kernel_family: Literal["auto", "lane_ray", "ray_per_wave"] = "auto"
     """Which form of the fused kernels a call runs (tn_render_config.kernel_family): "auto" picks by call size (lane = ray —
     one wave owns 64 consecutive rays — from ~60-80 k rays up, one ray per wave below); the other two force a form."""
+    sample_split: int = 0
+    """Sample-split tiles of the exact-fp32 lane = ray field kernel (tn_render_config.sample_split): 0 = the library picks the
+    number of segments a 64-ray tile's sample march is cut into from the call's size (1 from ~400 k rays up; a 65 536-ray chunk: 2),
+    1 = never, k = k segments.  Eval only; same tolerances, other last bits than the serial march (DESIGN §7)."""
     mlp_precision: Literal["f32", "bf16x6", "f16x3"] = "f32"
     """"f32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  Eval-only alternatives on the matrix cores' 16-bit rate, fp32 accumulate:
     "bf16x6" — every fp32 operand as three bf16 pieces (24 bits: an exact split), six piece products per fp32 product, 2^-23

@@ -408,6 +408,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         rc.early_stop_transmittance = 0.0 if training else float(cfg.early_termination_eps)
         rc.kernel_family = KERNEL_FAMILY[cfg.kernel_family]
         rc.initial_sampler = int(self.proposal_sampler.initial_sampler.uniform_spacing)
+        rc.sample_split = int(getattr(cfg, "sample_split", 0))
 
         ins = _hip.tn_render_inputs()
         ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
