@@ -656,14 +656,14 @@ def rccl_info(dist, world, dev):
     return info
 
 
-def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None):
+def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None, hw=None):
     """BASELINE config 4: ONE 1920x1080 camera-path frame, ray-sharded on the reference's chunk boundaries over the ranks and
     all-gathered inside every step (strong scaling).  Returns the JSON fields on rank 0, None elsewhere."""
     from thermo_nerf_amd import distributed as D
     from thermo_nerf_amd import synthetic
 
     S = S or args.samples or 48
-    H_, W_ = args.height or 1080, args.width or 1920
+    H_, W_ = hw or (args.height or 1080, args.width or 1920)
     chunk = args.chunk or REF_CHUNK
     model, cfg, _, engine = build_render(dev, S, chunk, args)
     o3, d3, _ = synthetic.orbit_camera_rays(H_, W_, view=3)
@@ -721,9 +721,10 @@ def measure_sharded_frame(dev, args, world, rank, dist, steps, warmup, S=None):
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "frame_latency_ms": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "config 4: synthetic %dx%d camera-path frame, P=(256,96)+%d samples/ray, chunk %d, shards = "
-                               "even contiguous ray runs cut on multiples of 64 (rays per rank: %s; the chunk-wide depth bounds "
-                               "all-reduced, 2 floats per chunk), all-gather of 36 B/ray in the timed step" % (W_, H_, S, chunk, counts),
+        "config": {"workload": "ONE synthetic %dx%d frame, P=(256,96)+%d samples/ray, chunk %d, shards = "
+                               "even contiguous ray runs cut on multiples of 64 (rays per rank: %s; %s sample segments per tile; the "
+                               "chunk-wide depth bounds all-reduced, 2 floats per chunk), all-gather of 36 B/ray in the timed step" % (
+                                   W_, H_, S, chunk, counts if world <= 2 else "%d x ~%d" % (world, counts[0]), k_split or 1),
                    "rays_per_step": n_rays, "parallelism": "one frame ray-sharded x%d + all_gather" % world},
         "roofline": {"bound": "hbm", "achieved": value * b_all / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                      "frac": value * b_all / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
@@ -966,14 +967,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info = rccl_info(dist, world, dev)
-    strong = None
+    strong = {}
     if world > 1 and not args.no_variants:
-        # the same ranks on ONE frame (BASELINE config 4, strong scaling): a driver that runs `bench.py --gpus N` sees both curves
-        saved = (args.height, args.width, args.chunk)
-        args.height = args.width = None
+        # the same ranks on ONE frame (strong scaling): BASELINE config 4's 1920x1080 x S=48 frame and the metric's own 800x800 x
+        # S=192 frame — a driver that runs `bench.py --gpus N` sees the weak curve (`value`) and both strong ones
+        saved = args.chunk
         args.chunk = 0
-        strong = measure_sharded_frame(dev, args, world, rank, dist, max(3, args.steps // 2), 1, S=48)
-        args.height, args.width, args.chunk = saved
+        strong["strong_frame_1080p_S48"] = measure_sharded_frame(dev, args, world, rank, dist, max(3, args.steps // 2), 1, S=48, hw=(1080, 1920))
+        strong["strong_frame_800_S192"] = measure_sharded_frame(dev, args, world, rank, dist, max(3, args.steps // 2), 1, S=192, hw=(800, 800))
+        args.chunk = saved
 
     if rank == 0:
         value = world * n_rays * args.steps / elapsed
@@ -993,8 +995,8 @@ def main():
             "roofline": roofline_of(S, n_rays, args.steps, prop_ms, main_ms, args.precision, args.no_mfma, value / world),
             "rccl": info,
         }
-        if strong is not None:
-            line["variants"] = {"strong_frame_1080p_S48": strong}
+        if strong:
+            line["variants"] = dict(strong)
         # every GPU measurement first, the CPU oracle last: its torch thread pools (probed up to 128 threads) slow the host side
         # of the 77-launch training step by 30-40 % for the rest of the process (2.65 against 1.83 ms at S=48, same kernels).
         # The GPU frames are sampled now on the rays the baseline will time (a strided sample) and compared afterwards.

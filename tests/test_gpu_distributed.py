@@ -514,3 +514,39 @@ def test_config5_training_replicas_do_not_interact():
             assert rel(params[name], w) <= 0.1, f"scene {scene} {name}: {rel(params[name], w):.2e}"
     moved = [n for n in got[0][0] if got[0][0][n].numel() and rel(got[0][0][n], got[1][0][n]) > 0.3]
     assert "camera_optimizer.pose_adjustment" in moved and "field.mlp_base.encoder.hash_table" in moved, moved
+
+
+def test_bench_two_ranks_prints_one_parseable_line():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), on the gloo backend with
+    both ranks on this box's one GPU (RCCL refuses two ranks per device; TN_BENCH_BACKEND is bench.py's switch for that): the LAST
+    stdout line is the compact record — strict JSON below the limit — with the weak-scaling value, both strong-scaling frames
+    (BASELINE config 4's 1080p x S=48 and the metric's 800x800 x S=192) and the transport record."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    last = lines[-1]
+    assert len(last) <= 4096
+
+    def no_constant(name):
+        raise ValueError(name)
+
+    line = json.loads(last, parse_constant=no_constant)
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["unit"] == "rays/s" and line["value"] > 1e6 and line["dtype"] == "f32"
+    assert line["value"] == pytest.approx(2 * 640000 / (line["ms_per_step"] * 1e-3), rel=1e-3)  # whole-job rays over the slowest rank's time
+    assert line["rccl"]["backend"] == "gloo" and line["rccl"]["world_size"] == 2 and len(line["rccl"]["device_ids"]) == 2
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] == "mfma"
+    for tag in ("strong_frame_1080p_S48", "strong_frame_800_S192"):
+        v = line["variants"][tag]
+        assert v["n_gpus"] == 2 and v["scaling"] == "strong" and v["value"] > 1e6 and v["ms_per_step"] > 0
+    detail = json.loads(lines[-2])["bench_detail"]  # the full tree went out on the line before
+    assert detail["variants"]["strong_frame_800_S192"]["config"]["rays_per_step"] == 640000
