@@ -286,7 +286,7 @@ def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, preci
     form = eng.lib.tn_render_kernel_form(fld, eng.rc, n, 1)
     assert form == (1 if n >= (57344 if precision == "f32" else 40960) else 2)
     assert eng.lib.tn_render_kernel_form(fld, eng.rc, n, 0) == (1 if n >= 81920 else 2)
-    assert eng._forms(fld, n, 0) == (eng.lib.tn_render_kernel_form(None, eng.rc, n, 0), form)
+    assert eng._forms(fld, n, 0)[:2] == (eng.lib.tn_render_kernel_form(None, eng.rc, n, 0), form)
     _shards_against_the_frame(eng, o, d, n, 4)
     assert eng.rc.kernel_family == 0  # render_shard leaves the engine's setting alone
 
@@ -386,7 +386,9 @@ def _fine_worker(rank, world, port, q):
         torch.cuda.synchronize()
         res = {}
         if rank == 0:
-            want = eng.render(o3.reshape(-1, 3).contiguous(), d3.reshape(-1, 3).contiguous())
+            # (the default sample_split="shard": the segments per tile that suit one rank's run — a property of the frame)
+            k = eng.shard_sample_split(D.ray_block(1080 * 1920, 0, world)[1])
+            want = eng.render(o3.reshape(-1, 3).contiguous(), d3.reshape(-1, 3).contiguous(), sample_split=k)
             torch.cuda.synchronize()
             for k in D.OUTPUT_KEYS:
                 res[k] = bool(torch.equal(got[k].reshape(want[k].shape), want[k]))

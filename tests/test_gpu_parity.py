@@ -434,10 +434,10 @@ def test_sample_split_tiles_match_the_oracle_and_the_serial_march(kind, S):
     rc.sample_split = 0
     auto_small, auto_frame = lib.tn_render_sample_split(fld, rc, 399), lib.tn_render_sample_split(fld, rc, 640000)
     assert auto_frame == 1 and auto_small == (cap if cap >= 2 else 1)
-    if S == 192:  # an 80 000-ray shard of the metric's frame: 1 250 tiles -> 8 segments; the reference's 65 536-ray chunk at S = 48: 2
-        assert lib.tn_render_sample_split(fld, rc, 80000) == 8 and lib.tn_render_sample_split(fld, rc, 160000) == 4
-    if S == 48:
-        assert lib.tn_render_sample_split(fld, rc, 65536) == 2
+    if S == 192:  # an 80 000-ray shard of the metric's frame (1 250 tiles on 2 048 wave slots) is marched in pieces
+        assert lib.tn_render_sample_split(fld, rc, 80000) >= 4 and lib.tn_render_sample_split(fld, rc, 160000) >= 4
+    if S == 48:  # ... and so is the reference's 65 536-ray chunk as one call; a 1080p frame is not
+        assert lib.tn_render_sample_split(fld, rc, 65536) >= 2 and lib.tn_render_sample_split(fld, rc, 1080 * 1920) == 1
     rc.training = 1
     assert lib.tn_render_sample_split(fld, rc, 399) == 1
     rc.training, rc.early_stop_transmittance = 0, 1e-3

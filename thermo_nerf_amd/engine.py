@@ -137,9 +137,14 @@ class RayRenderEngine:
             self.rc.kernel_family = family
             prop, field = (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)),
                            int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
+        # segments per tile: ONE value per frame (the rays' bits must not depend on which launch of the frame holds them) — the
+        # library's choice for the frame's launch size L; launches that overlap on several streams fill the chip together: 1
         self.rc.kernel_family = field
-        self.rc.sample_split = 0 if sample_split is None else max(int(sample_split), 1)
-        split = int(self.lib.tn_render_sample_split(fld, self.rc, whole))
+        if sample_split is None:
+            self.rc.sample_split = 1 if (self.num_streams > 1 and frame_rays > L) else 0
+        else:
+            self.rc.sample_split = max(int(sample_split), 1)
+        split = int(self.lib.tn_render_sample_split(fld, self.rc, min(L, frame_rays)))
         self.rc.sample_split = 0
         return prop, field, split
 
