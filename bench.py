@@ -233,6 +233,7 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
     (what rounds 1-3 timed: its samples crowd the same table entries, the scatter's worst case); "random" = pixels drawn
     uniformly over all 8 views of an 800x800 orbit, the way nerfstudio's PixelSampler fills a batch."""
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
+    from thermo_nerf_amd import training as TR
     from thermo_nerf_amd.rays import RayBundle
 
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=samples,  # camera_optimizer_mode = SO3xR3, the reference default
@@ -259,9 +260,9 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
     def step(i):
         model.set_step(i)
         out = model(RayBundle(origins=o, directions=d, camera_indices=cam))
-        loss = sum(model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch)).values())
+        loss = TR.total_loss(model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch)))  # as thermo_nerf_amd.trainer.Trainer does
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        TR.backward_total(loss)
         opt.step()
 
     # (a torch intra-op pool left large by an earlier CPU leg slows the host side of this 77-launch step: timed with the pool at 1)

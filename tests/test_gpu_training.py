@@ -338,6 +338,42 @@ def _gpu_step(gm, o, d, jit, cam, batch):
     return out, loss_dict
 
 
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+def test_total_loss_with_the_unit_seed_equals_sum_and_backward(kind):
+    """training.total_loss + backward_total (one summing node; a cached ones tensor as the seed, which the loss Functions recognise
+    and pass their stored gradients through without the `seed * gradient` launches) against the plain `sum(loss_dict.values())
+    .backward()` of NS Trainer.train_iteration: the same loss and bit-identical gradients of everything but the atomically
+    accumulated tables; a NON-unit seed through the same node scales every gradient."""
+    grads, losses = {}, {}
+    for mode in ("sum", "total", "total_x3"):
+        gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, 48)
+        rb = gm.collider(RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV)))
+        out = TR.get_outputs_train(gm, rb, jitter=torch.cat(jit, dim=1).T.contiguous().to(DEV))
+        b = {k: v.to(DEV) for k, v in batch.items()}
+        loss_dict = gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b))
+        gm.zero_grad(set_to_none=True)
+        if mode == "sum":
+            loss = sum(loss_dict.values())
+            loss.backward()
+        elif mode == "total":
+            loss = TR.total_loss(loss_dict)
+            TR.backward_total(loss)
+        else:
+            loss = TR.total_loss(loss_dict)
+            loss.backward(torch.full((), 3.0, device=DEV))
+        losses[mode] = float(loss)
+        grads[mode] = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+    assert abs(losses["total"] - losses["sum"]) <= 1e-6 * abs(losses["sum"]) and losses["total_x3"] == losses["total"]
+    assert set(grads["total"]) == set(grads["sum"]) == set(grads["total_x3"])
+    for n, g in grads["sum"].items():
+        if n.endswith("hash_table") or "camera_optimizer" in n:  # atomics: the summation order is not reproducible
+            assert rel(grads["total"][n], g) <= 1e-5, n
+        else:
+            assert rel(grads["total"][n], g) <= 1e-6, (n, rel(grads["total"][n], g))
+        if g.norm().item() > 1e-10:
+            assert rel(grads["total_x3"][n], 3.0 * g) <= 1e-5, n
+
+
 ONE_NET = {"one_proposal_network": True}  # helpers.build: use_same_proposal_network + a one-entry proposal_net_args_list
 
 

@@ -125,7 +125,7 @@ class RayRenderEngine:
     def _forms(self, fld, frame_rays: int, piece_start: int, sample_split: Optional[int] = None) -> Tuple[int, int, int]:
         """(proposal form, field form, sample segments per tile) of the frame launch that holds ray ``piece_start`` — what ``render``
         of the WHOLE frame runs there; the decisions are the library's (tn_render_kernel_form, tn_render_sample_split), never
-        re-derived here.  ``sample_split``: None = the library's choice for that launch's size, k = forced (capped by the library)."""
+        re-derived here.  ``sample_split``: None = the library's choice for a call of the frame's size, k = forced (capped by the library)."""
         L = self.frame_launch_rays(frame_rays)
         family = KERNEL_FAMILY[self.model.config.kernel_family]
         k = piece_start // L
@@ -137,15 +137,13 @@ class RayRenderEngine:
             self.rc.kernel_family = family
             prop, field = (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)),
                            int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
-        # segments per tile: ONE value per frame (the rays' bits must not depend on which launch of the frame holds them) — the
-        # library's choice for the frame's launch size L; launches that overlap on several streams fill the chip together: 1
+        # segments per tile: ONE value per frame, whatever launches it is cut into (a ray's bits must not depend on the launch that
+        # holds it, nor on the number of streams): the library's choice for a call of the WHOLE frame's size — 1 for a frame of
+        # 400 k rays or more, several for the small frames whose tiles would leave most wave slots idle
         self.rc.kernel_family = field
-        if sample_split is None:
-            self.rc.sample_split = 1 if (self.num_streams > 1 and frame_rays > L) else 0
-        else:
-            self.rc.sample_split = max(int(sample_split), 1)
-        split = int(self.lib.tn_render_sample_split(fld, self.rc, min(L, frame_rays)))
-        self.rc.sample_split = 0
+        self.rc.sample_split = 0 if sample_split is None else max(int(sample_split), 1)
+        split = int(self.lib.tn_render_sample_split(fld, self.rc, frame_rays))
+        self.rc.kernel_family, self.rc.sample_split = family, 0
         return prop, field, split
 
     @torch.no_grad()
@@ -157,7 +155,8 @@ class RayRenderEngine:
         the model's NearFarCollider fills them.  ``expected_depth`` is clipped to the mid-point range of its CHUNK, exactly
         like the reference's per-chunk forward: it depends on ``chunk`` (the other outputs do not).
         ``sample_split``: segments per 64-ray tile of the field pass (tn_render_config.sample_split): None = the library's choice
-        for each launch's size (1 for frames: a small call is marched in shorter pieces on more waves), k = that many."""
+        for a call of this frame's size (1 from ~500 k rays up; a small frame is marched in shorter pieces on more waves), k = that
+        many.  One value per frame, whatever launches it is cut into."""
         o = _hip.require_device_tensor(origins, "origins")
         d = _hip.require_device_tensor(directions, "directions")
         n, dev = o.shape[0], o.device

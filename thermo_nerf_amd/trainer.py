@@ -20,6 +20,7 @@ from torch import Tensor
 
 from .cameras import Cameras
 from .rays import RayBundle
+from .training import backward_total, total_loss
 
 
 @dataclass
@@ -135,10 +136,12 @@ class Trainer:
         outputs = model(ray_bundle)
         metrics_dict = model.get_metrics_dict(outputs, batch)
         loss_dict = model.get_loss_dict(outputs, batch, metrics_dict)
-        loss = sum(loss_dict.values())
+        # NS Trainer: functools.reduce(torch.add, loss_dict.values()) + loss.backward() — here one summing node and a unit seed
+        # the loss Functions recognise (training.total_loss / backward_total: ~9 fewer launches per step, same numbers)
+        loss = total_loss(loss_dict)
         for opt in self.optimizers.values():
             opt.zero_grad(set_to_none=True)
-        loss.backward()
+        backward_total(loss)
         for name, opt in self.optimizers.items():
             opt.step()
             self.schedulers[name].step()

@@ -873,6 +873,60 @@ def _take_precomputed(dev, which: str, key):
     return result
 
 
+# ---- the step's total loss and its backward seed --------------------------------------------------------------------------------
+# nerfstudio's Trainer sums the loss dictionary with torch.add and calls backward() on the sum; as torch ops that is len - 1 add
+# launches, a ones_like fill for the seed, and — in the loss Functions below, whose gradients are made by the forward launch — one
+# `seed * gradient` launch per loss term: eleven 4-6 us launches per step between the forward and the backward.
+# total_loss() sums the terms in ONE launch; backward_total() seeds the backward with a cached ones tensor that the loss Functions
+# RECOGNISE (same storage): a unit seed needs no multiplication, so their stored gradients pass through untouched.  A plain
+# total.backward() — or any other seed — takes the general path and gives the same numbers.
+_UNIT_SEEDS: Dict = {}
+
+
+def _unit_seed(dev) -> Tensor:
+    t = _UNIT_SEEDS.get(dev)
+    if t is None:
+        t = _UNIT_SEEDS[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
+def _is_unit_seed(g: Optional[Tensor]) -> bool:
+    if g is None or g.dim() != 0:
+        return False
+    t = _UNIT_SEEDS.get(g.device)
+    return t is not None and g.data_ptr() == t.data_ptr()
+
+
+def _seeded(go: Tensor, grad: Tensor) -> Tensor:
+    """go * grad; the stored gradient itself under the unit seed of backward_total()"""
+    return grad if _is_unit_seed(go) else go * grad
+
+
+class _TotalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *terms: Tensor):
+        ctx.n = len(terms)
+        return torch.stack([t.reshape(()) for t in terms]).sum()
+
+    @staticmethod
+    def backward(ctx, go):
+        return (go,) * ctx.n
+
+
+def total_loss(loss_dict: Dict[str, Tensor]) -> Tensor:
+    """The sum of a loss dictionary [NS Trainer.train_iteration: functools.reduce(torch.add, loss_dict.values())] as one
+    autograd node (two launches instead of one per term)."""
+    terms = list(loss_dict.values())
+    if len(terms) == 1:
+        return terms[0]
+    return _TotalLoss.apply(*terms)
+
+
+def backward_total(loss: Tensor) -> None:
+    """loss.backward() with a unit seed the loss Functions recognise (no ones_like fill, no seed * gradient launches)."""
+    torch.autograd.backward(loss, _unit_seed(loss.device))
+
+
 class _Distortion(torch.autograd.Function):
     """apply(weights, spacing_bins, mult) -> (metric, mult * metric): the distortion metric of get_metrics_dict and the loss
     term get_loss_dict makes of it, from one launch; the saved gradient is the TERM's (already scaled by mult)."""
@@ -890,7 +944,7 @@ class _Distortion(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_metric, g_term):
-        out = None if g_term is None else g_term * ctx.g
+        out = None if g_term is None else _seeded(g_term, ctx.g)
         if g_metric is not None:  # someone differentiates the metric itself: its gradient is the term's / mult
             t = (g_metric / ctx.mult) * ctx.g
             out = t if out is None else out + t
@@ -922,7 +976,7 @@ class _Interlevel(torch.autograd.Function):
     def backward(ctx, go):
         out = [None, None, None]
         for g, shape in zip(ctx.g, ctx.shapes):
-            out += [(go * g).view(shape), None]
+            out += [_seeded(go, g).view(shape), None]
         return tuple(out)
 
 
@@ -946,7 +1000,7 @@ class _ImageLosses(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_th, _g_psnr):
-        return (None if g_rgb is None else g_rgb * ctx.d_rgb, None if g_th is None else g_th * ctx.d_th, None, None)
+        return (None if g_rgb is None else _seeded(g_rgb, ctx.d_rgb), None if g_th is None else _seeded(g_th, ctx.d_th), None, None)
 
 
 def image_losses(rgb: Tensor, thermal: Tensor, gt_rgb: Tensor, gt_thermal: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
