@@ -361,7 +361,7 @@ def test_total_loss_with_the_unit_seed_equals_sum_and_backward(kind):
         else:
             loss = TR.total_loss(loss_dict)
             loss.backward(torch.full((), 3.0, device=DEV))
-        losses[mode] = float(loss)
+        losses[mode] = float(loss.detach())
         grads[mode] = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
     assert abs(losses["total"] - losses["sum"]) <= 1e-6 * abs(losses["sum"]) and losses["total_x3"] == losses["total"]
     assert set(grads["total"]) == set(grads["sum"]) == set(grads["total_x3"])
