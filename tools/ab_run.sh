@@ -5,7 +5,7 @@ for so in ab_*.so; do
   THERMONERF_HIP_LIB=$PWD/$so python bench.py --no-variants --no-cpu-baseline --steps 5 --warmup 2 "$@" 2>/dev/null | python -c "
 import json,sys
 for line in sys.stdin:
-    if line.startswith('{'):
+    if line.startswith('{') and 'bench_detail' not in line[:20]:
         d=json.loads(line); r=d['roofline']
         print('$so', 'ms/frame %.3f' % d['ms_per_step'], 'proposal %.3f' % r['proposal_ms'], 'field %.3f' % r['field_ms'], 'frac %.4f' % r['frac'])
 "
