@@ -34,6 +34,9 @@ constexpr int LG = 4;
 #ifndef TN_SPLIT_MLP_PRIO
 #define TN_SPLIT_MLP_PRIO 1
 #endif
+#ifndef TN_BF16_PK_SUB
+#define TN_BF16_PK_SUB 0
+#endif
 #ifndef TN_WAVES32
 #define TN_WAVES32 12
 #endif
@@ -105,11 +108,21 @@ struct BF16x6 {
         const f2 v = {x0, x1};
         const b2 p1 = __builtin_convertvector(v, b2);
         pk[0] = __builtin_bit_cast(unsigned, p1);
-        // (scalar subtractions: as one v_pk_add_f32 per pair the kernel took 23.2 instead of 21.5 ms — aligned register pairs, more spills)
+        // (scalar subtractions: as one v_pk_add_f32 per pair the kernel took 23.2 instead of 21.5 ms in round 4 — aligned register
+        // pairs, more spills — and 21.9 against 21.0 with round 5's pipelined layers: -DTN_BF16_PK_SUB=1)
+#if TN_BF16_PK_SUB
+        const f2 q1 = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u)};
+        const f2 r1 = v - q1;
+        const b2 p2 = __builtin_convertvector(r1, b2);
+        pk[1] = __builtin_bit_cast(unsigned, p2);
+        const f2 q2 = {__uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+        const f2 r2 = r1 - q2;
+#else
         const f2 r1 = {x0 - __uint_as_float(pk[0] << 16), x1 - __uint_as_float(pk[0] & 0xffff0000u)};
         const b2 p2 = __builtin_convertvector(r1, b2);
         pk[1] = __builtin_bit_cast(unsigned, p2);
         const f2 r2 = {r1[0] - __uint_as_float(pk[1] << 16), r1[1] - __uint_as_float(pk[1] & 0xffff0000u)};
+#endif
         pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
     }
     static constexpr int NPROD = 6;  // (0,2) (2,0) (1,1) (0,1) (1,0) (0,0): small terms first
