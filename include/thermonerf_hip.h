@@ -225,9 +225,9 @@ typedef struct tn_render_config {
      * (wave-wide vote).  Skipped samples carry weights < eps each; rgb/thermal/accumulation move by <= eps, the
      * expected depth by <= eps * far.  The reference has no such switch: 0 reproduces it. */
     float early_stop_transmittance;
-    /* 0 = choose by call size (lane = ray from ~60-80 k rays up: a 64-ray tile marches serially and needs >= ~1250 tiles
-     * to fill the chip; one ray per wave below), 1 = lane = ray (a caller that overlaps several calls on different
-     * streams, like RayRenderEngine, fills the chip with fewer rays per call), 2 = one ray per wave. */
+    /* 0 = choose by call size (tn_render_kernel_form: lane = ray — a wavefront marches 64 consecutive rays — from 65 536 rays in
+     * the proposal pass and from 8 192 in the field pass, whose tiles a small call marches in segments (sample_split); one ray
+     * per wave below), 1 = lane = ray, 2 = one ray per wave. */
     int32_t kernel_family;
     /* ProposalNetworkSampler's initial sampler [REF thermal_nerf_model.py:164-170]: 0 = UniformLinDispPiecewiseSampler
      * ("piecewise", the default), 1 = UniformSampler ("uniform").  Every level's spacing -> euclidean map follows it. */
@@ -306,12 +306,14 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
 int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays);
 
 /* Which kernel form a call of num_rays rays takes under cfg->kernel_family (0 = by call size): 1 = lane = ray (a wavefront marches
- * 64 consecutive rays), 2 = one ray per wavefront.  pass 0: tn_proposal_sample_fwd; pass 1: tn_field_render_fwd /
- * tn_field_render_chunked_fwd on `field` (may be NULL = no split-precision blob: those kernels only exist in form 1 and are chosen
- * from a smaller call size; a form-2 call with a split-precision blob runs the exact-fp32 ray-per-wave kernel).  The two forms sum in
- * different orders, so a caller that renders PART of a launch (ray shards of one frame, thermo_nerf_amd/engine.py::render_shard)
- * and wants the whole launch's bits asks for the whole launch's form here and passes it as cfg->kernel_family.  No reference
- * counterpart (the reference has one code path, REF render/renderer.py:182-187); 0 on a NULL cfg. */
+ * 64 consecutive rays), 2 = one ray per wavefront.  pass 0: tn_proposal_sample_fwd (lane = ray from 65 536 rays); pass 1:
+ * tn_field_render_fwd / tn_field_render_chunked_fwd on `field`: lane = ray from 8 192 rays where the exact-fp32 kernel can march
+ * its tiles in segments (sample_split != 1, no early termination, eval), from 40 960 with a split-precision blob (those kernels only
+ * exist in form 1; a form-2 call with such a blob runs the exact-fp32 ray-per-wave kernel), from 57 344 otherwise or with field ==
+ * NULL.  The two forms sum in different orders, so a caller that renders PART of a launch (ray shards of one frame,
+ * thermo_nerf_amd/engine.py::render_shard) and wants the whole launch's bits asks for the whole launch's form here and passes it
+ * as cfg->kernel_family.  No reference counterpart (the reference has one code path, REF render/renderer.py:182-187); 0 on a
+ * NULL cfg. */
 int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass);
 /* The number of sample segments per tile tn_field_render_fwd / _chunked_fwd use for a call of num_rays rays under
  * cfg->sample_split (see there).  Like the kernel form it is a property of the CALL: a caller that renders part of a launch and

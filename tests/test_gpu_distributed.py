@@ -200,7 +200,7 @@ def test_sub_chunk_shards_reproduce_the_unsharded_frame(h, w, chunk, world):
     would render (even runs of rays cut on multiples of 64, NOT on chunk boundaries: 800x800 over 8 ranks = 80 000 rays each
     where whole chunks give 2, 2, 1, 1, 1, 1, 1, 1), their per-chunk depth bounds min/max-reduced as the all-reduce does, against
     the unsharded frame: bit-equal in all seven outputs, expected depth included.  Frame sizes on both sides of the two
-    call-size thresholds of kernel_family="auto" (57 344 / 81 920 rays) and a frame that is one chunk."""
+    call-size thresholds of kernel_family="auto" (tn_render_kernel_form) and a frame that is one chunk."""
     from thermo_nerf_amd import distributed as D
     from thermo_nerf_amd import synthetic
     from thermo_nerf_amd.engine import RayRenderEngine
@@ -268,8 +268,8 @@ def _shards_against_the_frame(eng, o, d, n, world, nears=None, fars=None, sample
 @pytest.mark.parametrize("h,w", [(200, 250), (180, 250), (250, 400)])
 def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, precision):
     """The kernel form of a launch is the LIBRARY's decision (tn_render_kernel_form): with a split-precision blob the field pass
-    runs lane = ray from 40 960 rays per call, with exact fp32 from 57 344, the proposal pass from 81 920 — frames of 45 000,
-    50 000 and 100 000 rays sit between / above them.  A shard (1/4 of the frame: below every threshold) must run the form of
+    runs lane = ray from 40 960 rays per call, with exact fp32 (which marches small calls in segments) from 8 192, the proposal pass
+    from 65 536 — frames of 45 000, 50 000 and 100 000 rays sit between / above them.  A shard (1/4 of the frame: below every threshold) must run the form of
     the unsharded launch, in every precision (the engine used to re-derive the fp32 thresholds in Python)."""
     from thermo_nerf_amd import _hip, synthetic
     from thermo_nerf_amd.engine import RayRenderEngine
@@ -284,8 +284,8 @@ def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, preci
     _, _, fld = model._c_structs()
     eng.rc.kernel_family = 0
     form = eng.lib.tn_render_kernel_form(fld, eng.rc, n, 1)
-    assert form == (1 if n >= (57344 if precision == "f32" else 40960) else 2)
-    assert eng.lib.tn_render_kernel_form(fld, eng.rc, n, 0) == (1 if n >= 81920 else 2)
+    assert form == (1 if n >= (8192 if precision == "f32" else 40960) else 2)
+    assert eng.lib.tn_render_kernel_form(fld, eng.rc, n, 0) == (1 if n >= 65536 else 2)
     assert eng._forms(fld, n, 0)[:2] == (eng.lib.tn_render_kernel_form(None, eng.rc, n, 0), form)
     _shards_against_the_frame(eng, o, d, n, 4)
     assert eng.rc.kernel_family == 0  # render_shard leaves the engine's setting alone

@@ -138,20 +138,29 @@ def test_kernel_form_query_and_the_engine_launch_plan():
     rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = 256, 96, 48
     fld = _hip.tn_thermal_field()
     blob = (ctypes.c_float * 4)()
+    mfma_blob = (ctypes.c_float * 4)()
     for fam in (0, 1, 2):
         rc.kernel_family = fam
-        for n in (1, 40959, 40960, 57343, 57344, 81919, 81920, 1 << 21):
-            want_prop = fam or (1 if n >= 81920 else 2)
-            want_f32 = fam or (1 if n >= 57344 else 2)
-            want_split = fam or (1 if n >= 40960 else 2)
+        for n in (1, 8191, 8192, 40959, 40960, 57343, 57344, 65535, 65536, 1 << 21):
+            want_prop = fam or (1 if n >= 65536 else 2)
+            want_whole_tiles = fam or (1 if n >= 57344 else 2)   # the exact-fp32 kernel where it cannot march in segments
+            want_segments = fam or (1 if n >= 8192 else 2)       # ... and where it can
+            want_split_precision = fam or (1 if n >= 40960 else 2)
             assert lib.tn_render_kernel_form(None, rc, n, 0) == want_prop
-            assert lib.tn_render_kernel_form(None, rc, n, 1) == want_f32
-            fld.prepared_bf16x6 = None
-            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_f32
+            assert lib.tn_render_kernel_form(None, rc, n, 1) == want_whole_tiles
+            fld.prepared, fld.prepared_bf16x6 = None, None
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_whole_tiles
+            fld.prepared = ctypes.addressof(mfma_blob)
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_segments
+            rc.sample_split = 1  # never split: whole tiles
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_whole_tiles
+            rc.sample_split, rc.early_stop_transmittance = 0, 1e-3  # early termination has no segmented form
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_whole_tiles
+            rc.early_stop_transmittance = 0.0
             fld.prepared_bf16x6 = ctypes.addressof(blob)
-            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_split
-            rc.training = 1  # (the split kernels are eval-only)
-            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_f32
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_split_precision
+            rc.training = 1  # (the split-precision and segmented kernels are eval-only)
+            assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_whole_tiles
             rc.training = 0
     assert lib.tn_render_kernel_form(None, None, 100, 0) == 0
     model, _, _ = helpers.build("init", 48)

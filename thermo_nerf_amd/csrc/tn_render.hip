@@ -937,32 +937,44 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
     return field_render_fwd(field, cfg, in, out, num_rays, workspace, workspace_bytes, 0, 0, nullptr, 1, stream);
 }
 
-int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass) {
-    if (!cfg) return 0;
-    if (cfg->kernel_family == 1 || cfg->kernel_family == 2) return cfg->kernel_family;
-    if (pass == 0) return num_rays < 81920 ? 2 : 1;  // proposal pass: 1250 tiles fill the chip (see tn_proposal_sample_fwd)
-    // field pass: the split-precision kernels exist in the lane = ray form only and pay from 640 tiles; the exact-fp32 one from 896
-    const bool split = field && !cfg->training && (field->prepared_bf16x6 || field->prepared_f16x3);
-    return num_rays < (split ? 40960 : 57344) ? 2 : 1;
-}
-
-int32_t tn_render_sample_split(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays) {
-    if (!cfg || !field || num_rays <= 0 || cfg->sample_split == 1) return 1;
-    // only the exact-fp32 lane = ray eval kernel has the segmented form
+// the most sample segments per tile the exact-fp32 lane = ray field kernel can use on this configuration (1 = it cannot split): the
+// records (12 floats per segment) and the per-sample cumulative weights (S floats) of a ray must fit the proposal scratch of the
+// workspace (max(P0, P1) + P1 + 1 floats per ray); a segment is at least 8 samples
+static int sample_split_kmax(const tn_thermal_field *field, const tn_render_config *cfg) {
+    if (!cfg || !field || cfg->sample_split == 1) return 1;
     if (cfg->training || cfg->early_stop_transmittance > 0.0f || !field->prepared || field->prepared_bf16x6 || field->prepared_f16x3) return 1;
-    if (tn_render_kernel_form(field, cfg, num_rays, 1) != 1) return 1;
     const int S = cfg->num_nerf_samples, P0 = cfg->num_proposal_samples[0], P1 = cfg->num_proposal_samples[1];
-    // the records (12 floats per segment) and the per-sample cumulative weights (S floats) of a ray must fit the proposal
-    // scratch of the workspace (max(P0, P1) + P1 + 1 floats per ray); a segment is at least 8 samples
     const int scratch = (P0 > P1 ? P0 : P1) + P1 + 1;
     int kmax = (scratch - S) / 12;
     if (kmax > S / 8) kmax = S / 8;
     if (kmax > 8) kmax = 8;
-    if (kmax < 2) return 1;
+    return kmax < 2 ? 1 : kmax;
+}
+
+int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass) {
+    if (!cfg) return 0;
+    if (cfg->kernel_family == 1 || cfg->kernel_family == 2) return cfg->kernel_family;
+    // measured, tools/small_call_forms.py (profiles/micro/round5_small_call_forms.txt): the proposal pass's lane = ray form has a
+    // floor of 0.6 ms whatever the call and meets the ray-per-wave form at 65 536 rays
+    if (pass == 0) return num_rays < 65536 ? 2 : 1;
+    // field pass: the split-precision kernels exist in the lane = ray form only and pay from 640 tiles; the exact-fp32 kernel marches
+    // a small call's tiles in segments (tn_render_sample_split) and then beats one ray per wave from 8 192 rays (0.50 against
+    // 0.57 ms at S = 192, 0.19 against 0.24 at S = 48; 32 768 rays: 1.61 against 2.15 and 0.43 against 0.76); without segments
+    // (early termination, sample_split = 1) its whole tiles pay from 896
+    const bool split_precision = field && !cfg->training && (field->prepared_bf16x6 || field->prepared_f16x3);
+    const int64_t from = split_precision ? 40960 : (sample_split_kmax(field, cfg) >= 2 ? 8192 : 57344);
+    return num_rays < from ? 2 : 1;
+}
+
+int32_t tn_render_sample_split(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays) {
+    if (!cfg || !field || num_rays <= 0) return 1;
+    const int kmax = sample_split_kmax(field, cfg);  // only the exact-fp32 lane = ray eval kernel has the segmented form
+    if (kmax < 2 || tn_render_kernel_form(field, cfg, num_rays, 1) != 1) return 1;
+    const int S = cfg->num_nerf_samples;
     if (cfg->sample_split > 1) return cfg->sample_split < kmax ? cfg->sample_split : kmax;
     // by call size: a call of T tiles lasts about ceil(k T / 2048) marches of ceil(S / k) samples (+ half a sample's worth of
     // per-segment set-up).  The waves do not run in lock step, so finer pieces also balance better than the round count says
-    // (measured, tools/shard_split_bench.py: 4 050 tiles at S = 48 are two exact rounds, and 4.87 ms whole against 4.51 in 6 segments):
+    // (measured, tools/ab_split.py: 4 050 tiles at S = 48 are two exact rounds, and 4.83 ms whole against 4.53 in 6 segments):
     // the LARGEST k within 5 % of the cheapest.  From four full rounds on (the 800 x 800 frame: 10 000 tiles) the serial march stays.
     const long long slots = 2048, tiles = (num_rays + 63) / 64;
     if (tiles >= 4 * slots) return 1;

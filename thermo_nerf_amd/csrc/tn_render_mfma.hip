@@ -1053,7 +1053,7 @@ int launch_main_mfma(const tn_thermal_field *field, const tn_render_config *cfg,
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
     const long long cap = 256LL * 2;  // 2 resident blocks per CU (LDS 77 KB each)
     // 1.5 ms floor of the tile march vs 0.16 ms at 4096 rays
-    const bool small_call = tn_render_kernel_form(nullptr, cfg, num_rays, 1) == 2;
+    const bool small_call = tn_render_kernel_form(field, cfg, num_rays, 1) == 2;
     if (!cfg->training && !out->weights[2] && !small_call) {
         // eval: lane = ray (64 consecutive rays per wave), coherent gathers
         const bool dense = a.g.num_dense >= kFieldDense;  // the dense variant reads exactly kFieldDense levels densely
