@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic  # noqa: E402
+from thermo_nerf_amd import training as TR  # noqa: E402
 from thermo_nerf_amd.rays import RayBundle  # noqa: E402
 
 
@@ -69,10 +70,10 @@ def main():
         out = model(rb)
         t1 = time.perf_counter()
         metrics = model.get_metrics_dict(out, batch)
-        loss = sum(model.get_loss_dict(out, batch, metrics).values())
+        loss = TR.total_loss(model.get_loss_dict(out, batch, metrics))  # as thermo_nerf_amd.trainer.Trainer does
         t2 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        TR.backward_total(loss)
         t3 = time.perf_counter()
         if not a.no_opt:
             opt.step()
