@@ -79,8 +79,9 @@ class RayRenderEngine:
         if self._ws is None or self._ws.shape[1] < need or self._ws.shape[0] < slots or self._ws.device != dev:
             self._ws = None  # (release before growing: two generations of a GB-sized workspace need not coexist)
             self._ws = torch.empty((slots, need), dtype=torch.uint8, device=dev)
-        if len(self._streams) < self.num_streams or (self._streams and self._streams[0].device != self._ws.device):
-            # streams on distinct hardware queues (two pool streams may share one and run their launches back to back)
+        if slots > 1 and (len(self._streams) < self.num_streams or self._streams[0].device != self._ws.device):
+            # (only a frame of several launches needs them) streams on distinct hardware queues: two pool streams may share one
+            # and run their launches back to back
             self._streams = _hip.concurrent_streams(dev, self.num_streams)
         self._ws_rays = max(self._ws_rays, rays)
         # NS NearFarCollider in eval: near plane reset to 0; keyed on the planes, so a collider edited after

@@ -42,13 +42,28 @@ def step(i):
 for i in range(30):
     step(5000 + i)
 torch.cuda.synchronize()
+# the autograd engine runs Function.backward on its own device thread: a second profiler, switched on inside RenderTrain.backward
+bw = cProfile.Profile()
+_orig = TR.RenderTrain.backward
+
+
+def _profiled_backward(ctx, *grads):
+    bw.enable()
+    try:
+        return _orig(ctx, *grads)
+    finally:
+        bw.disable()
+
+
+TR.RenderTrain.backward = staticmethod(_profiled_backward)
 pr = cProfile.Profile()
 pr.enable()
 for i in range(steps):
     step(5030 + i)
 pr.disable()
 torch.cuda.synchronize()
-for key in ("cumulative", "tottime"):
-    buf = io.StringIO()
-    pstats.Stats(pr, stream=buf).sort_stats(key).print_stats(45)
-    print(buf.getvalue().replace(ROOT + "/", ""))
+for prof, n in ((pr, 30), (bw, 60)):
+    for key in ("cumulative", "tottime"):
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats(key).print_stats(n)
+        print(buf.getvalue().replace(ROOT + "/", ""))
