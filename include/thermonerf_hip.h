@@ -344,6 +344,15 @@ int tn_field_prepare_f16x3(const tn_thermal_field *field, void *prepared_dev, si
 size_t tn_field_prepare_bf16x6_bytes(const tn_thermal_field *field);
 int tn_field_prepare_bf16x6(const tn_thermal_field *field, void *prepared_dev, size_t bytes, void *stream);
 
+/* The operand split of mlp_precision = "bf16x6" on its own (test surface; no reference counterpart): per element i the three bf16
+ * pieces of a[i] and b[i] — p1 = bf16(x), p2 = bf16(x - p1), p3 = bf16(x - p1 - p2), round to nearest even — written as floats to
+ * pieces_a / pieces_b [n,3], and out[i] = the six piece products of order <= 2 accumulated in fp32 in the field kernel's order.
+ * x = p1 + p2 + p3 exactly while p3 is representable (|x| >= 2^-110: its exponent is >= 2^-133, bf16's smallest sub-normal). */
+int tn_bf16x6_split_product(const float *a, const float *b, int64_t n, float *pieces_a, float *pieces_b, float *out, void *stream);
+/* One v_mfma_f32_32x32x16_bf16 with constant operands bf16(a_value), bf16(b_value): out[0] = 16 a b (fp32) — what the matrix core
+ * does with sub-normal bf16 inputs (test surface). */
+int tn_bf16_mfma_value_probe(float a_value, float b_value, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Training step: forward with a tape of per-sample activations, losses, backward.
  * The reference gets all of this from torch autograd over nerfstudio's modules

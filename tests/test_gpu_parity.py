@@ -446,6 +446,76 @@ def test_sample_split_tiles_match_the_oracle_and_the_serial_march(kind, S):
     assert lib.tn_render_sample_split(fld, rc, 399) == 1
 
 
+def test_bf16x6_split_is_exact_and_its_six_products_are_an_fp32_product():
+    """The operand split of mlp_precision="bf16x6" on its own (tn_bf16x6_split_product = the field kernel's BF16x6::split and
+    product list): 1e6 random fp32 pairs over 60 binades + edge cases (powers of two, values on bf16 rounding boundaries, fp32
+    sub-normals, the largest magnitudes).  (1) every piece is a bf16 value and a = p1 + p2 + p3 EXACTLY for 2^-110 <= |a| <=
+    (2 - 2^-8) 2^127 (above it bf16(a) rounds to infinity; below it the third piece falls under bf16's smallest sub-normal and the
+    sum is off by < 2^-133); (2) round to nearest leaves |p2| <= 2^-8 |a| and |p3| <= 2^-16 |a|; (3) the six products, accumulated
+    in fp32, are within 2.5 x 2^-23 of the fp64 product (dropped terms <= (2 + 2^-8) 2^-24, plus five fp32 additions)."""
+    lib = _hip.load()
+    g = torch.Generator().manual_seed(11)
+    n = 1_000_000
+    def rnd():
+        mant = 1.0 + torch.rand(n, generator=g, dtype=torch.float64)
+        expo = torch.randint(-30, 31, (n,), generator=g).double()
+        sign = torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0).double()
+        return (sign * mant * torch.pow(torch.tensor(2.0, dtype=torch.float64), expo)).float()
+    a, b = rnd(), rnd()
+    edge = torch.tensor([1.0, -1.0, 2.0 ** -20, 2.0 ** 40, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -7 + 2.0 ** -8, 1.0 + 2.0 ** -23,
+                         0.99609375, 3.0, 2.0 ** -100, 2.0 ** -109, 2.0 ** -110 * 1.9999999, 3.38e38, -3.39e38, 0.0, -0.0])
+    a[: edge.numel()] = edge
+    b[: edge.numel()] = edge.flip(0)
+    ad, bd = a.to(DEV), b.to(DEV)
+    pa, pb = torch.empty((n, 3), device=DEV), torch.empty((n, 3), device=DEV)
+    out = torch.empty(n, device=DEV)
+    _hip.check(lib.tn_bf16x6_split_product(ad.data_ptr(), bd.data_ptr(), n, pa.data_ptr(), pb.data_ptr(), out.data_ptr(), _hip.current_stream()),
+               "tn_bf16x6_split_product")
+    torch.cuda.synchronize()
+    pa, pb, out = pa.cpu(), pb.cpu(), out.cpu()
+    for x, p in ((a, pa), (b, pb)):
+        assert torch.equal(p.to(torch.bfloat16).float(), p), "a piece is not a bf16 value"
+        assert torch.equal(p.double().sum(dim=1), x.double()), "the three pieces do not add up to the operand exactly"
+        mag = x.abs().double()
+        assert (p[:, 1].abs().double() <= mag * 2.0 ** -8).all() and (p[:, 2].abs().double() <= mag * 2.0 ** -16).all()
+    want = a.double() * b.double()
+    ok = want.abs() > 0
+    rel = ((out.double() - want).abs() / want.abs().clamp_min(1e-300))[ok]
+    print(f"bf16x6 six-product sum vs the fp64 product: max rel {rel.max().item():.3e} = {rel.max().item() * 2 ** 23:.2f} x 2^-23, mean {rel.mean().item():.2e}")
+    assert rel.max().item() <= 2.5 * 2.0 ** -23
+    # the range: below 2^-110 the third piece is lost (an absolute error under 2^-133), fp32 sub-normals split like any value
+    tiny = torch.tensor([2.0 ** -111, 3.0 * 2.0 ** -120, 2.0 ** -126, 1.1754942e-38, 1.4e-45, 7.1e-40], dtype=torch.float32)
+    td = tiny.to(DEV)
+    pt, po = torch.empty((tiny.numel(), 3), device=DEV), torch.empty(tiny.numel(), device=DEV)
+    ones = torch.ones_like(td)
+    p1 = torch.empty((tiny.numel(), 3), device=DEV)
+    _hip.check(lib.tn_bf16x6_split_product(td.data_ptr(), ones.data_ptr(), tiny.numel(), pt.data_ptr(), p1.data_ptr(), po.data_ptr(),
+                                           _hip.current_stream()), "tn_bf16x6_split_product")
+    torch.cuda.synchronize()
+    err = (pt.cpu().double().sum(dim=1) - tiny.double()).abs()
+    assert (err <= 2.0 ** -133).all(), err
+    # the largest magnitudes: bf16(x) is infinite above (2 - 2^-8) 2^127 — the split's upper limit (the field's activations are O(1))
+    big = torch.tensor([3.3895e38, 3.40e38], dtype=torch.float32).to(DEV)
+    pbig, o2 = torch.empty((2, 3), device=DEV), torch.empty(2, device=DEV)
+    pone = torch.empty((2, 3), device=DEV)
+    _hip.check(lib.tn_bf16x6_split_product(big.data_ptr(), torch.ones(2, device=DEV).data_ptr(), 2, pbig.data_ptr(), pone.data_ptr(),
+                                           o2.data_ptr(), _hip.current_stream()), "tn_bf16x6_split_product")
+    torch.cuda.synchronize()
+    assert torch.isfinite(pbig[0]).all() and float(pbig[0].double().sum()) == float(big[0].double())
+    assert torch.isinf(pbig[1, 0])
+
+
+def test_bf16_mfma_takes_subnormal_inputs_as_they_are():
+    """What the header's range note rests on: v_mfma_f32_32x32x16_bf16 does not flush sub-normal bf16 INPUTS (pieces of operands
+    below 2^-110 ... 2^-126 are sub-normal bf16 values): A = 2^-130 (a bf16 sub-normal), B = 2^100 -> 16 x 2^-30."""
+    lib = _hip.load()
+    out = torch.zeros(4, device=DEV)
+    for av, bv, want in ((2.0 ** -130, 2.0 ** 100, 16 * 2.0 ** -30), (2.0 ** -133, 2.0 ** 120, 16 * 2.0 ** -13), (1.5, 2.0, 48.0)):
+        _hip.check(lib.tn_bf16_mfma_value_probe(av, bv, out.data_ptr(), _hip.current_stream()), "tn_bf16_mfma_value_probe")
+        torch.cuda.synchronize()
+        assert float(out[0]) == want, (av, bv, float(out[0]), want)
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("kind", ["init", "stress", "scene"])
 @pytest.mark.parametrize("S", [48, 64, 192])

@@ -181,6 +181,8 @@ SIGNATURES = {
         [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), C.POINTER(tn_render_inputs),
          C.POINTER(tn_render_outputs), _i64, _vp, _sz, _vp],
     ),
+    "tn_bf16x6_split_product": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tn_bf16_mfma_value_probe": (C.c_int, [C.c_float, C.c_float, _vp, _vp]),
     "tn_depth_bound_slots": (_i64, [_i64, _i64, _i64]),
     "tn_render_kernel_form": (C.c_int32, [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), _i64, C.c_int32]),
     "tn_render_sample_split": (C.c_int32, [C.POINTER(tn_thermal_field), C.POINTER(tn_render_config), _i64]),

@@ -1053,6 +1053,40 @@ __global__ void __launch_bounds__(kWaves32 * 64, 1) main_split_rays32_kernel(H3A
 
 #endif  // TN_SPLIT_WAVE32
 
+// ---- the split itself, exposed for its unit test (tn_bf16x6_split_product) ---------------------------------------------------------
+// per element: the three bf16 pieces of a and of b (as floats) and the six-product sum p1q3 + p3q1 + p2q2 + p1q2 + p2q1 + p1q1
+// accumulated in fp32 in the kernel's order (every product is exact in fp32: 8 x 8 significand bits)
+__global__ void bf16x6_split_product_kernel(const float *a, const float *b, long long n, float *pieces_a, float *pieces_b, float *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    __bf16 pa[3], pb[3];
+    BF16x6::split(a[i], pa);
+    BF16x6::split(b[i], pb);
+    float fa[3], fb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        fa[k] = (float)pa[k];
+        fb[k] = (float)pb[k];
+        pieces_a[3 * i + k] = fa[k];
+        pieces_b[3 * i + k] = fb[k];
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < BF16x6::NPROD; ++j) acc = add_rn(acc, mul_rn(fa[BF16x6::ka(j)], fb[BF16x6::kb(j)]));
+    out[i] = acc;
+}
+// one v_mfma_f32_32x32x16_bf16 whose A operand is the constant `av` and whose B operand is the constant `bv` (both rounded to
+// bf16): out[0] = 16 av bv if the matrix core takes sub-normal bf16 inputs as they are, 0 if it flushes them
+__global__ void bf16_mfma_value_probe_kernel(float av, float bv, float *out) {
+    const __bf16 x = (__bf16)av, y = (__bf16)bv;
+    const v8bf a = {x, x, x, x, x, x, x, x}, b = {y, y, y, y, y, y, y, y};
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
 inline bool h3_supported(const tn_thermal_field *f) {
     return f && f->geo_feat_dim == GF && f->app_dim == APP && f->grid.num_levels == L16;
 }
@@ -1162,6 +1196,23 @@ size_t tn_field_prepare_bf16x6_bytes(const tn_thermal_field *field) {
 
 int tn_field_prepare_bf16x6(const tn_thermal_field *f, void *prepared_dev, size_t bytes, void *stream) {
     return tn::field_prepare_split<BF16x6>(f, prepared_dev, bytes, stream);
+}
+
+int tn_bf16x6_split_product(const float *a, const float *b, int64_t n, float *pieces_a, float *pieces_b, float *out, void *stream) {
+    if (n == 0) return TN_OK;
+    if (!a || !b || !pieces_a || !pieces_b || !out) return TN_ERR_NULL;
+    if (n < 0) return TN_ERR_SHAPE;
+    hipLaunchKernelGGL(bf16x6_split_product_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       (long long)n, pieces_a, pieces_b, out);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
+}
+
+int tn_bf16_mfma_value_probe(float a_value, float b_value, float *out, void *stream) {
+    if (!out) return TN_ERR_NULL;
+    hipLaunchKernelGGL(bf16_mfma_value_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a_value, b_value, out);
+    if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+    return TN_OK;
 }
 
 }  // extern "C"
