@@ -453,7 +453,9 @@ def test_training_step_at_config3_sizes_matches_autograd_oracle():
         if name.endswith("hash_table"):  # the same entries touched: 256 rays reach a small part of a full-size table
             touched = gw != 0
             assert 0 < int(touched.sum()) < gw.numel() // 4
-            assert float(gg.cpu()[~touched].abs().max()) == 0.0, name
+            # (entries where the oracle's contributions cancel to an exact zero may hold rounding residue here: 1e-12 against 1e-5)
+            assert float(gg.cpu()[~touched].abs().max()) <= 1e-6 * float(gw.abs().max()), name
+            assert int((gg.cpu()[~touched] != 0).sum()) <= 64, name
         checked += 1
     assert checked >= 18
 
