@@ -325,7 +325,25 @@ __device__ __forceinline__ void dense_gather(const G &g, int l, const HashTaps &
 __device__ __forceinline__ void hash_hold(HashTaps &t) {
     asm volatile("" : "+v"(t.ox), "+v"(t.oy), "+v"(t.oz)::"memory");
 }
+#ifndef TN_BLEND_PACKED
+// 1: the trilinear blend's two features per corner as packed fp32 (14 v_pk_add + v_pk_fma pairs per level instead of 28 scalar
+// pairs).  Measured (round 5, tools/ab_run.sh, two repeats): field kernel 30.42 against 30.36 ms (256 registers, 44 B of scratch),
+// proposal kernel 2.84 against 2.87 ms: off.
+#define TN_BLEND_PACKED 0
+#endif
 __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f)[8]) {
+#if TN_BLEND_PACKED
+    // both features of a corner in one packed instruction (v_pk_add_f32 + v_pk_fma_f32 per lerp instead of 2 + 2): the same
+    // roundings, bit for bit; the corner pairs arrive as aligned register pairs from the 8-byte gathers
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    auto L = [](v2 a, v2 b, float o) { return __builtin_elementwise_fma(v2{o, o}, a - b, b); };
+    auto V = [](const float2 &x) { return v2{x.x, x.y}; };
+    const v2 f03 = L(V(f[0]), V(f[3]), t.ox), f12 = L(V(f[1]), V(f[2]), t.ox);
+    const v2 f56 = L(V(f[5]), V(f[6]), t.ox), f47 = L(V(f[4]), V(f[7]), t.ox);
+    const v2 f0312 = L(f03, f12, t.oy), f4756 = L(f47, f56, t.oy);
+    const v2 r = L(f0312, f4756, t.oz);
+    return make_float2(r[0], r[1]);
+#else
     float2 r;
     {
         const float f03 = lerp_t<true>(f[0].x, f[3].x, t.ox), f12 = lerp_t<true>(f[1].x, f[2].x, t.ox);
@@ -340,6 +358,7 @@ __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f
         r.y = lerp_t<true>(f0312, f4756, t.oz);
     }
     return r;
+#endif
 }
 
 // NL hashed levels of one position (FAST flavour), software-pipelined over groups of LG levels: the 8*LG gathers of group
