@@ -446,6 +446,35 @@ def test_sample_split_tiles_match_the_oracle_and_the_serial_march(kind, S):
     assert lib.tn_render_sample_split(fld, rc, 399) == 1
 
 
+@pytest.mark.parametrize("dense_mb", [64, 0])
+def test_proposal_pass_in_density_segments_gives_the_one_launch_kernels_bits(dense_mb):
+    """Calls under 4 096 tiles run the lane = ray proposal pass as four launches (density segments per (tile, segment), scans + PDF
+    walks per tile: proposal_density_segments_kernel / proposal_resample_kernel); larger calls run proposal_rays_kernel.  The
+    weights are formed in sample order in both, so the resampled edges — and with them EVERY output — are the same bits: the
+    first 100 032 rays of a 262 208-ray call (4 097 tiles: one launch) against those rays as a call of their own (1 563 tiles:
+    segments), dense and hashed proposal grids, the field pass held to whole tiles on both sides."""
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    gm, sd, ocfg = gpu_model("scene", 48, small=False, family="lane_ray")
+    gm.config.dense_grid_budget_mb = dense_mb
+    gm.invalidate_prepared()
+    o3, d3, _ = synthetic.orbit_camera_rays(512, 513, view=2)
+    n_big, n_small = 4097 * 64, 1563 * 64
+    o, d = o3.reshape(-1, 3)[:n_big].contiguous().to(DEV), d3.reshape(-1, 3)[:n_big].contiguous().to(DEV)
+    eng = RayRenderEngine(gm, chunk=n_big)
+    big = {k: v.clone() for k, v in eng.render(o, d, sample_split=1).items()}
+    eng_s = RayRenderEngine(gm, chunk=n_small)
+    small = eng_s.render(o[:n_small].contiguous(), d[:n_small].contiguous(), sample_split=1)
+    torch.cuda.synchronize()
+    for k in ("rgb", "thermal", "accumulation", "depth", "prop_depth_0", "prop_depth_1"):
+        assert torch.equal(small[k], big[k][:n_small]), (k, (small[k] - big[k][:n_small]).abs().max().item())
+    # and a ragged call (the last tile partly idle)
+    rag = eng_s.render(o[:70001].contiguous(), d[:70001].contiguous(), sample_split=1)
+    torch.cuda.synchronize()
+    for k in ("rgb", "depth", "prop_depth_0", "prop_depth_1"):
+        assert torch.equal(rag[k], big[k][:70001]), k
+
+
 def test_bf16x6_split_is_exact_and_its_six_products_are_an_fp32_product():
     """The operand split of mlp_precision="bf16x6" on its own (tn_bf16x6_split_product = the field kernel's BF16x6::split and
     product list): 1e6 random fp32 pairs over 60 binades + edge cases (powers of two, values on bf16 rounding boundaries, fp32

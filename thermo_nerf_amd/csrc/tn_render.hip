@@ -18,6 +18,9 @@
 #ifndef TN_PROP_WAVES
 #define TN_PROP_WAVES 4   // waves per SIMD of proposal_rays_kernel (= workgroups per CU)
 #endif
+#ifndef TN_PROP_SPLIT
+#define TN_PROP_SPLIT 1  // calls under 4 096 tiles: the lane = ray proposal pass as density segments + per-tile resampling (same bits)
+#endif
 #ifndef TN_PROP_GROUPS
 #define TN_PROP_GROUPS 32  // levels per gather stage of the lean proposal density: 3 + 2 (32) or 2 + 2 + 1 (221)
 #endif
@@ -575,6 +578,125 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_rays_kernel(Pr
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The lane = ray proposal pass for calls that do not fill the chip (round 5): the SAME arithmetic in four launches.
+// proposal_rays_kernel marches a tile's 256 + 96 samples on one wave, so a call lasts one whole march (0.6 ms) however few tiles it
+// has: an 80 000-ray shard (1 250 tiles on 4 096 wave slots) pays 0.75 ms where its share of a frame is 0.36.  What is serial in a
+// level is only the transmittance scan and the PDF walk; the density evaluations — the gathers and the MLP — are independent per
+// sample.  So:  (1) proposal_density_segments_kernel<., 0>: (tile, segment) virtual tiles evaluate delta x density of level 0 into the
+// scratch; (2) proposal_resample_kernel<0>: one wave per tile turns them into weights IN SAMPLE ORDER (the running optical depth is
+// the same sum in the same order: weights, median, total and therefore the resampled edges are those of proposal_rays_kernel bit for
+// bit), walks the PDF and leaves the 97 edges; (3) + (4) the same for level 1 -> the final S + 1 edges.  LEAN configuration only
+// (the eval default: no jitter, piecewise spacing, anneal 1, contraction, 5-level nets, no per-level outputs).
+// ------------------------------------------------------------------------------------------------------
+struct PropSplitArgs {
+    PropRaysArgs ra;
+    int k[2], len[2];  // segments per tile and samples per segment, per level
+};
+
+template <int ND, int LEVEL>
+__global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_density_segments_kernel(PropSplitArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const PropRaysArgs &ra = sa.ra;
+    const PropArgs &a = ra.p;
+    const int P0 = a.P0, P1 = a.P1;
+    const int n = LEVEL == 0 ? P0 : P1, K = sa.k[LEVEL], len = sa.len[LEVEL];
+    float *lin0 = smem;  // [P0+1] (level 0)
+    if (LEVEL == 0) {
+        for (int i = threadIdx.x; i <= P0; i += blockDim.x) lin0[i] = a.lin0[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Space sp = make_space(a.net[LEVEL].space);
+    sp.contraction = 1;
+    const long long tiles = (a.R + 63) >> 6, vtiles = tiles * K;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long vt = (long long)blockIdx.x * kWaves + wave; vt < vtiles; vt += stride) {
+        const long long tile = vt / K;
+        const int s0 = (int)(vt - tile * K) * len, s1 = s0 + len < n ? s0 + len : n;
+        const long long r = tile * 64 + lane;
+        const long long rc = r < a.R ? r : a.R - 1;
+        const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
+        const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
+        const float s_near = spacing_fn(a.nears[rc], false), s_far = spacing_fn(a.fars[rc], false);
+        float *wsc = ra.w_scratch + (size_t)tile * ra.nmax * 64 + lane;
+        const float *b1sc = ra.b1_scratch + (size_t)tile * (P1 + 1) * 64 + lane;
+        auto edge = [&](int j) -> float { return LEVEL == 0 ? lin0[j] : b1sc[(size_t)j * 64]; };
+        float en = spacing_to_eucl<true>(edge(s0), s_near, s_far, false);
+        for (int i = s0; i < s1; ++i) {
+            const float st = en;
+            en = spacing_to_eucl<true>(edge(i + 1), s_near, s_far, false);
+            float px, py, pz;
+            const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
+                                                       frustum_pos(oz, dz, st, en), px, py, pz);
+            const float dens = proposal_density_kmajor<true, ND>(a.net[LEVEL].g, as_scalar(a.wk + LEVEL * kPropWFloats), a.net[LEVEL].avg,
+                                                                 px, py, pz, sel);
+            wsc[(size_t)i * 64] = mul_rn(sub_rn(en, st), dens);
+        }
+    }
+}
+
+template <int LEVEL>
+__global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_resample_kernel(PropSplitArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const PropRaysArgs &ra = sa.ra;
+    const PropArgs &a = ra.p;
+    const int P0 = a.P0, P1 = a.P1, S = a.S;
+    const int n = LEVEL == 0 ? P0 : P1, n_out = LEVEL == 0 ? P1 : S;
+    float *lin0 = smem;          // [P0+1] (level 0)
+    float *u = smem + (P0 + 1);  // [n_out+1]
+    if (LEVEL == 0)
+        for (int i = threadIdx.x; i <= P0; i += blockDim.x) lin0[i] = a.lin0[i];
+    for (int i = threadIdx.x; i <= n_out; i += blockDim.x) u[i] = (LEVEL == 0 ? a.u1 : a.u2)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tiles = (a.R + 63) >> 6;
+    const long long stride = (long long)gridDim.x * kWaves;
+    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < tiles; tile += stride) {
+        const long long r = tile * 64 + lane;
+        const bool live = r < a.R;
+        const long long rc = live ? r : a.R - 1;
+        float *wsc = ra.w_scratch + (size_t)tile * ra.nmax * 64 + lane;
+        float *b1sc = ra.b1_scratch + (size_t)tile * (P1 + 1) * 64 + lane;
+        float *fin = a.ws_spacing + tn_ws_bin(tile * 64, 0, S) + lane;
+        auto edge = [&](int j) -> float { return LEVEL == 0 ? lin0[j] : b1sc[(size_t)j * 64]; };
+        // get_weights in sample order: the sums of proposal_rays_kernel, term for term
+        float accum = 0.0f, cum_w = 0.0f, total = 0.0f;
+        int med_idx = n - 1;
+        bool found = false;
+        constexpr int WB = 8;
+        for (int i0 = 0; i0 < n; i0 += WB) {
+            float dv[WB];
+#pragma unroll
+            for (int k = 0; k < WB; ++k) dv[k] = wsc[(size_t)(i0 + k < n ? i0 + k : n - 1) * 64];
+#pragma unroll
+            for (int k = 0; k < WB; ++k) {
+                if (i0 + k >= n) break;
+                const float dd = dv[k];
+                const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
+                accum += dd;
+                cum_w += wi;
+                if (!found && cum_w >= 0.5f) {
+                    found = true;
+                    med_idx = i0 + k;
+                }
+                wsc[(size_t)(i0 + k) * 64] = wi;
+                total += add_rn(wi, 0.01f);
+            }
+        }
+        if (LEVEL == 0)
+            pdf_walk(wsc, n, total, 1.0f, u, false, 0.0f, n_out, edge, [&](int j, float v) { b1sc[(size_t)j * 64] = v; });
+        else
+            pdf_walk(wsc, n, total, 1.0f, u, false, 0.0f, n_out, edge, [&](int j, float v) { fin[(size_t)j * 64] = v; });
+        if (live && a.prop_depth[LEVEL]) {  // the median's mid-point, from the level's own edges (read before level 1 overwrites none of them)
+            const float s_near = spacing_fn(a.nears[rc], false), s_far = spacing_fn(a.fars[rc], false);
+            const float st = spacing_to_eucl<true>(edge(med_idx), s_near, s_far, false);
+            const float en = spacing_to_eucl<true>(edge(med_idx + 1), s_near, s_far, false);
+            a.prop_depth[LEVEL][r] = add_rn(st, en) / 2.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // main field + composite, lane per sample (reference form)
 // ------------------------------------------------------------------------------------------------------
 struct MainArgs {
@@ -838,6 +960,40 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
         bool lean = five && !pa.jitter && !pa.lin && pa.anneal == 1.0f && pa.net[0].space.contraction && pa.net[1].space.contraction &&
                     !pa.out_w[0] && !pa.out_w[1];
         for (int i = 0; i < 3; ++i) lean = lean && !pa.out_spacing[i] && !pa.out_eucl[i];
+        // calls that leave most wave slots idle: density evaluations as (tile, segment) virtual tiles, scans + PDF walks per tile — the
+        // same edges bit for bit (see proposal_density_segments_kernel); from 4 096 tiles on the one-launch form
+        constexpr long long kSlots = 256LL * TN_PROP_WAVES * kWaves;
+        if (TN_PROP_SPLIT && lean && five && (long long)tiles < kSlots && ((nd0 == 5 && nd1 == 4) || (nd0 == 0 && nd1 == 0)) && P0 >= 64 &&
+            P1 >= 32) {
+            PropSplitArgs sa;
+            sa.ra = ra;
+            const int counts[2] = {P0, P1}, kcap[2] = {8, 4};
+            for (int l = 0; l < 2; ++l) {
+                long long k = (3 * kSlots + (long long)tiles - 1) / (long long)tiles;  // ~three rounds of virtual tiles
+                if (k > kcap[l]) k = kcap[l];
+                if (k < 1) k = 1;
+                sa.len[l] = (int)((counts[l] + k - 1) / k);
+                sa.k[l] = (counts[l] + sa.len[l] - 1) / sa.len[l];
+            }
+            auto blocks = [&](long long units) {
+                const long long nb = (units + kWaves - 1) / kWaves;
+                return dim3((unsigned)(nb < kMaxGrid ? (nb < 1 ? 1 : nb) : kMaxGrid));
+            };
+            const size_t lds0 = (size_t)(P0 + 1) * sizeof(float);
+            const size_t ldsr0 = (size_t)(P0 + 1 + P1 + 1) * sizeof(float), ldsr1 = (size_t)(P0 + 1 + S + 1) * sizeof(float);
+            if (nd0 == 5) {
+                hipLaunchKernelGGL((proposal_density_segments_kernel<5, 0>), blocks((long long)tiles * sa.k[0]), dim3(kBlock), lds0, s, sa);
+                hipLaunchKernelGGL(proposal_resample_kernel<0>, blocks((long long)tiles), dim3(kBlock), ldsr0, s, sa);
+                hipLaunchKernelGGL((proposal_density_segments_kernel<4, 1>), blocks((long long)tiles * sa.k[1]), dim3(kBlock), 0, s, sa);
+            } else {
+                hipLaunchKernelGGL((proposal_density_segments_kernel<0, 0>), blocks((long long)tiles * sa.k[0]), dim3(kBlock), lds0, s, sa);
+                hipLaunchKernelGGL(proposal_resample_kernel<0>, blocks((long long)tiles), dim3(kBlock), ldsr0, s, sa);
+                hipLaunchKernelGGL((proposal_density_segments_kernel<0, 1>), blocks((long long)tiles * sa.k[1]), dim3(kBlock), 0, s, sa);
+            }
+            hipLaunchKernelGGL(proposal_resample_kernel<1>, blocks((long long)tiles), dim3(kBlock), ldsr1, s, sa);
+            TN_LAUNCH_CHECK();
+            return TN_OK;
+        }
         if (five && nd0 == 5 && nd1 == 4 && lean)
             hipLaunchKernelGGL((proposal_rays_kernel<5, 4, true>), dim3(grid), dim3(kBlock), rsmem, s, ra);
         else if (five && nd0 == 5 && nd1 == 4)
