@@ -448,7 +448,7 @@ def test_sample_split_tiles_match_the_oracle_and_the_serial_march(kind, S):
 
 @pytest.mark.parametrize("dense_mb", [64, 0])
 def test_proposal_pass_in_density_segments_gives_the_one_launch_kernels_bits(dense_mb):
-    """Calls under 4 096 tiles run the lane = ray proposal pass as four launches (density segments per (tile, segment), scans + PDF
+    """Calls under 3 072 tiles run the lane = ray proposal pass as four launches (density segments per (tile, segment), scans + PDF
     walks per tile: proposal_density_segments_kernel / proposal_resample_kernel); larger calls run proposal_rays_kernel.  The
     weights are formed in sample order in both, so the resampled edges — and with them EVERY output — are the same bits: the
     first 100 032 rays of a 262 208-ray call (4 097 tiles: one launch) against those rays as a call of their own (1 563 tiles:

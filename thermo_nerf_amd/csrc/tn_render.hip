@@ -18,8 +18,11 @@
 #ifndef TN_PROP_WAVES
 #define TN_PROP_WAVES 4   // waves per SIMD of proposal_rays_kernel (= workgroups per CU)
 #endif
+#ifndef TN_RESAMPLE_BLOCK
+#define TN_RESAMPLE_BLOCK 16  // bins per round trip in proposal_resample_kernel's scan and PDF walk (8 / 16 / 32: 0.444 / 0.435 / 0.435 ms at 80 000 rays)
+#endif
 #ifndef TN_PROP_SPLIT
-#define TN_PROP_SPLIT 1  // calls under 4 096 tiles: the lane = ray proposal pass as density segments + per-tile resampling (same bits)
+#define TN_PROP_SPLIT 1  // calls under 3 072 tiles: the lane = ray proposal pass as density segments + per-tile resampling (same bits)
 #endif
 #ifndef TN_PROP_GROUPS
 #define TN_PROP_GROUPS 32  // levels per gather stage of the lean proposal density: 3 + 2 (32) or 2 + 2 + 1 (221)
@@ -374,7 +377,10 @@ struct PropRaysArgs {
 
 // PDFSampler (histogram_padding 0.01, eps 1e-5) for one lane: inputs w[i] (scratch), existing edges via `edge(i)`,
 // total = sum(w^anneal + 0.01) over the level; emits n_out+1 new edges through `emit(j, value)`.
-template <typename EdgeFn, typename EmitFn>
+#ifndef TN_PDF_WALK_BLOCK
+#define TN_PDF_WALK_BLOCK 8
+#endif
+template <int WB = TN_PDF_WALK_BLOCK, typename EdgeFn, typename EmitFn>
 __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, float anneal, const float *u, bool jittered,
                                          float jit, int n_out, EdgeFn edge, EmitFn emit) {
     const float padding = fmaxf(sub_rn(1e-5f, total), 0.0f);
@@ -386,12 +392,8 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     float run = 0.0f, c0 = 0.0f;          // running cumsum(pdf); cdf[i] = min(1, run) before adding bin i
     float b0 = edge(0);
     float uj = jittered ? add_rn(u[0], jit) : u[0];
-#ifndef TN_PDF_WALK_BLOCK
-#define TN_PDF_WALK_BLOCK 8
-#endif
-    // TN_PDF_WALK_BLOCK bins at a time: their weights (scratch) and right edges are loaded up front, so a lane has that many
+    // WB (TN_PDF_WALK_BLOCK) bins at a time: their weights (scratch) and right edges are loaded up front, so a lane has that many
     // loads in flight instead of one round trip per bin (the emit stores inside the walk keep hipcc from hoisting them itself)
-    constexpr int WB = TN_PDF_WALK_BLOCK;
     for (int i0 = 0; i0 < n_in; i0 += WB) {
         float wv[WB], ev[WB];
 #if TN_PDF_LOAD_PRIO
@@ -578,7 +580,7 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_rays_kernel(Pr
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The lane = ray proposal pass for calls that do not fill the chip (round 5): the SAME arithmetic in four launches.
+// The lane = ray proposal pass for calls that do not fill the chip (under 3 072 tiles; round 5): the SAME arithmetic in four launches.
 // proposal_rays_kernel marches a tile's 256 + 96 samples on one wave, so a call lasts one whole march (0.6 ms) however few tiles it
 // has: an 80 000-ray shard (1 250 tiles on 4 096 wave slots) pays 0.75 ms where its share of a frame is 0.36.  What is serial in a
 // level is only the transmittance scan and the PDF walk; the density evaluations — the gathers and the MLP — are independent per
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_resample_kerne
         float accum = 0.0f, cum_w = 0.0f, total = 0.0f;
         int med_idx = n - 1;
         bool found = false;
-        constexpr int WB = 8;
+        constexpr int WB = TN_RESAMPLE_BLOCK;  // (a light kernel, one wave per tile: as many loads in flight as registers allow)
         for (int i0 = 0; i0 < n; i0 += WB) {
             float dv[WB];
 #pragma unroll
@@ -684,9 +686,9 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_resample_kerne
             }
         }
         if (LEVEL == 0)
-            pdf_walk(wsc, n, total, 1.0f, u, false, 0.0f, n_out, edge, [&](int j, float v) { b1sc[(size_t)j * 64] = v; });
+            pdf_walk<TN_RESAMPLE_BLOCK>(wsc, n, total, 1.0f, u, false, 0.0f, n_out, edge, [&](int j, float v) { b1sc[(size_t)j * 64] = v; });
         else
-            pdf_walk(wsc, n, total, 1.0f, u, false, 0.0f, n_out, edge, [&](int j, float v) { fin[(size_t)j * 64] = v; });
+            pdf_walk<TN_RESAMPLE_BLOCK>(wsc, n, total, 1.0f, u, false, 0.0f, n_out, edge, [&](int j, float v) { fin[(size_t)j * 64] = v; });
         if (live && a.prop_depth[LEVEL]) {  // the median's mid-point, from the level's own edges (read before level 1 overwrites none of them)
             const float s_near = spacing_fn(a.nears[rc], false), s_far = spacing_fn(a.fars[rc], false);
             const float st = spacing_to_eucl<true>(edge(med_idx), s_near, s_far, false);
@@ -961,9 +963,10 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
                     !pa.out_w[0] && !pa.out_w[1];
         for (int i = 0; i < 3; ++i) lean = lean && !pa.out_spacing[i] && !pa.out_eucl[i];
         // calls that leave most wave slots idle: density evaluations as (tile, segment) virtual tiles, scans + PDF walks per tile — the
-        // same edges bit for bit (see proposal_density_segments_kernel); from 4 096 tiles on the one-launch form
+        // same edges bit for bit (see proposal_density_segments_kernel).  Measured (tools/ab_prop_split.sh, S = 48, one-launch form ->
+        // segments): 65 536 rays 0.62 -> 0.41 ms, 80 000: 0.73 -> 0.44, 160 000: 0.92 -> 0.80, 259 200: 1.16 -> 1.27: up to 3 072 tiles
         constexpr long long kSlots = 256LL * TN_PROP_WAVES * kWaves;
-        if (TN_PROP_SPLIT && lean && five && (long long)tiles < kSlots && ((nd0 == 5 && nd1 == 4) || (nd0 == 0 && nd1 == 0)) && P0 >= 64 &&
+        if (TN_PROP_SPLIT && lean && five && 4 * (long long)tiles < 3 * kSlots && ((nd0 == 5 && nd1 == 4) || (nd0 == 0 && nd1 == 0)) && P0 >= 64 &&
             P1 >= 32) {
             PropSplitArgs sa;
             sa.ra = ra;
