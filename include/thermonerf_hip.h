@@ -227,7 +227,7 @@ typedef struct tn_render_config {
      * (wave-wide vote).  Skipped samples carry weights < eps each; rgb/thermal/accumulation move by <= eps, the
      * expected depth by <= eps * far.  The reference has no such switch: 0 reproduces it. */
     float early_stop_transmittance;
-    /* 0 = choose by call size (tn_render_kernel_form: lane = ray — a wavefront marches 64 consecutive rays — from 65 536 rays in
+    /* 0 = choose by call size (tn_render_kernel_form: lane = ray — a wavefront marches 64 consecutive rays — from 24 576 rays in
      * the proposal pass and from 8 192 in the field pass, whose tiles a small call marches in segments (sample_split); one ray
      * per wave below), 1 = lane = ray, 2 = one ray per wave. */
     int32_t kernel_family;
@@ -308,7 +308,7 @@ int tn_field_render_fwd(const tn_thermal_field *field, const tn_render_config *c
 int64_t tn_depth_bound_slots(int64_t first_ray, int64_t num_rays, int64_t chunk_rays);
 
 /* Which kernel form a call of num_rays rays takes under cfg->kernel_family (0 = by call size): 1 = lane = ray (a wavefront marches
- * 64 consecutive rays), 2 = one ray per wavefront.  pass 0: tn_proposal_sample_fwd (lane = ray from 65 536 rays); pass 1:
+ * 64 consecutive rays), 2 = one ray per wavefront.  pass 0: tn_proposal_sample_fwd (lane = ray from 24 576 rays; training calls: 65 536); pass 1:
  * tn_field_render_fwd / tn_field_render_chunked_fwd on `field`: lane = ray from 8 192 rays where the exact-fp32 kernel can march
  * its tiles in segments (sample_split != 1, no early termination, eval), from 40 960 with a split-precision blob (those kernels only
  * exist in form 1; a form-2 call with such a blob runs the exact-fp32 ray-per-wave kernel), from 57 344 otherwise or with field ==

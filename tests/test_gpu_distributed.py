@@ -269,7 +269,7 @@ def _shards_against_the_frame(eng, o, d, n, world, nears=None, fars=None, sample
 def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, precision):
     """The kernel form of a launch is the LIBRARY's decision (tn_render_kernel_form): with a split-precision blob the field pass
     runs lane = ray from 40 960 rays per call, with exact fp32 (which marches small calls in segments) from 8 192, the proposal pass
-    from 65 536 — frames of 45 000, 50 000 and 100 000 rays sit between / above them.  A shard (1/4 of the frame: below every threshold) must run the form of
+    from 24 576 — frames of 45 000, 50 000 and 100 000 rays sit between / above them.  A shard (1/4 of the frame: below every threshold) must run the form of
     the unsharded launch, in every precision (the engine used to re-derive the fp32 thresholds in Python)."""
     from thermo_nerf_amd import _hip, synthetic
     from thermo_nerf_amd.engine import RayRenderEngine
@@ -285,7 +285,7 @@ def test_shards_take_the_whole_launch_kernel_form_in_every_precision(h, w, preci
     eng.rc.kernel_family = 0
     form = eng.lib.tn_render_kernel_form(fld, eng.rc, n, 1)
     assert form == (1 if n >= (8192 if precision == "f32" else 40960) else 2)
-    assert eng.lib.tn_render_kernel_form(fld, eng.rc, n, 0) == (1 if n >= 65536 else 2)
+    assert eng.lib.tn_render_kernel_form(fld, eng.rc, n, 0) == (1 if n >= 24576 else 2)
     assert eng._forms(fld, n, 0)[:2] == (eng.lib.tn_render_kernel_form(None, eng.rc, n, 0), form)
     _shards_against_the_frame(eng, o, d, n, 4)
     assert eng.rc.kernel_family == 0  # render_shard leaves the engine's setting alone

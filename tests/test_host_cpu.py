@@ -141,8 +141,8 @@ def test_kernel_form_query_and_the_engine_launch_plan():
     mfma_blob = (ctypes.c_float * 4)()
     for fam in (0, 1, 2):
         rc.kernel_family = fam
-        for n in (1, 8191, 8192, 40959, 40960, 57343, 57344, 65535, 65536, 1 << 21):
-            want_prop = fam or (1 if n >= 65536 else 2)
+        for n in (1, 8191, 8192, 24575, 24576, 40959, 40960, 57343, 57344, 65535, 65536, 1 << 21):
+            want_prop = fam or (1 if n >= 24576 else 2)
             want_whole_tiles = fam or (1 if n >= 57344 else 2)   # the exact-fp32 kernel where it cannot march in segments
             want_segments = fam or (1 if n >= 8192 else 2)       # ... and where it can
             want_split_precision = fam or (1 if n >= 40960 else 2)
@@ -161,6 +161,7 @@ def test_kernel_form_query_and_the_engine_launch_plan():
             assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_split_precision
             rc.training = 1  # (the split-precision and segmented kernels are eval-only)
             assert lib.tn_render_kernel_form(fld, rc, n, 1) == want_whole_tiles
+            assert lib.tn_render_kernel_form(fld, rc, n, 0) == (fam or (1 if n >= 65536 else 2))
             rc.training = 0
     assert lib.tn_render_kernel_form(None, None, 100, 0) == 0
     model, _, _ = helpers.build("init", 48)

@@ -1113,9 +1113,10 @@ static int sample_split_kmax(const tn_thermal_field *field, const tn_render_conf
 int32_t tn_render_kernel_form(const tn_thermal_field *field, const tn_render_config *cfg, int64_t num_rays, int32_t pass) {
     if (!cfg) return 0;
     if (cfg->kernel_family == 1 || cfg->kernel_family == 2) return cfg->kernel_family;
-    // measured, tools/small_call_forms.py (profiles/micro/round5_small_call_forms.txt): the proposal pass's lane = ray form has a
-    // floor of 0.6 ms whatever the call and meets the ray-per-wave form at 65 536 rays
-    if (pass == 0) return num_rays < 65536 ? 2 : 1;
+    // measured, tools/small_call_forms.py (profiles/micro/round5_small_call_forms.txt): the proposal pass's lane = ray form — density
+    // segments + per-tile resampling for calls this small — has a floor of 0.21 ms and meets the ray-per-wave form at 24 576 rays
+    // (0.26 against 0.27 ms; 65 536 rays: 0.41 against 0.62); a training call's one-launch form (0.6 ms floor) at 65 536
+    if (pass == 0) return num_rays < (cfg->training ? 65536 : 24576) ? 2 : 1;
     // field pass: the split-precision kernels exist in the lane = ray form only and pay from 640 tiles; the exact-fp32 kernel marches
     // a small call's tiles in segments (tn_render_sample_split) and then beats one ray per wave from 8 192 rays (0.50 against
     // 0.57 ms at S = 192, 0.19 against 0.24 at S = 48; 32 768 rays: 1.61 against 2.15 and 0.43 against 0.76); without segments
