@@ -1135,7 +1135,7 @@ int32_t tn_render_sample_split(const tn_thermal_field *field, const tn_render_co
     // by call size: a call of T tiles lasts about ceil(k T / 2048) marches of ceil(S / k) samples (+ half a sample's worth of
     // per-segment set-up).  The waves do not run in lock step, so finer pieces also balance better than the round count says
     // (measured, tools/ab_split.py: 4 050 tiles at S = 48 are two exact rounds, and 4.83 ms whole against 4.53 in 6 segments):
-    // the LARGEST k within 5 % of the cheapest.  From four full rounds on (the 800 x 800 frame: 10 000 tiles) the serial march stays.
+    // the LARGEST k within 7 % of the cheapest.  From four full rounds on (the 800 x 800 frame: 10 000 tiles) the serial march stays.
     const long long slots = 2048, tiles = (num_rays + 63) / 64;
     if (tiles >= 4 * slots) return 1;
     long long cost[9], best_cost = 0;
@@ -1145,7 +1145,7 @@ int32_t tn_render_sample_split(const tn_thermal_field *field, const tn_render_co
     }
     int best = 1;
     for (int k = 2; k <= kmax; ++k)
-        if (20 * cost[k] <= 21 * best_cost) best = k;
+        if (100 * cost[k] <= 107 * best_cost) best = k;
     return best;
 }
 
