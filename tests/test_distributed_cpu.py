@@ -212,3 +212,61 @@ def test_pipelined_frame_gather_double_buffering():
     for rank, ok, slots in res:
         assert ok, f"rank {rank}: gathered frames differ"
         assert slots == [0, 1, 0, 1, 0]
+
+
+class SplitRecordingEngine(ToyEngine):
+    """ToyEngine + the engine's sample-split surface: proposes k from the size of a rank's run and records what render_shard got"""
+
+    def __init__(self, chunk):
+        super().__init__(chunk)
+        self.asked, self.got, self.planes = [], [], []
+
+    def shard_sample_split(self, shard_rays):
+        self.asked.append(shard_rays)
+        return 1 + shard_rays % 5
+
+    def render_shard(self, o, d, start, frame_rays, sample_split=None, nears=None, fars=None):
+        self.got.append(sample_split)
+        self.planes.append(None if nears is None else (tuple(nears.shape), tuple(fars.shape)))
+        return super().render_shard(o, d, start, frame_rays)
+
+
+def _split_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o, d, _ = synthetic.orbit_camera_rays(16, 12, view=1)
+        n = 16 * 12
+        eng = SplitRecordingEngine(50)
+        D.render_frame_sharded_fine(eng, o, d, align=4)                      # default: the k that suits ONE rank's run
+        D.render_frame_sharded_fine(eng, o, d, align=4, sample_split=None)   # the frame's own choice: nothing passed on
+        D.render_frame_sharded_fine(eng, o, d, align=4, sample_split=3, nears=torch.zeros(16, 12, 1), fars=torch.ones(16, 12, 1))
+        r0, r1 = D.ray_block(n, rank, world, 4)
+        q.put((rank, eng.asked, eng.got, eng.planes, D.ray_block(n, 0, world, 4)[1], r1 - r0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fine_sharding_hands_every_rank_the_same_sample_split():
+    """render_frame_sharded_fine: sample_split="shard" asks the engine ONCE per frame for the k of RANK 0's run size (so every rank
+    passes the same k, whatever its own run), None passes nothing (the engine's frame-level default), an integer is forced; per-ray
+    planes are sliced like the rays."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    ks = set()
+    for rank, asked, got, planes, run0, mine in res:
+        assert asked == [run0]
+        assert got == [1 + run0 % 5, None, 3]
+        assert planes == [None, None, ((mine,), (mine,))]
+        ks.add(got[0])
+    assert len(ks) == 1
