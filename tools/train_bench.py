@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--ray-batch", default="patch", choices=["patch", "random"],
                     help="patch: the sqrt(rays)^2 image of one orbit view (rounds 1-3); random: pixels drawn uniformly over all 8 "
                          "views of an 800x800 orbit, the way nerfstudio's PixelSampler fills a batch")
+    ap.add_argument("--kick-ms", type=float, default=0.0,
+                    help="probe: queue a spin kernel of this many ms before the timed steps, so that the host starts AHEAD of the device "
+                         "(is the slow start of a run a host-bound mode that sustains itself?)")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
@@ -99,6 +102,8 @@ def main():
     for i in range(a.warmup):
         step(a.start_step + i)
     torch.cuda.synchronize()
+    if a.kick_ms > 0:
+        torch.cuda._sleep(int(a.kick_ms * 2.4e6))
     if a.seconds > 0:
         print("before:", smi(), flush=True)
         marks, i, t0 = [], 0, time.perf_counter()
