@@ -169,7 +169,8 @@ int tn_field_heads_fwd(const tn_thermal_field *field, const float *directions, c
 /* The proposal sampler's initial sampler [REF thermal_nerf_model.py:164-170]: UniformLinDispPiecewiseSampler
  * (uniform_spacing == 0, the reference default) or UniformSampler (uniform_spacing == 1; spacing_fn and its inverse are the
  * identity).  spacing bins [n+1] (= torch.linspace(0,1,n+1), host-computed, device resident) (+ optional per-ray
- * stratified jitter t_rand [R], NULL in eval) -> spacing_bins [R,n+1], euclidean bins [R,n+1]. nears/fars [R]. */
+ * stratified jitter t_rand [R], NULL in eval) -> spacing_bins [R,n+1], euclidean bins [R,n+1]. nears/fars [R].
+ * Bit 1 of uniform_spacing (value 2, round 5) = NS single_jitter=False: t_rand is [R,n+1], one draw per bin edge. */
 int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *nears, const float *fars,
                       int64_t num_rays, int32_t n, int32_t uniform_spacing, float *spacing_bins, float *eucl_bins,
                       void *stream);
@@ -181,7 +182,8 @@ int tn_weights_fwd(const float *deltas, const float *densities, int64_t num_rays
 /* PDFSampler.generate_ray_samples (histogram_padding 0.01, eps 1e-5): weights [R,n_in] (already annealed),
  * existing spacing bins [R,n_in+1], u [n_out+1] (host-computed eval positions) or u_rand [R] jitter (training;
  * NULL in eval), nears/fars [R] -> spacing_bins [R,n_out+1], eucl_bins [R,n_out+1].  uniform_spacing = the initial
- * sampler's spacing function, which PDFSampler reuses for the new bins (see tn_sample_initial). */
+ * sampler's spacing function, which PDFSampler reuses for the new bins (see tn_sample_initial); its bit 1 (value 2) =
+ * single_jitter=False: u_rand is [R,n_out+1], one draw per new bin edge. */
 int tn_sample_pdf(const float *weights, const float *existing_bins, const float *u, const float *u_rand,
                   const float *nears, const float *fars, int64_t num_rays, int32_t n_in, int32_t n_out,
                   int32_t uniform_spacing, float *spacing_bins, float *eucl_bins, void *stream);
@@ -243,6 +245,10 @@ typedef struct tn_render_config {
      * 1 = never, k > 1 = k segments (capped so that the records fit the workspace: tn_render_sample_split reports the value used).
      * Ignored (1) by the training, early-termination, split-precision and one-ray-per-wave kernels. */
     int32_t sample_split;
+    /* Training only (round 5, appended): 0 = NS single_jitter=True (the reference's default, REF thermal_nerf_model.py:176): ONE
+     * stratified draw per ray and level, tn_render_inputs.jitter = [3,R]; 1 = single_jitter=False: one draw per bin edge,
+     * jitter = [R,P0+1] | [R,P1+1] | [R,S+1] back to back [NS SpacedSampler / PDFSampler.generate_ray_samples]. */
+    int32_t per_sample_jitter;
 } tn_render_config;
 
 typedef struct tn_render_inputs {
@@ -254,7 +260,8 @@ typedef struct tn_render_inputs {
     const float *lin_bins0;          /* [P0+1] torch.linspace(0,1,P0+1) */
     const float *u1;                 /* [P1+1] PDFSampler eval positions for level 1 */
     const float *u2;                 /* [S+1]  PDFSampler eval positions for the final level */
-    const float *jitter;             /* [3,R] per-level single-jitter draws (training) or NULL */
+    const float *jitter;             /* training: [3,R] per-level single-jitter draws, or the per-edge draws of
+                                      * tn_render_config.per_sample_jitter; NULL in eval */
 } tn_render_inputs;
 
 typedef struct tn_render_outputs {

@@ -359,7 +359,8 @@ def sample_initial(nears: Tensor, fars: Tensor, num_samples: int, t_rand: Option
                    uniform: bool = False) -> Samples:
     """NS UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (a4); ``uniform`` = NS UniformSampler
     (proposal_initial_sampler="uniform", REF thermal_nerf_model.py:164-170: identity spacing functions).
-    ``t_rand`` [R,1] = the single-jitter random draw in training, None in eval."""
+    ``t_rand`` = the stratified draw in training: [R,1] under single_jitter (one per ray), [R,n+1] otherwise (one per bin
+    edge; NS SpacedSampler draws rand((R, n+1)) and the same expression broadcasts); None in eval."""
     bins = torch.linspace(0.0, 1.0, num_samples + 1)[None, ...]
     if t_rand is not None:
         centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
@@ -377,7 +378,8 @@ def pdf_u(num_bins: int) -> Tensor:
 
 
 def sample_pdf(prev: Samples, weights: Tensor, num_samples: int, rand: Optional[Tensor]) -> Samples:
-    """NS PDFSampler.generate_ray_samples (a11); histogram_padding 0.01, eps 1e-5, single_jitter."""
+    """NS PDFSampler.generate_ray_samples (a11); histogram_padding 0.01, eps 1e-5.  ``rand``: [R,1] under single_jitter,
+    [R,num_samples+1] otherwise (NS draws rand((R, num_samples+1)); ``u + rand / num_bins`` broadcasts either)."""
     num_bins = num_samples + 1
     w = weights[..., 0] + 0.01
     ws = torch.sum(w, dim=-1, keepdim=True)

@@ -118,6 +118,59 @@ def test_uniform_sampler_and_its_pdf_resampling(near, far, n):
     assert_close(rs_p.frustums.ends, want_p.ends, 1e-6 + 5e-6 * (far - near), 0, "pdf ends(train)")
 
 
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("n,n_out", [(256, 96), (96, 48), (7, 192), (64, 5)])
+def test_samplers_with_one_draw_per_bin_edge(n, n_out, uniform):
+    """NS single_jitter=False (ThermalNerfactoModelConfig.use_single_jitter, REF thermal_nerf_model.py:176): SpacedSampler draws
+    rand((R, n+1)), PDFSampler rand((R, n_out+1)) — one stratified draw per bin edge rather than one per ray.  Same kernels,
+    bit 1 of their uniform_spacing argument; results against the oracle, and the single-draw layout still rejected by size."""
+    R = 37
+    o, d = helpers.rays(8, 8)
+    near, far = (0.05, 6.0) if uniform else (0.05, 1000.0)
+    nears, fars = torch.full((R, 1), near), torch.full((R, 1), far)
+    rb = bundle(o[:R], d[:R])
+    rb.nears, rb.fars = nears.to(DEV), fars.to(DEV)
+    g = torch.Generator().manual_seed(100 * n + n_out)
+    t = torch.rand(R, n + 1, generator=g)
+    cls = UniformSampler if uniform else UniformLinDispPiecewiseSampler
+    s = cls(single_jitter=False).train()
+    want = H.sample_initial(nears, fars, n, t, uniform=uniform)
+    rs = s(rb, num_samples=n, t_rand=t.to(DEV))
+    assert_close(rs.spacing_starts, want.spacing_starts, 1e-7, 0, "spacing")
+    assert_close(rs.spacing_ends, want.spacing_ends, 1e-7, 0, "spacing ends")
+    assert_close(rs.frustums.ends, want.ends, 1e-6 * (far - near) if uniform else 0, 5e-7, "ends")
+    # the draws really are per edge: a single-jitter run on column 0 differs
+    one = cls(single_jitter=True).train()(rb, num_samples=n, t_rand=t[:, :1].contiguous().to(DEV))
+    assert not torch.equal(one.spacing_ends, rs.spacing_ends)
+    with pytest.raises(ValueError, match="draws"):
+        s(rb, num_samples=n, t_rand=t[:, :1].contiguous().to(DEV))
+    # its own draws: stratified, i.e. edge j stays inside [centre(j-1), centre(j)] and the bins stay ordered
+    own = s(rb, num_samples=n)
+    sp = torch.cat([own.spacing_starts[..., 0], own.spacing_ends[:, -1:, 0]], -1).cpu()
+    assert bool((sp[:, 1:] >= sp[:, :-1]).all()) and float(sp.min()) >= 0.0 and float(sp.max()) <= 1.0
+    assert float((sp[0] - sp[1]).abs().max()) > 0  # rays differ
+    centres = (torch.arange(n + 1, dtype=torch.float32) - 0.5).clamp(0, n) / n
+    assert bool((sp >= centres[None] - 1e-6).all()) and bool((sp[:, :-1] <= centres[None, 1:] + 1e-6).all())
+
+    w = torch.rand(R, n, 1, generator=g) ** 6
+    w[0] = 0.0
+    u = torch.rand(R, n_out + 1, generator=g)
+    want_p = H.sample_pdf(want, w, n_out, u)
+    ps = PDFSampler(single_jitter=False).train()
+    rs_p = ps(rb, rs, w.to(DEV), num_samples=n_out, u_rand=u.to(DEV))
+    assert_close(rs_p.spacing_starts, want_p.spacing_starts, 5e-6, 0, "pdf spacing")
+    assert_close(rs_p.spacing_ends, want_p.spacing_ends, 5e-6, 0, "pdf spacing ends")
+    # (a spacing error e moves the distance by (far - near) e under the uniform map, by 2 x^2 e at distance x under 1/(2-2s))
+    x = want_p.ends.double()
+    lim = 1e-6 + 5e-6 * ((far - near) if uniform else 2 * torch.clamp(x, min=1.0) ** 2)
+    assert bool(((rs_p.frustums.ends.cpu().double() - x).abs() <= lim).all()), "pdf ends"
+    with pytest.raises(ValueError, match="draws"):
+        ps(rb, rs, w.to(DEV), num_samples=n_out, u_rand=u[:, :1].contiguous().to(DEV))
+    own = ps(rb, rs, w.to(DEV), num_samples=n_out)
+    sp = torch.cat([own.spacing_starts[..., 0], own.spacing_ends[:, -1:, 0]], -1)
+    assert bool((sp[:, 1:] >= sp[:, :-1]).all())
+
+
 @pytest.mark.parametrize("n", [48, 64, 192, 256, 5])
 def test_get_weights(n):
     g = torch.Generator().manual_seed(n)
@@ -657,6 +710,46 @@ def test_get_outputs_training_mode(impl):
         assert_close(got["weights_list"][i], want["weights_list"][i], 3e-5, 1e-4, f"weights_list[{i}]")
         assert_close(got["ray_samples_list"][i].spacing_starts, want["ray_samples_list"][i].spacing_starts, 1e-5, 0,
                      f"spacing_starts[{i}]")
+
+
+@pytest.mark.parametrize("family", ["lane_ray", "ray_per_wave"])
+@pytest.mark.parametrize("impl", list(IMPLS))
+@pytest.mark.parametrize("S", [48, 192])
+def test_get_outputs_training_mode_with_one_draw_per_bin_edge(impl, family, S):
+    """use_single_jitter=False through the train-mode forward: the modular samplers take [R,n+1] per level, the fused forward
+    tn_render_inputs.jitter in the per-edge layout (tn_render_config.per_sample_jitter) — in both proposal kernels (one ray per
+    wave: proposal_kernel; lane = ray: proposal_rays_kernel's sequential PDF walk)."""
+    gm, sd, ocfg = gpu_model("stress", S, family=family, use_single_jitter=False)
+    fused, gm.config.use_mfma = IMPLS[impl]
+    if not fused and family == "ray_per_wave":
+        pytest.skip("the modular path has one form")
+    gm.config.fused = fused
+    gm.train()
+    o, d = helpers.rays(12, 12, view=3)
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(13)
+    jit = [torch.rand(R, n + 1, generator=g) for n in (*gm.config.num_proposal_samples_per_ray, S)]
+    cam = torch.randint(0, 8, (R, 1), generator=g)
+    want = H.get_outputs(sd, o, d, cam, ocfg, training=True, jitter=jit)
+    rb = gm.collider(bundle(o, d, cam))
+    with torch.no_grad():
+        if fused:
+            got = gm._get_outputs_fused(rb, jitter=[j.to(DEV) for j in jit])
+            with pytest.raises(ValueError, match="draws"):
+                gm._get_outputs_fused(rb, jitter=torch.rand(3, R, device=DEV))
+        else:
+            got = gm._get_outputs_modular(rb, jitter=[j.to(DEV) for j in jit])
+    gm.eval()
+    check_outputs(got, want, f"train per-edge impl={impl} {family}")
+    for i in range(3):
+        assert_close(got["weights_list"][i], want["weights_list"][i], 3e-5, 1e-4, f"weights_list[{i}]")
+        assert_close(got["ray_samples_list"][i].spacing_starts, want["ray_samples_list"][i].spacing_starts, 1e-5, 0,
+                     f"spacing_starts[{i}]")
+    # not the single-draw result
+    single = H.get_outputs(sd, o, d, cam, ocfg, training=True, jitter=[j[:, :1] for j in jit])
+    for i in range(3):
+        a, b = single["ray_samples_list"][i].spacing_starts, want["ray_samples_list"][i].spacing_starts
+        assert (a - b).abs().max().item() > 1e-4, i
 
 
 def test_full_size_tables_default_config():

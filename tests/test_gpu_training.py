@@ -429,6 +429,64 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
     assert checked >= (13 if variant == "same_proposal_network" else 18)
 
 
+@pytest.mark.parametrize("update_step", [True, False])
+@pytest.mark.parametrize("S,hw", [(48, (12, 12)), (192, (7, 5))])
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+def test_training_step_with_one_jitter_draw_per_bin_edge(kind, S, hw, update_step):
+    """use_single_jitter=False [REF thermal_nerf_model.py:176, nerfacto_config/thermal_nerfacto.py]: every bin edge of every level
+    gets its own stratified draw ([R,n+1] per level).  Update steps sample level by level (tn_sample_initial / tn_sample_pdf with
+    bit 1 set); the other steps run the proposal levels as one kernel reading tn_render_inputs.jitter in the per-edge layout
+    (tn_render_config.per_sample_jitter).  Both against torch autograd over the oracle with the same draws."""
+    gm, sd, ocfg, o, d, _, cam, batch = _train_setup(kind, S, R_hw=hw, use_single_jitter=False)
+    assert gm.config.use_single_jitter is False
+    R = o.shape[0]
+    counts = (*gm.config.num_proposal_samples_per_ray, S)
+    g = torch.Generator().manual_seed(S + R)
+    jit = [torch.rand(R, n + 1, generator=g) for n in counts]
+    if not update_step:
+        gm.set_step(5000)
+        gm.proposal_sampler._steps_since_update = 0
+    rb = gm.collider(RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV)))
+    out = TR.get_outputs_train(gm, rb, jitter=[j.to(DEV) for j in jit])
+    assert out["weights_list"][0].requires_grad is update_step
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    loss_dict = gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b))
+    gm.zero_grad(set_to_none=True)
+    sum(loss_dict.values()).backward()
+    anneal = float(gm.proposal_sampler._anneal)
+    want_out, want_loss, want_grads = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit, anneal=anneal,
+                                                       proposal_requires_grad=update_step)
+    for k in ("rgb", "thermal", "accumulation"):
+        assert (out[k].detach().cpu() - want_out[k].detach()).abs().max().item() <= 2e-5, k
+    for i in range(3):
+        assert (out["weights_list"][i].detach().cpu() - want_out["weights_list"][i].detach()).abs().max().item() <= 2e-5, i
+        want_sp = torch.cat([want_out["ray_samples_list"][i].spacing_starts[..., 0],
+                             want_out["ray_samples_list"][i].spacing_ends[:, -1:, 0]], -1)
+        got_sp = out["ray_samples_list"][i].spacing_bins
+        assert (got_sp.detach().cpu() - want_sp.detach()).abs().max().item() <= 1e-5, i
+    for k, v in want_loss.items():
+        assert abs(loss_dict[k].item() - v.item()) <= 2e-5 * abs(v.item()) + 1e-8, (k, loss_dict[k].item(), v.item())
+    named = dict(gm.named_parameters())
+    checked = 0
+    for name, gw in want_grads.items():
+        if gw is None or gw.numel() == 0 or name.startswith("camera_optimizer") or name.startswith("__"):
+            continue
+        gg = named[name].grad
+        if gw.norm().item() < 1e-10:
+            assert gg is None or gg.norm().item() < 1e-9, name
+            continue
+        assert gg is not None, f"{name}: no gradient"
+        assert rel(gg, gw) <= 2e-3, f"{name}: rel {rel(gg, gw):.2e}"
+        checked += 1
+    assert checked >= (18 if update_step else 8)
+    # the model's own draws: the per-edge layout, different per call, and a [3,R] tensor is refused by size
+    a = TR.get_outputs_train(gm, rb)["rgb"].detach().clone()
+    c = TR.get_outputs_train(gm, rb)["rgb"].detach()
+    assert torch.isfinite(a).all() and not torch.equal(a, c)
+    with pytest.raises(ValueError, match="draws"):
+        TR.get_outputs_train(gm, rb, jitter=torch.rand(3, R, device=DEV))
+
+
 def test_training_step_at_config3_sizes_matches_autograd_oracle():
     """BASELINE config 3's step held against the ORACLE at its real sizes (VERDICT r4 Weak #5: the full-size step was only held
     against other forms of the HIP step): S = 192 samples per ray on the FULL-SIZE tables (16 x 2^19 field entries, 5 x 2^17 per

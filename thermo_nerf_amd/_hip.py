@@ -114,6 +114,7 @@ class tn_render_config(C.Structure):
         ("kernel_family", C.c_int32),
         ("initial_sampler", C.c_int32),
         ("sample_split", C.c_int32),
+        ("per_sample_jitter", C.c_int32),
     ]
 
 

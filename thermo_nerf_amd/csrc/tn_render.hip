@@ -73,6 +73,7 @@ struct PropArgs {
     PropNet net[2];
     const float *origins, *dirs, *nears, *fars;
     const float *lin0, *u1, *u2, *jitter;
+    int jper;  // 0: jitter [3,R] (single_jitter); 1: [R,P0+1] | [R,P1+1] | [R,S+1] (NS single_jitter=False)
     const float *wk;  // [2][kPropWFloats] k-major copies of the two proposal MLPs (workspace), scalar-operand evaluation
     long long R;
     int P0, P1, S, training;
@@ -130,7 +131,7 @@ __device__ __forceinline__ float prop_level(const PropNet &net, const TwoLayerLd
 
 // NS PDFSampler: wts[n_in] (weights), bins[n_in+1] (existing spacing bins) -> new_bins[n_out+1]
 __device__ __forceinline__ void pdf_resample(const float *wts, const float *bins, int n_in, float *cdf,
-                                             const float *u, bool jittered, float u_rand, float anneal, int n_out,
+                                             const float *u, bool jittered, const float *jrow, bool jper, float anneal, int n_out,
                                              float *new_bins, int lane) {
     float part = 0.0f;
     for (int i = lane; i < n_in; i += 64) {
@@ -158,9 +159,9 @@ __device__ __forceinline__ void pdf_resample(const float *wts, const float *bins
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nb = n_out + 1;
-    const float jit = jittered ? u_rand / (float)nb : 0.0f;
+    const float jit = (jittered && !jper) ? jrow[0] / (float)nb : 0.0f;
     for (int j = lane; j < nb; j += 64) {
-        const float uu = jittered ? add_rn(u[j], jit) : u[j];
+        const float uu = jittered ? add_rn(u[j], jper ? jrow[j] / (float)nb : jit) : u[j];
         int lo = 0, hi = n_in + 1;
         while (lo < hi) {  // searchsorted(cdf, uu, side="right")
             const int mid = (lo + hi) >> 1;
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_kernel(PropArgs a, int nma
         for (int j = lane; j <= P0; j += 64) {
             float b = a.lin0[j];
             if (a.jitter) {
-                const float t = a.jitter[r];
+                const float t = a.jper ? a.jitter[r * (P0 + 1) + j] : a.jitter[r];
                 const float lo = (j == 0) ? a.lin0[0] : add_rn(a.lin0[j], a.lin0[j - 1]) / 2.0f;
                 const float hi = (j == P0) ? a.lin0[P0] : add_rn(a.lin0[j + 1], a.lin0[j]) / 2.0f;
                 b = add_rn(lo, mul_rn(sub_rn(hi, lo), t));
@@ -229,13 +230,13 @@ __global__ void __launch_bounds__(kBlock, 4) proposal_kernel(PropArgs a, int nma
         store_bins(binsA, P0 + 1, s_near, s_far, lin, a.out_spacing[0], a.out_eucl[0], r, lane);
         const float med0 = prop_level(a.net[0], w0, ox, oy, oz, dx, dy, dz, s_near, s_far, lin, binsA, P0, wts, lane);
         if (a.out_w[0]) for (int i = lane; i < P0; i += 64) a.out_w[0][r * P0 + i] = wts[i];
-        pdf_resample(wts, binsA, P0, cdf, a.u1, a.jitter != nullptr, a.jitter ? a.jitter[a.R + r] : 0.0f, a.anneal, P1,
-                     binsB, lane);
+        const float *j1 = !a.jitter ? nullptr : (a.jper ? a.jitter + a.R * (P0 + 1) + r * (P1 + 1) : a.jitter + a.R + r);
+        const float *j2 = !a.jitter ? nullptr : (a.jper ? a.jitter + a.R * (P0 + 1 + P1 + 1) + r * (S + 1) : a.jitter + 2 * a.R + r);
+        pdf_resample(wts, binsA, P0, cdf, a.u1, a.jitter != nullptr, j1, a.jper != 0, a.anneal, P1, binsB, lane);
         store_bins(binsB, P1 + 1, s_near, s_far, lin, a.out_spacing[1], a.out_eucl[1], r, lane);
         const float med1 = prop_level(a.net[1], w1, ox, oy, oz, dx, dy, dz, s_near, s_far, lin, binsB, P1, wts, lane);
         if (a.out_w[1]) for (int i = lane; i < P1; i += 64) a.out_w[1][r * P1 + i] = wts[i];
-        pdf_resample(wts, binsB, P1, cdf, a.u2, a.jitter != nullptr, a.jitter ? a.jitter[2 * a.R + r] : 0.0f, a.anneal,
-                     S, binsA, lane);
+        pdf_resample(wts, binsB, P1, cdf, a.u2, a.jitter != nullptr, j2, a.jper != 0, a.anneal, S, binsA, lane);
         for (int j = lane; j <= S; j += 64) a.ws_spacing[tn_ws_bin(r, j, S)] = binsA[j];
         store_bins(binsA, S + 1, s_near, s_far, lin, nullptr, a.out_eucl[2], r, lane);
         if (a.out_spacing[2]) for (int j = lane; j <= S; j += 64) a.out_spacing[2][r * (S + 1) + j] = binsA[j];
@@ -382,7 +383,8 @@ struct PropRaysArgs {
 #endif
 template <int WB = TN_PDF_WALK_BLOCK, typename EdgeFn, typename EmitFn>
 __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, float anneal, const float *u, bool jittered,
-                                         float jit, int n_out, EdgeFn edge, EmitFn emit) {
+                                         float jit, int n_out, EdgeFn edge, EmitFn emit, const float *jrow = nullptr) {
+    // jrow (NS single_jitter=False): this ray's n_out + 1 draws; jit is then unused
     const float padding = fmaxf(sub_rn(1e-5f, total), 0.0f);
     const float pad_each = padding / (float)n_in;
     const float ws = add_rn(total, padding);
@@ -391,7 +393,7 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
     int j = 0;
     float run = 0.0f, c0 = 0.0f;          // running cumsum(pdf); cdf[i] = min(1, run) before adding bin i
     float b0 = edge(0);
-    float uj = jittered ? add_rn(u[0], jit) : u[0];
+    float uj = jittered ? add_rn(u[0], jrow ? jrow[0] / (float)(n_out + 1) : jit) : u[0];
     // WB (TN_PDF_WALK_BLOCK) bins at a time: their weights (scratch) and right edges are loaded up front, so a lane has that many
     // loads in flight instead of one round trip per bin (the emit stores inside the walk keep hipcc from hoisting them itself)
     for (int i0 = 0; i0 < n_in; i0 += WB) {
@@ -422,7 +424,7 @@ __device__ __forceinline__ void pdf_walk(const float *w, int n_in, float total, 
                 t = fminf(fmaxf(t, 0.0f), 1.0f);
                 emit(j, add_rn(b0, mul_rn(t, sub_rn(b1, b0))));
                 ++j;
-                if (j < nb) uj = jittered ? add_rn(u[j], jit) : u[j];
+                if (j < nb) uj = jittered ? add_rn(u[j], jrow ? jrow[j] / (float)nb : jit) : u[j];
             }
             c0 = c1;
             b0 = b1;
@@ -478,14 +480,18 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_rays_kernel(Pr
         float *wsc = ra.w_scratch + (size_t)tile * ra.nmax * 64 + lane;       // w[i] at wsc[i*64]
         float *b1sc = ra.b1_scratch + (size_t)tile * (P1 + 1) * 64 + lane;   // edge j at b1sc[j*64]
         float *fin = a.ws_spacing + tn_ws_bin(tile * 64, 0, S) + lane;       // final edge j at fin[j*64]
-        const float t0 = jittered ? a.jitter[rc] : 0.0f;
+        const bool jper = jittered && a.jper != 0;
+        const float t0 = (jittered && !jper) ? a.jitter[rc] : 0.0f;
+        const float *jr0 = jper ? a.jitter + rc * (P0 + 1) : nullptr;
+        const float *jr1 = jper ? a.jitter + a.R * (P0 + 1) + rc * (P1 + 1) : nullptr;
+        const float *jr2 = jper ? a.jitter + a.R * (P0 + 1 + P1 + 1) + rc * (S + 1) : nullptr;
         // level-0 spacing edge j: linspace, or its stratified jitter
         auto edge0 = [&](int j) -> float {
             float b = lin0[j];
             if (jittered) {
                 const float lo = (j == 0) ? lin0[0] : add_rn(lin0[j], lin0[j - 1]) / 2.0f;
                 const float hi = (j == P0) ? lin0[P0] : add_rn(lin0[j + 1], lin0[j]) / 2.0f;
-                b = add_rn(lo, mul_rn(sub_rn(hi, lo), t0));
+                b = add_rn(lo, mul_rn(sub_rn(hi, lo), jper ? jr0[j] : t0));
             }
             return b;
         };
@@ -525,8 +531,8 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_rays_kernel(Pr
             if (!found) med0 = step;
         }
         // ================= PDF resample 0 -> P1 + 1 edges ===================================================
-        pdf_walk(wsc, P0, total, anneal, u1, jittered, jittered ? a.jitter[a.R + rc] / (float)(P1 + 1) : 0.0f, P1,
-                 edge0, [&](int j, float v) { b1sc[(size_t)j * 64] = v; });
+        pdf_walk(wsc, P0, total, anneal, u1, jittered, (jittered && !jper) ? a.jitter[a.R + rc] / (float)(P1 + 1) : 0.0f, P1,
+                 edge0, [&](int j, float v) { b1sc[(size_t)j * 64] = v; }, jr1);
         // ================= level 1: P1 samples through proposal net 1 =====================================
         float med1 = 0.0f;
         total = 0.0f;
@@ -565,13 +571,13 @@ __global__ void __launch_bounds__(kBlock, TN_PROP_WAVES) proposal_rays_kernel(Pr
             if (!found) med1 = step;
         }
         // ================= PDF resample 1 -> S + 1 final edges (ray-tiled workspace) ========================
-        pdf_walk(wsc, P1, total, anneal, u2, jittered, jittered ? a.jitter[2 * a.R + rc] / (float)(S + 1) : 0.0f, S,
+        pdf_walk(wsc, P1, total, anneal, u2, jittered, (jittered && !jper) ? a.jitter[2 * a.R + rc] / (float)(S + 1) : 0.0f, S,
                  [&](int j) -> float { return b1sc[(size_t)j * 64]; },
                  [&](int j, float v) {
                      fin[(size_t)j * 64] = v;
                      if (live && osp2) osp2[r * (S + 1) + j] = v;
                      if (live && oeu2) oeu2[r * (S + 1) + j] = spacing_to_eucl<true>(v, s_near, s_far, lin);
-                 });
+                 }, jr2);
         if (live) {
             if (a.prop_depth[0]) a.prop_depth[0][r] = med0;
             if (a.prop_depth[1]) a.prop_depth[1][r] = med1;
@@ -919,6 +925,7 @@ int tn_proposal_sample_fwd(const tn_density_field *prop0, const tn_density_field
     pa.origins = in->origins; pa.dirs = in->directions; pa.nears = in->nears; pa.fars = in->fars;
     pa.lin0 = in->lin_bins0; pa.u1 = in->u1; pa.u2 = in->u2;
     pa.jitter = cfg->training ? in->jitter : nullptr;
+    pa.jper = cfg->per_sample_jitter != 0;
     pa.R = num_rays; pa.P0 = P0; pa.P1 = P1; pa.S = S; pa.training = cfg->training; pa.anneal = cfg->pdf_anneal;
     pa.lin = cfg->initial_sampler == 1;
     pa.ws_spacing = reinterpret_cast<float *>(workspace);

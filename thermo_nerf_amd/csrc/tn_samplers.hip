@@ -50,7 +50,7 @@ __global__ void frustum_from_edges_kernel(const float *__restrict__ o, const flo
 
 __global__ void sample_initial_kernel(const float *__restrict__ lin_bins, const float *__restrict__ t_rand,
                                       const float *__restrict__ nears, const float *__restrict__ fars,
-                                      long long num_rays, int n, bool lin, float *__restrict__ spacing,
+                                      long long num_rays, int n, bool lin, bool per_sample, float *__restrict__ spacing,
                                       float *__restrict__ eucl) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = n + 1;
@@ -62,7 +62,7 @@ __global__ void sample_initial_kernel(const float *__restrict__ lin_bins, const 
         // bins = lower + (upper - lower) * t ; centers between neighbouring linspace points
         const float lo = (j == 0) ? lin_bins[0] : add_rn(lin_bins[j], lin_bins[j - 1]) / 2.0f;
         const float hi = (j == n) ? lin_bins[n] : add_rn(lin_bins[j + 1], lin_bins[j]) / 2.0f;
-        b = add_rn(lo, mul_rn(sub_rn(hi, lo), t_rand[r]));
+        b = add_rn(lo, mul_rn(sub_rn(hi, lo), t_rand[per_sample ? i : r]));  // single_jitter: one draw per ray; else [R, n+1]
     }
     const float sn = spacing_fn(nears[r], lin), sf = spacing_fn(fars[r], lin);
     spacing[i] = b;
@@ -95,7 +95,7 @@ __global__ void weights_kernel(const float *__restrict__ deltas, const float *__
 __global__ void sample_pdf_kernel(const float *__restrict__ weights, const float *__restrict__ existing,
                                   const float *__restrict__ u, const float *__restrict__ u_rand,
                                   const float *__restrict__ nears, const float *__restrict__ fars,
-                                  long long num_rays, int n_in, int n_out, bool lin, float *__restrict__ spacing,
+                                  long long num_rays, int n_in, int n_out, bool lin, bool per_sample, float *__restrict__ spacing,
                                   float *__restrict__ eucl) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -128,9 +128,10 @@ __global__ void sample_pdf_kernel(const float *__restrict__ weights, const float
     __threadfence_block();
     const int nb = n_out + 1;
     const float sn = spacing_fn(nears[r], lin), sf = spacing_fn(fars[r], lin);
-    const float jit = u_rand ? u_rand[r] / (float)nb : 0.0f;
+    const float jit = (u_rand && !per_sample) ? u_rand[r] / (float)nb : 0.0f;
     for (int j = lane; j < nb; j += 64) {
-        const float uu = u_rand ? add_rn(u[j], jit) : u[j];
+        // single_jitter: one draw per ray; else u_rand [R, n_out+1] (NS PDFSampler: u + rand / num_bins)
+        const float uu = u_rand ? add_rn(u[j], per_sample ? u_rand[r * nb + j] / (float)nb : jit) : u[j];
         // searchsorted(cdf, uu, side="right"): first index with cdf[idx] > uu, over n_in+1 entries
         int lo = 0, hi = n_in + 1;
         while (lo < hi) {
@@ -421,8 +422,8 @@ int tn_sample_initial(const float *lin_bins, const float *t_rand, const float *n
     if (num_rays == 0) return TN_OK;
     const long long total = (long long)num_rays * (n + 1);
     hipLaunchKernelGGL(sample_initial_kernel, dim3(blocks_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                       lin_bins, t_rand, nears, fars, (long long)num_rays, n, uniform_spacing != 0, spacing_bins,
-                       eucl_bins);
+                       lin_bins, t_rand, nears, fars, (long long)num_rays, n, (uniform_spacing & 1) != 0, (uniform_spacing & 2) != 0,
+                       spacing_bins, eucl_bins);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }
@@ -449,7 +450,7 @@ int tn_sample_pdf(const float *weights, const float *existing_bins, const float 
     const size_t smem = (size_t)kWavesPerBlock * 2 * (n_in + 1) * sizeof(float);
     hipLaunchKernelGGL(sample_pdf_kernel, dim3(blocks_for(num_rays, kWavesPerBlock)), dim3(kBlock), smem,
                        (hipStream_t)stream, weights, existing_bins, u, u_rand, nears, fars, (long long)num_rays, n_in,
-                       n_out, uniform_spacing != 0, spacing_bins, eucl_bins);
+                       n_out, (uniform_spacing & 1) != 0, (uniform_spacing & 2) != 0, spacing_bins, eucl_bins);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

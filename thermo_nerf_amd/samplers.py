@@ -77,6 +77,28 @@ class LazyRaySamples(RaySamples):
         return f"LazyRaySamples(spacing_bins={tuple(self.spacing_bins.shape)}, uniform_spacing={self.uniform_spacing})"
 
 
+def draw_jitter(num_rays: int, counts: Sequence[int], single_jitter: bool, device) -> Tensor:
+    """The stratified draws of one training forward, in the layout tn_render_inputs.jitter takes: single_jitter -> [3,R]
+    (one draw per ray and level); otherwise the flat [R,P0+1] | [R,P1+1] | [R,S+1] of tn_render_config.per_sample_jitter
+    (one draw per bin edge) [NS SpacedSampler / PDFSampler.generate_ray_samples: rand((R,1)) vs rand((R,n+1))]."""
+    if single_jitter:
+        return torch.rand((len(counts), num_rays), dtype=torch.float32, device=device)
+    return torch.rand((num_rays * sum(n + 1 for n in counts),), dtype=torch.float32, device=device)
+
+
+def jitter_levels(jitter, num_rays: int, counts: Sequence[int], single_jitter: bool) -> Tuple[Tensor, List[Tensor]]:
+    """(flat device tensor, per-level views) of ``jitter``: a tensor in draw_jitter's layout, or a sequence of per-level
+    tensors ([R] / [R,1] single, [R,n+1] per edge) as the modular samplers take them."""
+    if not torch.is_tensor(jitter):
+        jitter = torch.cat([j.reshape(-1).to(torch.float32) for j in jitter])
+    flat = _hip.require_device_tensor(jitter.reshape(-1), "jitter")
+    sizes = [num_rays * (1 if single_jitter else n + 1) for n in counts]
+    if flat.numel() != sum(sizes):
+        raise ValueError("jitter holds %d draws; single_jitter=%s over %d rays and levels %s takes %d"
+                         % (flat.numel(), single_jitter, num_rays, tuple(counts), sum(sizes)))
+    return flat, list(torch.split(flat, sizes))
+
+
 class UniformLinDispPiecewiseSampler(nn.Module):
     """NS UniformLinDispPiecewiseSampler (the "piecewise" proposal_initial_sampler default)."""
 
@@ -94,11 +116,12 @@ class UniformLinDispPiecewiseSampler(nn.Module):
         assert n is not None and ray_bundle.nears is not None and ray_bundle.fars is not None
         o = _hip.require_device_tensor(ray_bundle.origins, "origins")
         R = o.shape[0]
+        draws = R if self.single_jitter else R * (n + 1)  # NS SpacedSampler: rand((R,1)) or rand((R,n+1))
         if self.train_stratified and self.training:
-            if not self.single_jitter:
-                raise NotImplementedError("kernels implement single_jitter=True (REF thermal_nerf_model.py:176)")
             if t_rand is None:
-                t_rand = torch.rand((R, 1), dtype=torch.float32, device=o.device)
+                t_rand = torch.rand((draws,), dtype=torch.float32, device=o.device)
+            if t_rand.numel() != draws:
+                raise ValueError("t_rand holds %d draws, single_jitter=%s takes %d" % (t_rand.numel(), self.single_jitter, draws))
         else:
             t_rand = None
         nears = _hip.require_device_tensor(ray_bundle.nears.reshape(-1), "nears")
@@ -109,7 +132,8 @@ class UniformLinDispPiecewiseSampler(nn.Module):
         _hip.check(
             lib.tn_sample_initial(linspace_bins(n, o.device).data_ptr(),
                                   None if t_rand is None else _hip.require_device_tensor(t_rand.reshape(-1), "t_rand").data_ptr(),
-                                  nears.data_ptr(), fars.data_ptr(), R, n, int(self.uniform_spacing), spacing.data_ptr(),
+                                  nears.data_ptr(), fars.data_ptr(), R, n,
+                                  int(self.uniform_spacing) | (0 if self.single_jitter else 2), spacing.data_ptr(),
                                   eucl.data_ptr(), _hip.current_stream()),
             "tn_sample_initial",
         )
@@ -143,11 +167,12 @@ class PDFSampler(nn.Module):
         w = _hip.require_device_tensor(weights[..., 0], "weights")
         R, n_in = w.shape
         jitter = self.train_stratified and self.training
+        draws = R if self.single_jitter else R * (n_out + 1)  # NS PDFSampler: rand((R,1)) or rand((R,n_out+1))
         if jitter:
-            if not self.single_jitter:
-                raise NotImplementedError("kernels implement single_jitter=True (REF thermal_nerf_model.py:176)")
             if u_rand is None:
-                u_rand = torch.rand((R, 1), dtype=torch.float32, device=w.device)
+                u_rand = torch.rand((draws,), dtype=torch.float32, device=w.device)
+            if u_rand.numel() != draws:
+                raise ValueError("u_rand holds %d draws, single_jitter=%s takes %d" % (u_rand.numel(), self.single_jitter, draws))
         else:
             u_rand = None
         existing = _hip.require_device_tensor(ray_samples.spacing_bins, "spacing_bins")
@@ -160,7 +185,8 @@ class PDFSampler(nn.Module):
         _hip.check(
             lib.tn_sample_pdf(w.data_ptr(), existing.data_ptr(), pdf_positions(n_out + 1, w.device, jitter).data_ptr(),
                               None if u_rand is None else _hip.require_device_tensor(u_rand.reshape(-1), "u_rand").data_ptr(),
-                              nears.data_ptr(), fars.data_ptr(), R, n_in, n_out, int(uniform), spacing.data_ptr(),
+                              nears.data_ptr(), fars.data_ptr(), R, n_in, n_out,
+                              int(uniform) | (0 if self.single_jitter else 2), spacing.data_ptr(),
                               eucl.data_ptr(), _hip.current_stream()),
             "tn_sample_pdf",
         )

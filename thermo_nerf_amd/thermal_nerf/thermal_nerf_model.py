@@ -26,7 +26,8 @@ from ..nerfacto_config.thermal_nerfacto import KERNEL_FAMILY, ThermalNerfactoMod
 from ..rays import RayBundle, RaySamples
 from ..rendered_image_modalities import RenderedImageModality
 from ..renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
-from ..samplers import ProposalNetworkSampler, UniformSampler, linspace_bins, pdf_positions, _samples_from_bins
+from ..samplers import (ProposalNetworkSampler, UniformSampler, draw_jitter, jitter_levels, linspace_bins, pdf_positions,
+                        _samples_from_bins)
 from ..scene import NearFarCollider, SceneBox, SceneContraction
 from .thermal_field import ThermalNerfactoTField
 from .thermal_field_head import FieldHeadNamesT
@@ -409,6 +410,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
         rc.kernel_family = KERNEL_FAMILY[cfg.kernel_family]
         rc.initial_sampler = int(self.proposal_sampler.initial_sampler.uniform_spacing)
         rc.sample_split = int(getattr(cfg, "sample_split", 0))
+        rc.per_sample_jitter = 0 if cfg.use_single_jitter else 1
 
         ins = _hip.tn_render_inputs()
         ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
@@ -419,8 +421,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
             cam = _hip.require_device_tensor(ray_bundle.camera_indices.reshape(-1).to(torch.int32), "camera_indices",
                                              torch.int32)
             if jitter is None:
-                jitter = torch.rand((3, R), dtype=torch.float32, device=dev)
-            jitter = _hip.require_device_tensor(jitter, "jitter")
+                jitter = draw_jitter(R, (P0, P1, S), bool(cfg.use_single_jitter), dev)
+            jitter = jitter_levels(jitter, R, (P0, P1, S), bool(cfg.use_single_jitter))[0]
         ins.camera_indices = _hip.ptr(cam)
         ins.jitter = _hip.ptr(jitter) if training else None
         ins.lin_bins0 = linspace_bins(P0, dev).data_ptr()

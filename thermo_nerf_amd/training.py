@@ -24,7 +24,7 @@ from torch import Tensor
 
 from . import _hip
 from .rays import RayBundle
-from .samplers import LazyRaySamples, linspace_bins, pdf_positions
+from .samplers import LazyRaySamples, draw_jitter, jitter_levels, linspace_bins, pdf_positions
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -420,6 +420,9 @@ class RenderTrain(torch.autograd.Function):
         fld = model.field.train_struct()
         anneal = float(model.proposal_sampler._anneal)
         uniform = int(model.proposal_sampler.initial_sampler.uniform_spacing)  # REF thermal_nerf_model.py:164-170
+        single = bool(cfg.use_single_jitter)  # REF thermal_nerf_model.py:176; False: one draw per bin edge
+        jitter, jit = jitter_levels(jitter, R, (P[0], P[1], S), single)
+        spacing_flags = uniform | (0 if single else 2)
 
         # ---- proposal levels ---------------------------------------------------------------------------------
         tapes: List[_LevelTape] = []
@@ -428,8 +431,8 @@ class RenderTrain(torch.autograd.Function):
             # the proposal networks take gradient this step: sample -> taped density -> weights, level by level
             spacing = _f32((R, P[0] + 1), dev)
             eucl = _f32((R, P[0] + 1), dev)
-            _hip.check(lib.tn_sample_initial(linspace_bins(P[0], dev).data_ptr(), jitter[0].data_ptr(), nears.data_ptr(),
-                                             fars.data_ptr(), R, P[0], uniform, spacing.data_ptr(), eucl.data_ptr(),
+            _hip.check(lib.tn_sample_initial(linspace_bins(P[0], dev).data_ptr(), jit[0].data_ptr(), nears.data_ptr(),
+                                             fars.data_ptr(), R, P[0], spacing_flags, spacing.data_ptr(), eucl.data_ptr(),
                                              _stream()),
                        "tn_sample_initial")
             counts = (P[1], S)
@@ -440,8 +443,8 @@ class RenderTrain(torch.autograd.Function):
                 w_in = t.weights if anneal == 1.0 else torch.pow(t.weights, anneal)
                 spacing, eucl = _f32((R, n_out + 1), dev), _f32((R, n_out + 1), dev)
                 _hip.check(lib.tn_sample_pdf(w_in.data_ptr(), t.spacing.data_ptr(), pdf_positions(n_out + 1, dev, True).data_ptr(),
-                                             jitter[lvl + 1].data_ptr(), nears.data_ptr(), fars.data_ptr(), R, P[lvl], n_out,
-                                             uniform, spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
+                                             jit[lvl + 1].data_ptr(), nears.data_ptr(), fars.data_ptr(), R, P[lvl], n_out,
+                                             spacing_flags, spacing.data_ptr(), eucl.data_ptr(), _stream()), "tn_sample_pdf")
         else:
             # nerfstudio evaluates the proposal densities under no_grad on these steps (5 of 6 after warm-up): no tape is
             # needed, so both levels run as ONE fused kernel (tn_proposal_sample_fwd, train-mode semantics)
@@ -449,6 +452,7 @@ class RenderTrain(torch.autograd.Function):
             rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = P[0], P[1], S
             rc.training, rc.pdf_anneal, rc.early_stop_transmittance, rc.kernel_family = 1, anneal, 0.0, 0
             rc.initial_sampler = uniform
+            rc.per_sample_jitter = 0 if single else 1
             ins = _hip.tn_render_inputs()
             ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
             ins.camera_indices, ins.jitter = cam.data_ptr(), jitter.data_ptr()
@@ -1033,9 +1037,9 @@ def interlevel_loss(weights_list: Sequence[Tensor], ray_samples_list: Sequence, 
 def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """Train-mode ``get_outputs`` with gradients [REF thermal_nerf_model.py:210-275]."""
     cfg = model.config
-    if cfg.num_proposal_iterations != 2 or cfg.predict_normals or not cfg.use_single_jitter:
-        raise NotImplementedError("the training path implements two proposal iterations, single jitter and no predicted "
-                                  "normals (the reference configuration)")
+    if cfg.num_proposal_iterations != 2 or cfg.predict_normals:
+        raise NotImplementedError("the training path implements two proposal iterations and no predicted normals (the "
+                                  "reference configuration)")
     # a fused optimizer may have stepped since the last forward without bumping parameter versions: the MFMA blob of the
     # fused taped forward (and every other derived copy) is rebuilt from the current weights
     model.invalidate_prepared()
@@ -1047,9 +1051,10 @@ def get_outputs_train(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = N
     if ray_bundle.camera_indices is None:
         raise AttributeError("Camera indices are not provided.")
     cam = _hip.require_device_tensor(ray_bundle.camera_indices.reshape(-1).to(torch.int32), "camera_indices", torch.int32)
+    counts = (*cfg.num_proposal_samples_per_ray, cfg.num_nerf_samples_per_ray)
     if jitter is None:
-        jitter = torch.rand((3, R), dtype=torch.float32, device=dev)
-    jitter = _hip.require_device_tensor(jitter, "jitter")
+        jitter = draw_jitter(R, counts, bool(cfg.use_single_jitter), dev)
+    jitter = jitter_levels(jitter, R, counts, bool(cfg.use_single_jitter))[0]
     sampler = model.proposal_sampler
     updated = sampler._steps_since_update > sampler.update_sched(sampler._step) or sampler._step < 10
     params = model.named_parameter_lists()[1]
