@@ -484,7 +484,9 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * in tiles of 64 consecutive samples, [ceil(N/64)][16 levels][64 samples][2] floats (the layout tn_field_bwd_fused reads;
  * allocate 32 * 64 * ceil(N/64) floats).  `ray_bias` [R,64] = mlp_head.0's
  * bias plus its SH(direction) and appearance-embedding columns applied to each ray's constants (tn_ray_head_fwd): the colour
- * layer sees them as a per-ray bias.
+ * layer sees them as a per-ray bias.  `base_out` (round 5; NULL to skip): mlp_base's 16 output rows [N,16] (raw density | geo
+ * features) as well — 64 B per sample more — which tn_field_bwd_fused's split form then reads in its two head launches
+ * instead of recomputing mlp_base there (pass the same pointer, or NULL to recompute).
  *
  * tn_field_bwd_fused recomputes the five hidden layers from `enc` in registers and runs their adjoints next to them (no
  * [N,64] activation ever touches HBM).  Inputs: enc / selector / rgb of the forward, ray_bias, the per-sample output
@@ -527,10 +529,11 @@ typedef struct tn_field_grads {
     float *th0_w, *th0_b, *th1_w, *th1_b, *thead_w, *thead_b;
 } tn_field_grads;
 int tn_field_fwd_train(const tn_thermal_field *field, const float *positions, const float *ray_bias, int64_t num_rays,
-                       int32_t n, float *enc, float *selector, float *density, float *rgb, float *thermal, void *stream);
+                       int32_t n, float *enc, float *selector, float *density, float *rgb, float *thermal, float *base_out,
+                       void *stream);
 size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n);
 int tn_field_bwd_fused(const tn_thermal_field *field, int64_t num_rays, int32_t n, const float *enc, const float *selector,
-                       const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
+                       const float *base_out, const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
                        const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split,
                        float *d_enc, float *d_ray_sum, const float *positions, float *d_positions,
                        const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream);

@@ -4,6 +4,7 @@ CPU oracle (oracle/hotpath.py + oracle/training.py), then the whole step (output
 Tolerances (written per test): the kernels are fp32 with a different summation order than torch's (tiled dots, atomics),
 so gradients are compared in relative L2 norm per tensor; values pointwise."""
 import copy
+import ctypes as C
 
 import numpy as np
 import pytest
@@ -586,6 +587,86 @@ def test_tape_free_step_equals_the_taped_step(kind, S, hw, split):
             assert g1[n].norm().item() < 1e-9, n
             continue
         assert rel(g1[n], g) <= 2e-4, f"{n}: rel {rel(g1[n], g):.2e} (|g| {g.norm().item():.2e})"
+
+
+@pytest.mark.parametrize("hw", [(12, 12), (7, 5), (1, 3)])  # 64-sample multiples, a ragged last tile, fewer samples than a tile
+@pytest.mark.parametrize("S", [48, 192, 5])
+def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
+    """config.store_base_output (round 5): tn_field_fwd_train's optional base_out [N,16] holds the rows tn_field_fwd_taped writes
+    as `bo` (same MFMA chain: bit for bit), and tn_field_bwd_fused's head launches reading them give the gradients of the launches
+    that recompute mlp_base from the hash features (fp32 summation order of mlp_base's products differs between the two)."""
+    from thermo_nerf_amd import _hip
+
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("stress", S, R_hw=hw)
+    lib = _hip.load()
+    R = o.shape[0]
+    N = R * S
+    dd, cc = d.to(DEV), cam.to(DEV).reshape(-1).to(torch.int32)
+    pos = (torch.rand(N, 3, generator=torch.Generator().manual_seed(5)) * 3 - 1.5).to(DEV)
+    fld = gm.field.c_struct(prepare=True, dense=False)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=DEV)
+    st = _hip.current_stream()
+    enc, sel, dens, h1, bo = f32(N, 32), f32(N), f32(N), f32(N, 64), f32(N, 16)
+    c1, c2, rgb, t1, t2, th = f32(N, 64), f32(N, 64), f32(N, 3), f32(N, 64), f32(N, 64), f32(N, 1)
+    _hip.check(lib.tn_field_fwd_taped(fld, pos.data_ptr(), dd.data_ptr(), cc.data_ptr(), R, S, enc.data_ptr(), sel.data_ptr(),
+                                      h1.data_ptr(), bo.data_ptr(), dens.data_ptr(), c1.data_ptr(), c2.data_ptr(), rgb.data_ptr(),
+                                      t1.data_ptr(), t2.data_ptr(), th.data_ptr(), st), "tn_field_fwd_taped")
+    ray_bias = f32(R, 64)
+    _hip.check(lib.tn_ray_head_fwd(fld, dd.data_ptr(), cc.data_ptr(), R, ray_bias.data_ptr(), st), "tn_ray_head_fwd")
+    enc_t, sel_t, dens_t, rgb_t, th_t = f32((N + 63) // 64 * 64, 32), f32(N), f32(N), f32(N, 3), f32(N, 1)
+    base = torch.full((N + 1, 16), 7.0, device=DEV)  # one guard row behind the last sample
+    _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc_t.data_ptr(), sel_t.data_ptr(),
+                                      dens_t.data_ptr(), rgb_t.data_ptr(), th_t.data_ptr(), base.data_ptr(), st), "tn_field_fwd_train")
+    torch.cuda.synchronize()
+    assert torch.equal(base[:N], bo) and bool((base[N] == 7.0).all())
+    rgb_n, th_n = f32(N, 3), f32(N, 1)
+    _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc_t.data_ptr(), sel_t.data_ptr(),
+                                      dens_t.data_ptr(), rgb_n.data_ptr(), th_n.data_ptr(), None, st), "tn_field_fwd_train")
+    assert torch.equal(rgb_n, rgb_t) and torch.equal(th_n, th_t)  # the optional store changes nothing else
+
+    g = torch.Generator().manual_seed(9)
+    g_rgb, g_th, g_dens = (torch.randn(N, 3, generator=g) * 1e-3).to(DEV), (torch.randn(N, generator=g) * 1e-3).to(DEV), \
+        (torch.randn(N, generator=g) * 1e-3).to(DEV)
+    names = {"base0": "field.mlp_base.mlp.layers.0", "base1": "field.mlp_base.mlp.layers.1", "head0": "field.mlp_head.layers.0",
+             "head1": "field.mlp_head.layers.1", "head2": "field.mlp_head.layers.2", "th0": "field.mlp_thermal.layers.0",
+             "th1": "field.mlp_thermal.layers.1", "thead": "field.field_head_thermal.net"}
+    ws = torch.empty(lib.tn_field_bwd_fused_workspace_bytes(R, S), dtype=torch.uint8, device=DEV)
+    res = {}
+    for stored in (True, False):
+        grads = {n: torch.zeros_like(p) for n, p in gm.named_parameters()}
+        gr = _hip.tn_field_grads()
+        for k, nme in names.items():
+            setattr(gr, k + "_w", grads[nme + ".weight"].data_ptr())
+            if k != "head0":
+                setattr(gr, k + "_b", grads[nme + ".bias"].data_ptr())
+        g_enc, g_ray, g_pos = f32(N, 32), torch.zeros(R, 64, device=DEV), f32(N, 3)
+        _hip.check(lib.tn_field_bwd_fused(fld, R, S, enc_t.data_ptr(), sel_t.data_ptr(), base.data_ptr() if stored else None,
+                                          ray_bias.data_ptr(), rgb_t.data_ptr(), g_rgb.data_ptr(), g_th.data_ptr(), g_dens.data_ptr(),
+                                          1, -15.0, 1, g_enc.data_ptr(), g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(),
+                                          C.byref(gr), ws.data_ptr(), ws.numel(), st), "tn_field_bwd_fused")
+        torch.cuda.synchronize()
+        res[stored] = dict({nme + sfx: grads[nme + sfx] for nme in names.values() for sfx in (".weight", ".bias") if nme + sfx in grads},
+                           g_enc=g_enc, g_ray=g_ray, g_pos=g_pos)
+    for k, want in res[False].items():
+        if want.norm().item() == 0.0:
+            assert res[True][k].norm().item() == 0.0, k
+            continue
+        assert rel(res[True][k], want) <= 2e-5, f"{k}: rel {rel(res[True][k], want):.2e}"
+
+    # the whole step with and without the kept rows
+    got = {}
+    for keep in (True, False):
+        gm2, _, _, o2, d2, jit2, cam2, batch2 = _train_setup("scene", S, R_hw=hw, store_base_output=keep)
+        assert gm2.config.store_base_output is keep
+        out, loss = _gpu_step(gm2, o2, d2, jit2, cam2, batch2)
+        got[keep] = (out, loss, {n: p.grad.clone() for n, p in gm2.named_parameters() if p.grad is not None})
+    for k in ("rgb", "thermal", "accumulation"):
+        assert torch.equal(got[True][0][k], got[False][0][k]), k
+    assert set(got[True][2]) == set(got[False][2])
+    for n, gw in got[False][2].items():
+        if gw.norm().item() < 1e-10:
+            continue
+        assert rel(got[True][2][n], gw) <= 2e-5, f"{n}: rel {rel(got[True][2][n], gw):.2e}"
 
 
 def test_trunc_exp_backward_clamp():

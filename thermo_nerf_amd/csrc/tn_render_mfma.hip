@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         // ---- mlp_base layer 1: [N,16] = raw density | geo ------------------------------------------------------------
         f32x4 G[4];
         base2_tiles(A, lds + OFF_B_BASE2, lane, h1, G);
-        if (TAPE) {
+        if (TAPE || a.bo) {  // (tn_field_fwd_train: optional — the head launches of tn_field_bwd_fused then skip mlp_base's recomputation)
 #pragma unroll
             for (int T = 0; T < 4; ++T) {
                 const long long row = row0 + 16 * T + (lane & 15);
@@ -1132,7 +1132,7 @@ int tn_field_fwd_taped(const tn_thermal_field *f, const float *positions, const 
 }
 
 int tn_field_fwd_train(const tn_thermal_field *f, const float *positions, const float *ray_bias, int64_t num_rays, int32_t n,
-                       float *enc, float *selector, float *density, float *rgb, float *thermal, void *stream) {
+                       float *enc, float *selector, float *density, float *rgb, float *thermal, float *base_out, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!f || !positions || !ray_bias || !enc || !selector || !density || !rgb || !thermal) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
@@ -1147,7 +1147,7 @@ int tn_field_fwd_train(const tn_thermal_field *f, const float *positions, const 
     a.sh_shifted = f->sh_shifted;
     a.positions = positions; a.dirs = nullptr; a.cam = nullptr;
     a.N = (long long)num_rays * n; a.n = n;
-    a.enc = enc; a.sel = selector; a.h1 = nullptr; a.bo = nullptr; a.density = density; a.c1 = nullptr; a.c2 = nullptr; a.rgb = rgb;
+    a.enc = enc; a.sel = selector; a.h1 = nullptr; a.bo = base_out; a.density = density; a.c1 = nullptr; a.c2 = nullptr; a.rgb = rgb;
     a.t1 = nullptr; a.t2 = nullptr; a.thermal = thermal; a.ray_bias = ray_bias;
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
     if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel<false>>(smem)) return TN_ERR_LAUNCH;

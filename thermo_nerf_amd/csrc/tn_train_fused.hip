@@ -193,6 +193,7 @@ struct FusedBwdArgs {
     long long N;
     int S, pass_thermal;
     const float *enc;       // hash features of the forward in its pass tiles [ceil(N/64)][16 levels][64][2]
+    const float *bo;        // [N,16] mlp_base's output rows as the forward computed them (head launches: no recomputation), or nullptr
     const float *sel;       // [N]
     const float *ray_bias;  // [R,64]  mlp_head.0 bias + its SH and appearance columns applied to the ray's constants
     const float *rgb;       // [N,3]   forward output (sigmoid)
@@ -251,9 +252,13 @@ __device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long
     tile_load_rest<MODE>(t, a, tile, n, sl);
 }
 
-template <int MODE, int WAVES>
+// STORED (head launches of the split form, round 5): mlp_base's 16 output rows come from the forward's copy (a.bo, 64 B per
+// sample) instead of being recomputed from the hash features — 48 of a head tile's ~330 MFMAs, the 128 B feature read and the
+// staging of mlp_base's weights go away.
+template <int MODE, int WAVES, bool STORED = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(FusedBwdArgs a) {
     constexpr bool COLOUR = (MODE & 1) != 0, THERMAL = (MODE & 2) != 0, BASE = (MODE & 4) != 0;
+    static_assert(!STORED || !BASE, "the mlp_base launch needs its hidden layer: it recomputes");
     constexpr int kThreads = WAVES * 64;
     using L = Lay<MODE>;
     constexpr int O_B0R = L::B0R, O_B1R = L::B1R, O_C0R = L::C0R, O_C1R = L::C1R, O_C1T = L::C1T, O_C2 = L::C2, O_T0R = L::T0R,
@@ -261,8 +266,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
                   O_BT1 = L::BT1, O_SCRATCH = L::SCRATCH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- stage the weights -----------------------------------------------------------------------------------------------
-    for (int e = threadIdx.x; e < 64 * 32; e += kThreads) lds[O_B0R + (e >> 5) * LD_B0 + (e & 31)] = a.b0w[e];
-    for (int e = threadIdx.x; e < 16 * 64; e += kThreads) lds[O_B1R + (e >> 6) * LD_64 + (e & 63)] = a.b1w[e];
+    if (!STORED) {
+        for (int e = threadIdx.x; e < 64 * 32; e += kThreads) lds[O_B0R + (e >> 5) * LD_B0 + (e & 31)] = a.b0w[e];
+        for (int e = threadIdx.x; e < 16 * 64; e += kThreads) lds[O_B1R + (e >> 6) * LD_64 + (e & 63)] = a.b1w[e];
+    }
     for (int e = threadIdx.x; e < 64 * 16; e += kThreads) {
         const int f = e >> 4, row = e & 15;
         if (COLOUR) lds[O_C0R + f * LD_G + row] = row >= 1 ? a.h0w[f * IN0 + 16 + row - 1] : 0.0f;
@@ -328,8 +335,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
     // only read by the first product of a tile, so the NEXT tile's features are requested into the same registers right after
     // it; the tile's remaining inputs (output gradients, rgb) are requested at the top of the tile, a hundred MFMAs before
     // they are read.  No load is issued right in front of its use.
+    f32x4 bo_next = zero4();  // STORED: the next tile's rows of bo, requested a tile ahead
+    auto load_bo = [&](long long t) {
+        const long long i = t * TS + n;
+        return ld4(a.bo + (i < a.N ? i : a.N - 1) * 16 + 4 * sl);
+    };
     if (tile < tiles) {
         if (BASE) tile_load<MODE>(cur, a, tile, n, sl);
+        else if (STORED) bo_next = load_bo(tile);
         else tile_load_enc(cur.e, a, tile, n, sl);
     }
 #if TN_BWD_POSE_PRIO
@@ -347,12 +360,18 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
         }
         // ---- recompute: mlp_base -------------------------------------------------------------------------------------------
         f32x4 h1[4];
+        f32x4 G[1];   // G[0][q] = row 4 sl + q of bo (0 = raw density, 1.. = geo), sample n
+        if (STORED) {
+            G[0] = bo_next;
+            if (tile + stride < tiles) bo_next = load_bo(tile + stride);
+        } else {
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob) h1[ob] = ld4(lds + O_BB0 + 16 * ob + 4 * sl);
-        mm<4, 2, LD_B0, false>(lds + O_B0R, n, sl, cur.e, h1);
-        if (!BASE && tile + stride < tiles) tile_load_enc(cur.e, a, tile + stride, n, sl);
-        f32x4 G[1] = {ld4(lds + O_BB1 + 4 * sl)};   // G[0][q] = row 4 sl + q of bo (0 = raw density, 1.. = geo), sample n
-        mm<1, 4, LD_64, true>(lds + O_B1R, n, sl, h1, G);
+            for (int ob = 0; ob < 4; ++ob) h1[ob] = ld4(lds + O_BB0 + 16 * ob + 4 * sl);
+            mm<4, 2, LD_B0, false>(lds + O_B0R, n, sl, cur.e, h1);
+            if (!BASE && tile + stride < tiles) tile_load_enc(cur.e, a, tile + stride, n, sl);
+            G[0] = ld4(lds + O_BB1 + 4 * sl);
+            mm<1, 4, LD_64, true>(lds + O_B1R, n, sl, h1, G);
+        }
         // adjoint of bo's 16 rows, same layout; the heads add their parts
         f32x4 dG[1] = {zero4()};
         if (MODE == 4) {  // split launches: the heads ran before
@@ -922,7 +941,7 @@ size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n) {
 }
 
 int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, const float *enc, const float *selector,
-                       const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
+                       const float *base_out, const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
                        const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split, float *d_enc,
                        float *d_ray_sum, const float *positions, float *d_positions, const tn_field_grads *grads, void *workspace,
                        size_t workspace_bytes, void *stream) {
@@ -943,7 +962,7 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     a.N = (long long)num_rays * n;
     a.S = n;
     a.pass_thermal = pass_thermal_gradients;
-    a.enc = enc; a.sel = selector; a.ray_bias = ray_bias; a.rgb = rgb; a.g_rgb = d_rgb; a.g_th = d_thermal; a.g_dens = d_density;
+    a.enc = enc; a.bo = base_out; a.sel = selector; a.ray_bias = ray_bias; a.rgb = rgb; a.g_rgb = d_rgb; a.g_th = d_thermal; a.g_dens = d_density;
     a.g_enc = d_enc; a.gsum = d_ray_sum;
     a.g = tn_make_grid(f->grid); a.space = f->space; a.positions = positions; a.d_pos = d_positions;
     float *slabs = reinterpret_cast<float *>(workspace);
@@ -998,13 +1017,18 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     if (!tn_ensure_dynamic_lds<field_bwd_fused_kernel<1, 8>>(smem1) || !tn_ensure_dynamic_lds<field_bwd_fused_kernel<2, 8>>(smem2) ||
         !tn_ensure_dynamic_lds<field_bwd_fused_kernel<4, 8>>(smem4))
         return TN_ERR_LAUNCH;
+    if (base_out && (!tn_ensure_dynamic_lds<field_bwd_fused_kernel<1, 8, true>>(smem1) ||
+                     !tn_ensure_dynamic_lds<field_bwd_fused_kernel<2, 8, true>>(smem2)))
+        return TN_ERR_LAUNCH;
     if (c) {
         a.g_bo_c = g_bo;
-        TN_TRY(launch(field_bwd_fused_kernel<1, 8>, 1, 8, smem1));
+        if (base_out) TN_TRY(launch(field_bwd_fused_kernel<1, 8, true>, 1, 8, smem1));
+        else TN_TRY(launch(field_bwd_fused_kernel<1, 8>, 1, 8, smem1));
     }
     if (t) {
         if (pass_thermal_gradients) a.g_bo_t = g_bo + (size_t)a.N * 16;
-        TN_TRY(launch(field_bwd_fused_kernel<2, 8>, 2, 8, smem2));
+        if (base_out) TN_TRY(launch(field_bwd_fused_kernel<2, 8, true>, 2, 8, smem2));
+        else TN_TRY(launch(field_bwd_fused_kernel<2, 8>, 2, 8, smem2));
     }
     return launch(field_bwd_fused_kernel<4, 8>, 4, 8, smem4);
 }

@@ -109,6 +109,10 @@ class NerfactoModelConfig:
     trunc_exp_clamp_min: float = -15.0
     """Lower clamp of trunc_exp's backward, g * exp(clamp(x, min, 15)): -15 = nerfstudio's activations.trunc_exp (taken from
     torch-ngp, two-sided); float("-inf") = upper clamp only (SURVEY A.3 [UNSURE])."""
+    store_base_output: bool = True
+    """Training (round 5, with tape_free_training and fused_backward_split): the forward also keeps mlp_base's 16 output rows
+    (64 B per sample, 54 floats per sample in all) and the backward's colour and thermal launches read them instead of
+    recomputing mlp_base from the hash features — 48 of a head tile's ~330 MFMAs (DESIGN §5.6)."""
     bucketed_table_scatter: bool = True
     """Training: hash-table gradient of the field's fine levels (scaling >= 200: levels 8-15) as bucketed records + LDS sums instead of
     global atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,

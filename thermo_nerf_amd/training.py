@@ -499,10 +499,15 @@ class RenderTrain(torch.autograd.Function):
             _hip.check(lib.tn_ray_head_fwd(fld, d.data_ptr(), cam.data_ptr(), R, ray_bias.data_ptr(), _stream()), "tn_ray_head_fwd")
             f.enc, f.sel, f.density = _f32(((N + 63) // 64 * 64, 32), dev), _f32((N,), dev), _f32((N,), dev)  # enc: 64-sample tiles
             rgb_s, th_s = _f32((N, 3), dev), _f32((N, 1), dev)
+            # (round 5) mlp_base's 16 output rows too, 64 B per sample: the backward's two head launches read them instead of
+            # recomputing mlp_base (the split form only: the one-launch form needs the hidden layer anyway)
+            keep_base = bool(getattr(cfg, "store_base_output", True)) and bool(getattr(cfg, "fused_backward_split", True))
+            base_out = _f32((N, 16), dev) if keep_base else None
             _hip.check(lib.tn_field_fwd_train(fused, f.pos.data_ptr(), ray_bias.data_ptr(), R, S, f.enc.data_ptr(), f.sel.data_ptr(),
-                                              f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _stream()),
+                                              f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _hip.ptr(base_out), _stream()),
                        "tn_field_fwd_train")
-            bo = ray_bias  # (slot reuse in ctx.acts: the tape-free backward reads (ray_bias, rgb_s))
+            bo = ray_bias  # (slot reuse in ctx.acts: the tape-free backward reads (ray_bias, rgb_s) ...
+            h1 = base_out  # ... and mlp_base's output rows, if kept)
         elif fused is not None and cfg.fused_train_forward:
             # the whole field forward of the level in one launch; every tensor of the tape in the layout the adjoints read
             f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
@@ -659,7 +664,7 @@ class RenderTrain(torch.autograd.Function):
             g_ray = arena.zeros((R, 64)) if g_rgb_s is not None else None
             ws = _fused_bwd_workspace(dev, R, S)
             g_pos = _f32((N, 3), dev) if ray_grads else None  # d loss / d sample position, written by the mlp_base launch
-            _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), self_bias.data_ptr(), rgb_s.data_ptr(),
+            _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), _hip.ptr(h1), self_bias.data_ptr(), rgb_s.data_ptr(),
                                               _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
                                               1 if model.field.pass_thermal_gradients else 0, exp_min,
                                               1 if getattr(cfg, "fused_backward_split", True) else 0, g_enc.data_ptr(),
