@@ -592,7 +592,9 @@ def test_tape_free_step_equals_the_taped_step(kind, S, hw, split):
 @pytest.mark.parametrize("hw", [(12, 12), (7, 5), (1, 3)])  # 64-sample multiples, a ragged last tile, fewer samples than a tile
 @pytest.mark.parametrize("S", [48, 192, 5])
 def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
-    """config.store_base_output (round 5): tn_field_fwd_train's optional base_out [N,16] holds the rows tn_field_fwd_taped writes
+    """config.backward_bf16_pieces (round 5): tn_field_bwd_fused's split form 2 — the heads' 64 x 64 products as six products of
+    exact bf16 pieces — against form 1 (fp32 MFMA) on the same inputs, and
+    config.store_base_output (round 5): tn_field_fwd_train's optional base_out [N,16] holds the rows tn_field_fwd_taped writes
     as `bo` (same MFMA chain: bit for bit), and tn_field_bwd_fused's head launches reading them give the gradients of the launches
     that recompute mlp_base from the hash features (fp32 summation order of mlp_base's products differs between the two)."""
     from thermo_nerf_amd import _hip
@@ -632,7 +634,7 @@ def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
              "th1": "field.mlp_thermal.layers.1", "thead": "field.field_head_thermal.net"}
     ws = torch.empty(lib.tn_field_bwd_fused_workspace_bytes(R, S), dtype=torch.uint8, device=DEV)
     res = {}
-    for stored in (True, False):
+    for stored, form in ((True, 1), (False, 1), (True, 2)):  # form 2: the heads' 64 x 64 products as six bf16-piece products
         grads = {n: torch.zeros_like(p) for n, p in gm.named_parameters()}
         gr = _hip.tn_field_grads()
         for k, nme in names.items():
@@ -642,31 +644,36 @@ def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
         g_enc, g_ray, g_pos = f32(N, 32), torch.zeros(R, 64, device=DEV), f32(N, 3)
         _hip.check(lib.tn_field_bwd_fused(fld, R, S, enc_t.data_ptr(), sel_t.data_ptr(), base.data_ptr() if stored else None,
                                           ray_bias.data_ptr(), rgb_t.data_ptr(), g_rgb.data_ptr(), g_th.data_ptr(), g_dens.data_ptr(),
-                                          1, -15.0, 1, g_enc.data_ptr(), g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(),
+                                          1, -15.0, form, g_enc.data_ptr(), g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(),
                                           C.byref(gr), ws.data_ptr(), ws.numel(), st), "tn_field_bwd_fused")
         torch.cuda.synchronize()
-        res[stored] = dict({nme + sfx: grads[nme + sfx] for nme in names.values() for sfx in (".weight", ".bias") if nme + sfx in grads},
+        res[(stored, form)] = dict({nme + sfx: grads[nme + sfx] for nme in names.values() for sfx in (".weight", ".bias") if nme + sfx in grads},
                            g_enc=g_enc, g_ray=g_ray, g_pos=g_pos)
-    for k, want in res[False].items():
-        if want.norm().item() == 0.0:
-            assert res[True][k].norm().item() == 0.0, k
-            continue
-        assert rel(res[True][k], want) <= 2e-5, f"{k}: rel {rel(res[True][k], want):.2e}"
+    for k, want in res[(False, 1)].items():
+        for other in ((True, 1), (True, 2)):
+            if want.norm().item() == 0.0:
+                assert res[other][k].norm().item() == 0.0, k
+                continue
+            assert rel(res[other][k], want) <= 2e-5, f"{k} {other}: rel {rel(res[other][k], want):.2e}"
+    # the bf16-piece products are fp32 products up to the rounding of a product: the two stored-base forms differ by summation order only
+    assert any(not torch.equal(res[(True, 1)][k], res[(True, 2)][k]) for k in res[(True, 1)])  # (form 2 really is another kernel)
 
     # the whole step with and without the kept rows
     got = {}
-    for keep in (True, False):
-        gm2, _, _, o2, d2, jit2, cam2, batch2 = _train_setup("scene", S, R_hw=hw, store_base_output=keep)
-        assert gm2.config.store_base_output is keep
+    for keep, pieces in ((True, True), (True, False), (False, False)):
+        gm2, _, _, o2, d2, jit2, cam2, batch2 = _train_setup("scene", S, R_hw=hw, store_base_output=keep, backward_bf16_pieces=pieces)
+        assert gm2.config.store_base_output is keep and gm2.config.backward_bf16_pieces is pieces
         out, loss = _gpu_step(gm2, o2, d2, jit2, cam2, batch2)
-        got[keep] = (out, loss, {n: p.grad.clone() for n, p in gm2.named_parameters() if p.grad is not None})
-    for k in ("rgb", "thermal", "accumulation"):
-        assert torch.equal(got[True][0][k], got[False][0][k]), k
-    assert set(got[True][2]) == set(got[False][2])
-    for n, gw in got[False][2].items():
-        if gw.norm().item() < 1e-10:
-            continue
-        assert rel(got[True][2][n], gw) <= 2e-5, f"{n}: rel {rel(got[True][2][n], gw):.2e}"
+        got[(keep, pieces)] = (out, loss, {n: p.grad.clone() for n, p in gm2.named_parameters() if p.grad is not None})
+    want = got[(False, False)]
+    for other in ((True, True), (True, False)):
+        for k in ("rgb", "thermal", "accumulation"):
+            assert torch.equal(got[other][0][k], want[0][k]), k
+        assert set(got[other][2]) == set(want[2])
+        for n, gw in want[2].items():
+            if gw.norm().item() < 1e-10:
+                continue
+            assert rel(got[other][2][n], gw) <= 2e-5, f"{n} {other}: rel {rel(got[other][2][n], gw):.2e}"
 
 
 def test_trunc_exp_backward_clamp():
@@ -1225,7 +1232,7 @@ def test_config3_step_size_fresh_batches_against_the_atomic_single_stream_taped_
                 # the same table entries touched.  (Up to a handful of entries whose contributions cancel to exactly 0 in one
                 # summation order and to a denormal-sized rest in the other: 786 k samples x 8 corners meet in few coarse entries.)
                 differ = (g1[n] == 0) != (g == 0)
-                assert int(differ.sum()) <= 16, (n, int(differ.sum()))
+                assert int(differ.sum()) <= max(64, int((g != 0).sum()) // 1000), (n, int(differ.sum()))
                 if differ.any():
                     assert float(torch.maximum(g1[n].abs(), g.abs())[differ].max()) <= 1e-9 * float(g.abs().max()), n
         print(f"step {step}: worst relative gradient difference " + ", ".join(f"{n.split('.')[-3:]}: {v:.1e}" for n, v in

@@ -52,19 +52,22 @@ constexpr int LDT = 68;  // row stride of the transpose buffers (16-byte row wri
 // 16-lane group (rows n, columns 4 sl ..) fall on 64 distinct banks.  The narrow layers' W^T fragments are read 4 bytes at a
 // time from the R form (2-way conflicts on 80 of a tile's ~700 reads).
 constexpr int LD_B0 = 40, LD_64 = 72, LD_G = 24;
-template <int MODE>
+// B6 (round 5): the 64 x 64 layers as MFMA fragments of their three bf16 pieces, [ob 4][k pair 2][piece 3][lane 64] x 16 bytes
+constexpr int FRAG_64 = 4 * 2 * 3 * 64 * 4;
+template <int MODE, bool B6 = false>
 struct Lay {  // a launch stages only the matrices its branches read
     static constexpr bool C = (MODE & 1) != 0, T = (MODE & 2) != 0;
+    static constexpr int M64 = B6 ? FRAG_64 : 64 * LD_64;
     static constexpr int B0R = 0;                              // mlp_base.0      [64][40]
     static constexpr int B1R = B0R + 64 * LD_B0;               // mlp_base.1      [16][72]
     static constexpr int C0R = B1R + 16 * LD_64;               // mlp_head.0, columns of bo's rows: [64][24], column 0 (raw density) zero
     static constexpr int C1R = C0R + (C ? 64 * LD_G : 0);      // mlp_head.1      [64][72]
-    static constexpr int C1T = C1R + (C ? 64 * LD_64 : 0);     //   transposed    [64][72]
-    static constexpr int C2 = C1T + (C ? 64 * LD_64 : 0);      // mlp_head.2      [3][64]
+    static constexpr int C1T = C1R + (C ? M64 : 0);            //   transposed    [64][72]
+    static constexpr int C2 = C1T + (C ? M64 : 0);             // mlp_head.2      [3][64]
     static constexpr int T0R = C2 + (C ? 3 * 64 : 0);          // mlp_thermal.0   [64][24]
     static constexpr int T1R = T0R + (T ? 64 * LD_G : 0);      // mlp_thermal.1   [64][72]
-    static constexpr int T1T = T1R + (T ? 64 * LD_64 : 0);     //   transposed    [64][72]
-    static constexpr int TH = T1T + (T ? 64 * LD_64 : 0);      // thermal head    [64]
+    static constexpr int T1T = T1R + (T ? M64 : 0);            //   transposed    [64][72]
+    static constexpr int TH = T1T + (T ? M64 : 0);             // thermal head    [64]
     static constexpr int BB0 = TH + (T ? 64 : 0);              // biases: base.0 [64] | base.1 [16] | head.1 [64] | thermal.0 [64] | thermal.1 [64]
     static constexpr int BB1 = BB0 + 64;
     static constexpr int BC1 = BB1 + 16;
@@ -97,6 +100,10 @@ static_assert(IMG_FLOATS <= Lay<4>::SCRATCH + 8 * SCRATCH_PER_WAVE, "slab image 
 static_assert((Lay<7>::SCRATCH + 4 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024, "LDS budget (whole field, 4 waves)");
 static_assert((Lay<1>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024 && (Lay<2>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024,
               "LDS budget (split, 8 waves)");
+static_assert((Lay<1, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024 && (Lay<2, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024,
+              "LDS budget (split, bf16 pieces, 8 waves)");
+static_assert(Lay<1, true>::C1R % 4 == 0 && Lay<1, true>::C1T % 4 == 0 && Lay<2, true>::T1R % 4 == 0 && Lay<2, true>::T1T % 4 == 0,
+              "fragment arrays are read 16 bytes at a time");
 
 constexpr int kFusedBlocks = 256;  // one persistent block per CU
 
@@ -157,6 +164,76 @@ __device__ __forceinline__ void mm_t_from_r(const float *W, int n, int sl, const
         for (int ib = 0; ib < NIB; ++ib) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) MFMA16(out[ib], wl[(16 * kb + q) * LD + 16 * ib], d[kb][q]);
+        }
+    }
+}
+
+// ---- the 64 x 64 products on the bf16 matrix cores, fp32-exact (round 5) ------------------------------------------------------------
+// Every operand as three bf16 pieces (a = p1 + p2 + p3 exactly, tn_render_h3.hip's BF16x6), the product as the six piece products
+// above 2^-24, on v_mfma_f32_16x16x32_bf16: 16 384 flop in 16 cycles where v_mfma_f32_16x16x4_f32 does 2 048 in 32.  K = 32 spans
+// two 16-feature blocks; the k order is free as long as A and B agree, so lane (n, sl) supplies k = 8 sl + j as feature
+// 16 (2 kp) + 4 sl + j (j < 4) | 16 (2 kp + 1) + 4 sl + j - 4: its C/D registers of the two blocks, as they are.  The weights are
+// split once per block into MFMA fragments [ob][kp][piece][lane] of 8 bf16 (one ds_read_b128 each).
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned (&pk)[3]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 v = {x0, x1};
+    pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));  // RNE, one v_cvt_pk_bf16_f32
+    const f2 r1 = {x0 - __uint_as_float(pk[0] << 16), x1 - __uint_as_float(pk[0] & 0xffff0000u)};  // exact
+    pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, b2));
+    const f2 r2 = {r1[0] - __uint_as_float(pk[1] << 16), r1[1] - __uint_as_float(pk[1] & 0xffff0000u)};  // exact, 8 bits left
+    pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
+}
+// stage W (R form source: element (o, i) = w[o * 64 + i]; TRANSPOSED: the fragments of W^T) as fragments at `dst`
+template <bool TRANSPOSED>
+__device__ __forceinline__ void stage_frag64(float *dst, const float *__restrict__ w, int tid, int threads) {
+    u32x4 *d = reinterpret_cast<u32x4 *>(dst);
+    for (int e = tid; e < 4 * 2 * 64; e += threads) {  // (ob, kp, lane)
+        const int lane = e & 63, kp = (e >> 6) & 1, ob = e >> 7, n = lane & 15, sl = lane >> 4;
+        const int row = 16 * ob + n;
+        unsigned pk[4][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int k0 = 16 * (2 * kp + h) + 4 * sl + 2 * pr;
+                const float x0 = TRANSPOSED ? w[k0 * 64 + row] : w[row * 64 + k0];
+                const float x1 = TRANSPOSED ? w[(k0 + 1) * 64 + row] : w[row * 64 + k0 + 1];
+                split_pair_bf16(x0, x1, pk[2 * h + pr]);
+            }
+        }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) d[((ob * 2 + kp) * 3 + pc) * 64 + lane] = u32x4{pk[0][pc], pk[1][pc], pk[2][pc], pk[3][pc]};
+    }
+}
+#define MFMA_B6(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), (acc), 0, 0, 0)
+// out[ob] += W . act(in), 64 inputs, 64 outputs
+template <bool RELU_IN>
+__device__ __forceinline__ void mm64_b6(const float *W, int lane, const f32x4 *in, f32x4 *out) {
+    const u32x4 *wf = reinterpret_cast<const u32x4 *>(W) + lane;
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+        const f32x4 x0 = RELU_IN ? relu4(in[2 * kp]) : in[2 * kp], x1 = RELU_IN ? relu4(in[2 * kp + 1]) : in[2 * kp + 1];
+        unsigned pk[4][3];
+        split_pair_bf16(x0[0], x0[1], pk[0]);
+        split_pair_bf16(x0[2], x0[3], pk[1]);
+        split_pair_bf16(x1[0], x1[1], pk[2]);
+        split_pair_bf16(x1[2], x1[3], pk[3]);
+        u32x4 b[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) b[pc] = u32x4{pk[0][pc], pk[1][pc], pk[2][pc], pk[3][pc]};
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const u32x4 a0 = wf[((ob * 2 + kp) * 3 + 0) * 64], a1 = wf[((ob * 2 + kp) * 3 + 1) * 64], a2 = wf[((ob * 2 + kp) * 3 + 2) * 64];
+            // small terms first
+            MFMA_B6(out[ob], a0, b[2]);
+            MFMA_B6(out[ob], a2, b[0]);
+            MFMA_B6(out[ob], a1, b[1]);
+            MFMA_B6(out[ob], a0, b[1]);
+            MFMA_B6(out[ob], a1, b[0]);
+            MFMA_B6(out[ob], a0, b[0]);
         }
     }
 }
@@ -255,12 +332,15 @@ __device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long
 // STORED (head launches of the split form, round 5): mlp_base's 16 output rows come from the forward's copy (a.bo, 64 B per
 // sample) instead of being recomputed from the hash features — 48 of a head tile's ~330 MFMAs, the 128 B feature read and the
 // staging of mlp_base's weights go away.
-template <int MODE, int WAVES, bool STORED = false>
+// B6 (head launches, round 5): the four 64 x 64 products of a head (forward and dx of its second layer) on the bf16 matrix cores as
+// fp32-exact six-product splits (mm64_b6); the weight-gradient products (K = the tile's 16 samples) stay on the fp32 MFMA.
+template <int MODE, int WAVES, bool STORED = false, bool B6 = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(FusedBwdArgs a) {
     constexpr bool COLOUR = (MODE & 1) != 0, THERMAL = (MODE & 2) != 0, BASE = (MODE & 4) != 0;
     static_assert(!STORED || !BASE, "the mlp_base launch needs its hidden layer: it recomputes");
+    static_assert(!B6 || !BASE, "bf16 pieces: the head launches only");
     constexpr int kThreads = WAVES * 64;
-    using L = Lay<MODE>;
+    using L = Lay<MODE, B6>;
     constexpr int O_B0R = L::B0R, O_B1R = L::B1R, O_C0R = L::C0R, O_C1R = L::C1R, O_C1T = L::C1T, O_C2 = L::C2, O_T0R = L::T0R,
                   O_T1R = L::T1R, O_T1T = L::T1T, O_TH = L::TH, O_BB0 = L::BB0, O_BB1 = L::BB1, O_BC1 = L::BC1, O_BT0 = L::BT0,
                   O_BT1 = L::BT1, O_SCRATCH = L::SCRATCH;
@@ -275,17 +355,28 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
         if (COLOUR) lds[O_C0R + f * LD_G + row] = row >= 1 ? a.h0w[f * IN0 + 16 + row - 1] : 0.0f;
         if (THERMAL) lds[O_T0R + f * LD_G + row] = row >= 1 ? a.t0w[f * GF + row - 1] : 0.0f;
     }
-    for (int e = threadIdx.x; e < 64 * 64; e += kThreads) {
-        const int o = e >> 6, i = e & 63;
+    if (B6) {
         if (COLOUR) {
-            const float v = a.h1w[e];
-            lds[O_C1R + o * LD_64 + i] = v;
-            lds[O_C1T + i * LD_64 + o] = v;
+            stage_frag64<false>(lds + O_C1R, a.h1w, threadIdx.x, kThreads);
+            stage_frag64<true>(lds + O_C1T, a.h1w, threadIdx.x, kThreads);
         }
         if (THERMAL) {
-            const float v = a.t1w[e];
-            lds[O_T1R + o * LD_64 + i] = v;
-            lds[O_T1T + i * LD_64 + o] = v;
+            stage_frag64<false>(lds + O_T1R, a.t1w, threadIdx.x, kThreads);
+            stage_frag64<true>(lds + O_T1T, a.t1w, threadIdx.x, kThreads);
+        }
+    } else {
+        for (int e = threadIdx.x; e < 64 * 64; e += kThreads) {
+            const int o = e >> 6, i = e & 63;
+            if (COLOUR) {
+                const float v = a.h1w[e];
+                lds[O_C1R + o * LD_64 + i] = v;
+                lds[O_C1T + i * LD_64 + o] = v;
+            }
+            if (THERMAL) {
+                const float v = a.t1w[e];
+                lds[O_T1R + o * LD_64 + i] = v;
+                lds[O_T1T + i * LD_64 + o] = v;
+            }
         }
     }
     if (COLOUR)
@@ -387,7 +478,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             f32x4 c2[4];
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) c2[ob] = ld4(lds + O_BC1 + 16 * ob + 4 * sl);
-            mm<4, 4, LD_64, true>(lds + O_C1R, n, sl, c1, c2);
+            if (B6) mm64_b6<true>(lds + O_C1R, lane, c1, c2);
+            else mm<4, 4, LD_64, true>(lds + O_C1R, n, sl, c1, c2);
             float d3[3];  // d(rgb pre-activation) = g_rgb . rgb (1 - rgb)
 #pragma unroll
             for (int c = 0; c < 3; ++c) d3[c] = cur.g_rgb[c] * (cur.rgb[c] * (1.0f - cur.rgb[c]));
@@ -420,7 +512,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             rows_store<4, false>(D, n, sl, d2);
             rows_store<4, true>(X, n, sl, c1);
             f32x4 d1[4] = {zero4(), zero4(), zero4(), zero4()};
-            mm<4, 4, LD_64, false>(lds + O_C1T, n, sl, d2, d1);
+            if (B6) mm64_b6<false>(lds + O_C1T, lane, d2, d1);
+            else mm<4, 4, LD_64, false>(lds + O_C1T, n, sl, d2, d1);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
 #pragma unroll
@@ -471,7 +564,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
                 t2[ob] = ld4(lds + O_BT1 + 16 * ob + 4 * sl);
             }
             mm<4, 1, LD_G, false>(lds + O_T0R, n, sl, G, t1);
-            mm<4, 4, LD_64, true>(lds + O_T1R, n, sl, t1, t2);
+            if (B6) mm64_b6<true>(lds + O_T1R, lane, t1, t2);
+            else mm<4, 4, LD_64, true>(lds + O_T1R, n, sl, t1, t2);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
 #pragma unroll
@@ -496,7 +590,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             rows_store<4, false>(D, n, sl, d2);
             rows_store<4, true>(X, n, sl, t1);
             f32x4 d1[4] = {zero4(), zero4(), zero4(), zero4()};
-            mm<4, 4, LD_64, false>(lds + O_T1T, n, sl, d2, d1);
+            if (B6) mm64_b6<false>(lds + O_T1T, lane, d2, d1);
+            else mm<4, 4, LD_64, false>(lds + O_T1T, n, sl, d2, d1);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
 #pragma unroll
@@ -1017,17 +1112,24 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     if (!tn_ensure_dynamic_lds<field_bwd_fused_kernel<1, 8>>(smem1) || !tn_ensure_dynamic_lds<field_bwd_fused_kernel<2, 8>>(smem2) ||
         !tn_ensure_dynamic_lds<field_bwd_fused_kernel<4, 8>>(smem4))
         return TN_ERR_LAUNCH;
+    constexpr size_t smem1b = (size_t)(Lay<1, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * sizeof(float);
+    constexpr size_t smem2b = (size_t)(Lay<2, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * sizeof(float);
+    const bool b6 = split == 2 && base_out;  // (the bf16-piece products come with the stored-base head launches only)
     if (base_out && (!tn_ensure_dynamic_lds<field_bwd_fused_kernel<1, 8, true>>(smem1) ||
-                     !tn_ensure_dynamic_lds<field_bwd_fused_kernel<2, 8, true>>(smem2)))
+                     !tn_ensure_dynamic_lds<field_bwd_fused_kernel<2, 8, true>>(smem2) ||
+                     !tn_ensure_dynamic_lds<field_bwd_fused_kernel<1, 8, true, true>>(smem1b) ||
+                     !tn_ensure_dynamic_lds<field_bwd_fused_kernel<2, 8, true, true>>(smem2b)))
         return TN_ERR_LAUNCH;
     if (c) {
         a.g_bo_c = g_bo;
-        if (base_out) TN_TRY(launch(field_bwd_fused_kernel<1, 8, true>, 1, 8, smem1));
+        if (b6) TN_TRY(launch(field_bwd_fused_kernel<1, 8, true, true>, 1, 8, smem1b));
+        else if (base_out) TN_TRY(launch(field_bwd_fused_kernel<1, 8, true>, 1, 8, smem1));
         else TN_TRY(launch(field_bwd_fused_kernel<1, 8>, 1, 8, smem1));
     }
     if (t) {
         if (pass_thermal_gradients) a.g_bo_t = g_bo + (size_t)a.N * 16;
-        if (base_out) TN_TRY(launch(field_bwd_fused_kernel<2, 8, true>, 2, 8, smem2));
+        if (b6) TN_TRY(launch(field_bwd_fused_kernel<2, 8, true, true>, 2, 8, smem2b));
+        else if (base_out) TN_TRY(launch(field_bwd_fused_kernel<2, 8, true>, 2, 8, smem2));
         else TN_TRY(launch(field_bwd_fused_kernel<2, 8>, 2, 8, smem2));
     }
     return launch(field_bwd_fused_kernel<4, 8>, 4, 8, smem4);

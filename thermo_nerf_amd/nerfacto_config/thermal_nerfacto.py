@@ -113,6 +113,11 @@ class NerfactoModelConfig:
     """Training (round 5, with tape_free_training and fused_backward_split): the forward also keeps mlp_base's 16 output rows
     (64 B per sample, 54 floats per sample in all) and the backward's colour and thermal launches read them instead of
     recomputing mlp_base from the hash features — 48 of a head tile's ~330 MFMAs (DESIGN §5.6)."""
+    backward_bf16_pieces: bool = True
+    """Training (round 5, with store_base_output): the 64 x 64 products of the backward's two head launches — the second layer's
+    recomputed forward and its dx — on the bf16 matrix cores as six-product splits of three exact bf16 pieces per operand
+    (fp32's rounding size per product, the arithmetic of mlp_precision="bf16x6"); the weight-gradient products stay on the fp32
+    MFMA (DESIGN §5.6).  False: every product on v_mfma_f32_16x16x4_f32."""
     bucketed_table_scatter: bool = True
     """Training: hash-table gradient of the field's fine levels (scaling >= 200: levels 8-15) as bucketed records + LDS sums instead of
     global atomics (tn_hash_encode_bwd_sorted), the coarse levels with the atomics: 5.03 against 5.25 ms per step at S=192,

@@ -663,11 +663,13 @@ class RenderTrain(torch.autograd.Function):
                     setattr(gr, key + "_b", zeros(name + ".bias").data_ptr())
             g_ray = arena.zeros((R, 64)) if g_rgb_s is not None else None
             ws = _fused_bwd_workspace(dev, R, S)
+            # 0: one launch; 1: colour head | thermal head | mlp_base; 2: the same with the heads' 64 x 64 products as bf16 pieces
+            split_form = 0 if not getattr(cfg, "fused_backward_split", True) else (2 if getattr(cfg, "backward_bf16_pieces", True) else 1)
             g_pos = _f32((N, 3), dev) if ray_grads else None  # d loss / d sample position, written by the mlp_base launch
             _hip.check(lib.tn_field_bwd_fused(fld, R, S, f.enc.data_ptr(), f.sel.data_ptr(), _hip.ptr(h1), self_bias.data_ptr(), rgb_s.data_ptr(),
                                               _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
                                               1 if model.field.pass_thermal_gradients else 0, exp_min,
-                                              1 if getattr(cfg, "fused_backward_split", True) else 0, g_enc.data_ptr(),
+                                              split_form, g_enc.data_ptr(),
                                               _hip.ptr(g_ray), f.pos.data_ptr() if ray_grads else None, _hip.ptr(g_pos),
                                               C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
                        "tn_field_bwd_fused")

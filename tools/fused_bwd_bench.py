@@ -76,7 +76,7 @@ def main():
     for keep in (False, True):
         t = time(fwd, keep)
         print(f"N {N}: tn_field_fwd_train base_out={keep} {t:8.1f} us  ({flops / t / 1e6:.1f} TF of the 1x forward)")
-    for split, stored in ((1, False), (1, True), (0, False)):
+    for split, stored in ((1, False), (1, True), (2, True), (0, False)):
         t = time(bwd, split, stored)
         print(f"N {N}: tn_field_bwd_fused split={split} stored_base={stored} {t:8.1f} us  ({3 * flops / t / 1e6:.1f} TF of recompute + dx + dW = 3x forward)")
 
