@@ -486,7 +486,9 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * bias plus its SH(direction) and appearance-embedding columns applied to each ray's constants (tn_ray_head_fwd): the colour
  * layer sees them as a per-ray bias.  `base_out` (round 5; NULL to skip): mlp_base's 16 output rows [N,16] (raw density | geo
  * features) as well — 64 B per sample more — which tn_field_bwd_fused's split form then reads in its two head launches
- * instead of recomputing mlp_base there (pass the same pointer, or NULL to recompute).
+ * instead of recomputing mlp_base there (pass the same pointer, or NULL to recompute).  `position_jacobian` (round 5; NULL to
+ * skip; 96 * 64 * ceil(N/64) floats): d hash features / d normalised position, [ceil(N/64)][16 levels][3 axes][64 samples][2] —
+ * the corner values are in registers in the forward; handed to tn_field_bwd_fused, its d_positions needs no table read.
  *
  * tn_field_bwd_fused recomputes the five hidden layers from `enc` in registers and runs their adjoints next to them (no
  * [N,64] activation ever touches HBM).  Inputs: enc / selector / rgb of the forward, ray_bias, the per-sample output
@@ -532,13 +534,13 @@ typedef struct tn_field_grads {
 } tn_field_grads;
 int tn_field_fwd_train(const tn_thermal_field *field, const float *positions, const float *ray_bias, int64_t num_rays,
                        int32_t n, float *enc, float *selector, float *density, float *rgb, float *thermal, float *base_out,
-                       void *stream);
+                       float *position_jacobian, void *stream);
 size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n);
 int tn_field_bwd_fused(const tn_thermal_field *field, int64_t num_rays, int32_t n, const float *enc, const float *selector,
                        const float *base_out, const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
                        const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split,
-                       float *d_enc, float *d_ray_sum, const float *positions, float *d_positions,
-                       const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+                       float *d_enc, float *d_ray_sum, const float *positions, const float *position_jacobian,
+                       float *d_positions, const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
 
 /* NS scale_gradients_by_distance_squared [REF thermal_nerf_model.py:228-231, use_gradient_scaling]: the forward is the
  * identity; in the backward the gradient of EVERY field output of a sample (density [n], rgb [n,3], thermal [n]; any may

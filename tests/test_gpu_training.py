@@ -618,13 +618,22 @@ def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
     enc_t, sel_t, dens_t, rgb_t, th_t = f32((N + 63) // 64 * 64, 32), f32(N), f32(N), f32(N, 3), f32(N, 1)
     base = torch.full((N + 1, 16), 7.0, device=DEV)  # one guard row behind the last sample
     _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc_t.data_ptr(), sel_t.data_ptr(),
-                                      dens_t.data_ptr(), rgb_t.data_ptr(), th_t.data_ptr(), base.data_ptr(), st), "tn_field_fwd_train")
+                                      dens_t.data_ptr(), rgb_t.data_ptr(), th_t.data_ptr(), base.data_ptr(), None, st), "tn_field_fwd_train")
     torch.cuda.synchronize()
     assert torch.equal(base[:N], bo) and bool((base[N] == 7.0).all())
     rgb_n, th_n = f32(N, 3), f32(N, 1)
     _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc_t.data_ptr(), sel_t.data_ptr(),
-                                      dens_t.data_ptr(), rgb_n.data_ptr(), th_n.data_ptr(), None, st), "tn_field_fwd_train")
+                                      dens_t.data_ptr(), rgb_n.data_ptr(), th_n.data_ptr(), None, None, st), "tn_field_fwd_train")
     assert torch.equal(rgb_n, rgb_t) and torch.equal(th_n, th_t)  # the optional store changes nothing else
+    # ... nor does the optional position Jacobian (config.store_position_jacobian), another instantiation of the kernel
+    jac = torch.full(((N + 63) // 64 * 64 + 1, 96), 7.0, device=DEV)
+    enc_j, base_j = torch.empty_like(enc_t), torch.empty_like(base)
+    _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc_j.data_ptr(), sel_t.data_ptr(),
+                                      dens_t.data_ptr(), rgb_n.data_ptr(), th_n.data_ptr(), base_j.data_ptr(), jac.data_ptr(), st),
+               "tn_field_fwd_train")
+    torch.cuda.synchronize()
+    assert torch.equal(rgb_n, rgb_t) and torch.equal(th_n, th_t) and torch.equal(base_j[:N], bo) and bool((jac[-1] == 7.0).all())
+    assert torch.equal(enc_j.view(-1, 16, 64, 2)[: N // 64], enc_t.view(-1, 16, 64, 2)[: N // 64])
 
     g = torch.Generator().manual_seed(9)
     g_rgb, g_th, g_dens = (torch.randn(N, 3, generator=g) * 1e-3).to(DEV), (torch.randn(N, generator=g) * 1e-3).to(DEV), \
@@ -634,7 +643,9 @@ def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
              "th1": "field.mlp_thermal.layers.1", "thead": "field.field_head_thermal.net"}
     ws = torch.empty(lib.tn_field_bwd_fused_workspace_bytes(R, S), dtype=torch.uint8, device=DEV)
     res = {}
-    for stored, form in ((True, 1), (False, 1), (True, 2)):  # form 2: the heads' 64 x 64 products as six bf16-piece products
+    # form 2: the heads' 64 x 64 products as six bf16-piece products; "jac": the position gradient from the forward's Jacobian
+    for stored, form in ((True, 1), (False, 1), (True, 2), (True, "jac")):
+        from_jac, form = (form == "jac"), (2 if form == "jac" else form)
         grads = {n: torch.zeros_like(p) for n, p in gm.named_parameters()}
         gr = _hip.tn_field_grads()
         for k, nme in names.items():
@@ -644,24 +655,29 @@ def test_kept_base_output_equals_the_tape_and_the_recomputing_backward(S, hw):
         g_enc, g_ray, g_pos = f32(N, 32), torch.zeros(R, 64, device=DEV), f32(N, 3)
         _hip.check(lib.tn_field_bwd_fused(fld, R, S, enc_t.data_ptr(), sel_t.data_ptr(), base.data_ptr() if stored else None,
                                           ray_bias.data_ptr(), rgb_t.data_ptr(), g_rgb.data_ptr(), g_th.data_ptr(), g_dens.data_ptr(),
-                                          1, -15.0, form, g_enc.data_ptr(), g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(),
+                                          1, -15.0, form, g_enc.data_ptr(), g_ray.data_ptr(), pos.data_ptr(), jac.data_ptr() if from_jac else None, g_pos.data_ptr(),
                                           C.byref(gr), ws.data_ptr(), ws.numel(), st), "tn_field_bwd_fused")
         torch.cuda.synchronize()
-        res[(stored, form)] = dict({nme + sfx: grads[nme + sfx] for nme in names.values() for sfx in (".weight", ".bias") if nme + sfx in grads},
+        res[(stored, "jac" if from_jac else form)] = dict({nme + sfx: grads[nme + sfx] for nme in names.values() for sfx in (".weight", ".bias") if nme + sfx in grads},
                            g_enc=g_enc, g_ray=g_ray, g_pos=g_pos)
     for k, want in res[(False, 1)].items():
-        for other in ((True, 1), (True, 2)):
+        for other in ((True, 1), (True, 2), (True, "jac")):
             if want.norm().item() == 0.0:
                 assert res[other][k].norm().item() == 0.0, k
                 continue
             assert rel(res[other][k], want) <= 2e-5, f"{k} {other}: rel {rel(res[other][k], want):.2e}"
     # the bf16-piece products are fp32 products up to the rounding of a product: the two stored-base forms differ by summation order only
     assert any(not torch.equal(res[(True, 1)][k], res[(True, 2)][k]) for k in res[(True, 1)])  # (form 2 really is another kernel)
+    assert not torch.equal(res[(True, 2)]["g_pos"], res[(True, "jac")]["g_pos"])  # (and so is the Jacobian's position gradient)
+    # the position gradient sample by sample, not only in norm: positions inside and outside the unit box, every level
+    a, b = res[(True, "jac")]["g_pos"], res[(False, 1)]["g_pos"]
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
 
     # the whole step with and without the kept rows
     got = {}
     for keep, pieces in ((True, True), (True, False), (False, False)):
-        gm2, _, _, o2, d2, jit2, cam2, batch2 = _train_setup("scene", S, R_hw=hw, store_base_output=keep, backward_bf16_pieces=pieces)
+        gm2, _, _, o2, d2, jit2, cam2, batch2 = _train_setup("scene", S, R_hw=hw, store_base_output=keep, backward_bf16_pieces=pieces,
+                                                             store_position_jacobian=keep)
         assert gm2.config.store_base_output is keep and gm2.config.backward_bf16_pieces is pieces
         out, loss = _gpu_step(gm2, o2, d2, jit2, cam2, batch2)
         got[(keep, pieces)] = (out, loss, {n: p.grad.clone() for n, p in gm2.named_parameters() if p.grad is not None})

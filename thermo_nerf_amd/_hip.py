@@ -225,10 +225,10 @@ SIGNATURES = {
     "tn_density_bwd_train": (C.c_int, [C.POINTER(tn_density_field), _vp, _vp, _vp, _vp, _i64, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tn_ray_head_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _vp, _vp]),
     "tn_ray_head_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "tn_field_fwd_train": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _i32] + [_vp] * 7),
+    "tn_field_fwd_train": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i64, _i32] + [_vp] * 8),
     "tn_field_bwd_fused_workspace_bytes": (_sz, [_i64, _i32]),
     "tn_field_bwd_fused": (C.c_int, [C.POINTER(tn_thermal_field), _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, C.c_float,
-                                     _i32, _vp, _vp, _vp, _vp, C.POINTER(tn_field_grads), _vp, _sz, _vp]),
+                                     _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(tn_field_grads), _vp, _sz, _vp]),
     "tn_composite_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "tn_color_input_fwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     "tn_color_input_bwd": (C.c_int, [C.POINTER(tn_thermal_field), _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),

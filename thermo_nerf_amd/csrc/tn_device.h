@@ -369,8 +369,10 @@ __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f
 // the stages would cost the exact wait counts the pipelining lives on).
 // GP > 0: s_setprio(GP) while a group's indices are computed and its gathers issued, s_setprio(0) for the interpolation (a caller's
 // A/B switch: the wave whose memory requests can go out ahead of its SIMD partners' arithmetic).
-template <int NL, int LG, int ND = 0, int GP = 0, typename G, typename Emit>
-__device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, float py, float pz, Emit emit, int base = 0) {
+// (hash_encode_pipelined_raw hands the level's taps and corner values to emit_raw(level - base, taps, corners): a caller that
+// wants more than the blended features — the training forward's position Jacobian — interpolates itself.)
+template <int NL, int LG, int ND = 0, int GP = 0, typename G, typename EmitRaw>
+__device__ __forceinline__ void hash_encode_pipelined_raw(const G &g, float px, float py, float pz, EmitRaw emit_raw, int base = 0) {
     static_assert(NL % LG == 0 && 16 * LG <= 64, "two groups of 8*LG gathers must fit the 6-bit vmcnt counter");
     constexpr int NG = NL / LG;
     HashTaps taps[2][LG];
@@ -403,10 +405,43 @@ __device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, floa
         if (GP > 0) __builtin_amdgcn_s_setprio(0);
         TN_STAGE_FENCE();
 #pragma unroll
-        for (int q = 0; q < LG; ++q) emit(gi * LG + q, hash_blend(taps[cur][q], fv[cur][q]));
+        for (int q = 0; q < LG; ++q) emit_raw(gi * LG + q, taps[cur][q], fv[cur][q]);
         if (GP > 0 && gi + 1 < NG) __builtin_amdgcn_s_setprio(GP);
         TN_STAGE_FENCE();
     }
+}
+template <int NL, int LG, int ND = 0, int GP = 0, typename G, typename Emit>
+__device__ __forceinline__ void hash_encode_pipelined(const G &g, float px, float py, float pz, Emit emit, int base = 0) {
+    hash_encode_pipelined_raw<NL, LG, ND, GP>(g, px, py, pz, [&](int l, const HashTaps &t, const float2 (&f)[8]) { emit(l, hash_blend(t, f)); }, base);
+}
+// hash_blend's features AND their derivatives with respect to the three interpolation offsets (jac[c] = d features / d offset c;
+// times the level's scale = d features / d normalised position).  The differences are the ones the lerps form anyway.
+__device__ __forceinline__ float2 hash_blend_jac(const HashTaps &t, const float2 (&f)[8], float2 (&jac)[3]) {
+    float2 r;
+#define TN_BLEND_JAC(c)                                                                                              \
+    {                                                                                                                \
+        const float d03 = f[0].c - f[3].c, d12 = f[1].c - f[2].c, d56 = f[5].c - f[6].c, d47 = f[4].c - f[7].c;      \
+        const float f03 = fmaf(t.ox, d03, f[3].c), f12 = fmaf(t.ox, d12, f[2].c);                                    \
+        const float f56 = fmaf(t.ox, d56, f[6].c), f47 = fmaf(t.ox, d47, f[7].c);                                    \
+        const float e0312 = f03 - f12, e4756 = f47 - f56;                                                            \
+        const float f0312 = fmaf(t.oy, e0312, f12), f4756 = fmaf(t.oy, e4756, f56);                                  \
+        const float ez = f0312 - f4756;                                                                              \
+        r.c = fmaf(t.oz, ez, f4756);                                                                                 \
+        const float dx_hi = fmaf(t.oy, d03 - d12, d12), dx_lo = fmaf(t.oy, d47 - d56, d56);                          \
+        jac[0].c = fmaf(t.oz, dx_hi - dx_lo, dx_lo);                                                                 \
+        jac[1].c = fmaf(t.oz, e0312 - e4756, e4756);                                                                 \
+        jac[2].c = ez;                                                                                               \
+    }
+    TN_BLEND_JAC(x)
+    TN_BLEND_JAC(y)
+#undef TN_BLEND_JAC
+    // torch's corners are ceil / floor of the scaled coordinate: on a grid plane (offset exactly 0 — one (sample, axis, level) in
+    // ~1e3 samples at fp32, the fine levels' coordinates have 13 fraction bits) the two coincide and the feature has no slope along
+    // that axis, while the floor / floor + 1 corners read here would give the right-hand one
+    if (t.ox == 0.0f) jac[0] = make_float2(0.0f, 0.0f);
+    if (t.oy == 0.0f) jac[1] = make_float2(0.0f, 0.0f);
+    if (t.oz == 0.0f) jac[2] = make_float2(0.0f, 0.0f);
+    return r;
 }
 
 template <bool FAST = false>

@@ -793,6 +793,8 @@ struct TapedArgs {
     int n;                    // samples per ray
     float *enc, *sel, *h1, *bo, *density, *c1, *c2, *rgb, *t1, *t2, *thermal;
     const float *ray_bias;    // [R,64]  (TAPE == false) mlp_head.0's bias + SH + appearance part of each ray
+    float *jac;               // (TAPE == false, optional) d hash features / d normalised position in pass tiles
+                              // [pass][16 levels][3 axes][64 samples][2 features]
 };
 
 template <int ACT>  // 1 relu, 2 sigmoid (exact flavour: the tape is what the backward differentiates)
@@ -821,7 +823,10 @@ __device__ __forceinline__ void tape_store(float *dst, long long row0, long long
 
 // TAPE == false (tn_field_fwd_train): nothing but enc / selector / density / rgb / thermal leaves the kernel, and the per-ray
 // constant part of the colour layer (SH(direction), appearance embedding: 24 of its 32 k-steps) arrives as a per-ray bias.
-template <bool TAPE>
+#ifndef TN_TRAIN_JAC_LG
+#define TN_TRAIN_JAC_LG LG
+#endif
+template <bool TAPE, bool JAC = false>
 __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
@@ -849,10 +854,26 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
             // the hash features in pass tiles [pass][level][64 samples][2]: every store instruction writes 512 contiguous bytes
             // (row-major [N,32] rows put 8 bytes of each of 64 lines on a store); tn_field_bwd_fused reads the same tiling
             float2 *et = reinterpret_cast<float2 *>(a.enc) + ps * (16 * 64) + lane;
-            hash_encode_pipelined<L16, LG, 0, TN_TRAIN_GATHER_PRIO>(a.g, px, py, pz, [&](int l, float2 f) {
-                et[l * 64] = f;
-                swap32(f.x, f.y, bt0[l], bt1[l]);
-            });
+            if (JAC) {
+                // camera-pose optimisation (round 5): the corner values are in registers here — the backward's position gradient
+                // re-read all of them (100 M table reads per S=192 step); 18 more vector instructions per level and 24 more
+                // bytes per (sample, level) give it d features / d position instead
+                float2 *jt = reinterpret_cast<float2 *>(a.jac) + ps * (16 * 3 * 64) + lane;
+                hash_encode_pipelined_raw<L16, TN_TRAIN_JAC_LG, 0, TN_TRAIN_GATHER_PRIO>(a.g, px, py, pz, [&](int l, const HashTaps &t, const float2 (&fc)[8]) {
+                    float2 jc[3];
+                    const float2 f = hash_blend_jac(t, fc, jc);
+                    const float s = a.g.scal[l];
+                    et[l * 64] = f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) jt[(l * 3 + c) * 64] = make_float2(jc[c].x * s, jc[c].y * s);
+                    swap32(f.x, f.y, bt0[l], bt1[l]);
+                });
+            } else {
+                hash_encode_pipelined<L16, LG, 0, TN_TRAIN_GATHER_PRIO>(a.g, px, py, pz, [&](int l, float2 f) {
+                    et[l * 64] = f;
+                    swap32(f.x, f.y, bt0[l], bt1[l]);
+                });
+            }
         } else if (a.g.num_dense == 0) {
             hash_encode_pipelined<L16, 2>(a.g, px, py, pz, [&](int l, float2 f) {
                 if (live) *reinterpret_cast<float2 *>(a.enc + ic * 32 + 2 * l) = f;
@@ -1120,7 +1141,7 @@ int tn_field_fwd_taped(const tn_thermal_field *f, const float *positions, const 
     a.positions = positions; a.dirs = directions; a.cam = camera_indices;
     a.N = (long long)num_rays * n; a.n = n;
     a.enc = enc; a.sel = selector; a.h1 = h1; a.bo = bo; a.density = density; a.c1 = c1; a.c2 = c2; a.rgb = rgb;
-    a.t1 = t1; a.t2 = t2; a.thermal = thermal; a.ray_bias = nullptr;
+    a.t1 = t1; a.t2 = t2; a.thermal = thermal; a.ray_bias = nullptr; a.jac = nullptr;
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
     if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel<true>>(smem)) return TN_ERR_LAUNCH;
     const long long passes = (a.N + 63) / 64;
@@ -1132,7 +1153,8 @@ int tn_field_fwd_taped(const tn_thermal_field *f, const float *positions, const 
 }
 
 int tn_field_fwd_train(const tn_thermal_field *f, const float *positions, const float *ray_bias, int64_t num_rays, int32_t n,
-                       float *enc, float *selector, float *density, float *rgb, float *thermal, float *base_out, void *stream) {
+                       float *enc, float *selector, float *density, float *rgb, float *thermal, float *base_out, float *position_jacobian,
+                       void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!f || !positions || !ray_bias || !enc || !selector || !density || !rgb || !thermal) return TN_ERR_NULL;
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
@@ -1148,13 +1170,15 @@ int tn_field_fwd_train(const tn_thermal_field *f, const float *positions, const 
     a.positions = positions; a.dirs = nullptr; a.cam = nullptr;
     a.N = (long long)num_rays * n; a.n = n;
     a.enc = enc; a.sel = selector; a.h1 = nullptr; a.bo = base_out; a.density = density; a.c1 = nullptr; a.c2 = nullptr; a.rgb = rgb;
-    a.t1 = nullptr; a.t2 = nullptr; a.thermal = thermal; a.ray_bias = ray_bias;
+    a.t1 = nullptr; a.t2 = nullptr; a.thermal = thermal; a.ray_bias = ray_bias; a.jac = position_jacobian;
     const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
-    if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel<false>>(smem)) return TN_ERR_LAUNCH;
+    if (!tn_ensure_dynamic_lds<field_fwd_taped_kernel<false>>(smem) || !tn_ensure_dynamic_lds<field_fwd_taped_kernel<false, true>>(smem))
+        return TN_ERR_LAUNCH;
     const long long passes = (a.N + 63) / 64;
     const long long need = (passes + kWaves - 1) / kWaves;
     const unsigned grid = (unsigned)(need < 512 ? (need < 1 ? 1 : need) : 512);
-    hipLaunchKernelGGL(field_fwd_taped_kernel<false>, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
+    if (a.jac) hipLaunchKernelGGL((field_fwd_taped_kernel<false, true>), dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(field_fwd_taped_kernel<false>, dim3(grid), dim3(kBlock), smem, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
     return TN_OK;
 }

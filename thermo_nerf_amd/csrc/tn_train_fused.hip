@@ -281,6 +281,8 @@ struct FusedBwdArgs {
     float *gsum;            // [R,64]  += per-ray sums of mlp_head.0's pre-activation gradient
     Grid g;                 // the field's hash grid and position normalisation: only for d_pos
     tn_space space;
+    const float *jac;       // d hash features / d normalised position of the forward (tn_field_fwd_train), pass tiles
+                            // [pass][16][3][64][2], or nullptr: the pose gradient re-reads the table
     const float *positions; // [N,3]   sample positions (d_pos != nullptr)
     float *d_pos;           // [N,3]   d loss / d position through the hash encoding (camera-pose optimisation), or nullptr
     float *g_bo_c, *g_bo_t; // [N,16]  split launches: the colour / thermal head's adjoint of bo's rows (nullptr: that head did not run)
@@ -611,9 +613,22 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
         }
 
         // =================================== mlp_base ===================================================================
+        float2 jv[12];  // (BASE, pose gradient from the forward's Jacobian) levels 2 sl, 2 sl + 1, 8 + 2 sl, 9 + 2 sl x 3 axes of sample n
         if (BASE) {
             // the next tile's inputs: in flight during this section
             if (tile + stride < tiles) tile_load<MODE>(nxt, a, tile + stride, n, sl);
+            if (a.d_pos && a.jac) {
+                const long long ic = live ? i0 + n : a.N - 1;
+                const float2 *jt = reinterpret_cast<const float2 *>(a.jac) + (ic >> 6) * (16 * 3 * 64) + (ic & 63);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) jv[(2 * b + jj) * 3 + c] = jt[((8 * b + 2 * sl + jj) * 3 + c) * 64];
+                    }
+                }
+            }
             // row 0 of d_bo: trunc_exp backward, g . exp(clamp(raw)) with the selector and the average density folded in
             const float raw = __shfl(G[0][0], n, 64);  // lane n (sl == 0), q == 0: bo row 0 of sample n
             const float dr = cur.g_dens * cur.sel * a.avg * expf(fminf(fmaxf(raw, a.exp_clamp_min), 15.0f));
@@ -652,11 +667,25 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
                 float px, py, pz;
                 const float selp = normalize_position(sp, x, y, z, px, py, pz);
                 float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+                if (a.jac) {
+                    // (round 5) the forward kept d features / d position: 12 streamed 8-byte reads per lane instead of 32 table reads
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                    for (int b = 0; b < 2; ++b) {
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        encode_level_grad(a.g, 8 * b + 2 * sl + jj, px, py, pz, make_float2(de[b][2 * jj], de[b][2 * jj + 1]), gx, gy, gz);
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const float gex = de[b][2 * jj], gey = de[b][2 * jj + 1];
+                            gx = fmaf(gex, jv[(2 * b + jj) * 3 + 0].x, fmaf(gey, jv[(2 * b + jj) * 3 + 0].y, gx));
+                            gy = fmaf(gex, jv[(2 * b + jj) * 3 + 1].x, fmaf(gey, jv[(2 * b + jj) * 3 + 1].y, gy));
+                            gz = fmaf(gex, jv[(2 * b + jj) * 3 + 2].x, fmaf(gey, jv[(2 * b + jj) * 3 + 2].y, gz));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            encode_level_grad(a.g, 8 * b + 2 * sl + jj, px, py, pz, make_float2(de[b][2 * jj], de[b][2 * jj + 1]), gx, gy, gz);
+                    }
                 }
                 gx += __shfl_xor(gx, 16, 64); gy += __shfl_xor(gy, 16, 64); gz += __shfl_xor(gz, 16, 64);
                 gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
@@ -1038,8 +1067,8 @@ size_t tn_field_bwd_fused_workspace_bytes(int64_t num_rays, int32_t n) {
 int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, const float *enc, const float *selector,
                        const float *base_out, const float *ray_bias, const float *rgb, const float *d_rgb, const float *d_thermal,
                        const float *d_density, int32_t pass_thermal_gradients, float trunc_exp_min, int32_t split, float *d_enc,
-                       float *d_ray_sum, const float *positions, float *d_positions, const tn_field_grads *grads, void *workspace,
-                       size_t workspace_bytes, void *stream) {
+                       float *d_ray_sum, const float *positions, const float *position_jacobian, float *d_positions,
+                       const tn_field_grads *grads, void *workspace, size_t workspace_bytes, void *stream) {
     if (num_rays == 0) return TN_OK;
     if (!f || !enc || !selector || !d_density || !d_enc || !grads || !workspace) return TN_ERR_NULL;
     if (d_rgb && (!rgb || !ray_bias || !d_ray_sum)) return TN_ERR_NULL;
@@ -1060,6 +1089,7 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     a.enc = enc; a.bo = base_out; a.sel = selector; a.ray_bias = ray_bias; a.rgb = rgb; a.g_rgb = d_rgb; a.g_th = d_thermal; a.g_dens = d_density;
     a.g_enc = d_enc; a.gsum = d_ray_sum;
     a.g = tn_make_grid(f->grid); a.space = f->space; a.positions = positions; a.d_pos = d_positions;
+    a.jac = split ? position_jacobian : nullptr;  // (the one-launch form has no registers to spare for it)
     float *slabs = reinterpret_cast<float *>(workspace);
     float *g_bo = slabs + (size_t)3 * kFusedBlocks * SLAB_FLOATS;
     const long long tiles = (a.N + TS - 1) / TS;

@@ -113,6 +113,10 @@ class NerfactoModelConfig:
     """Training (round 5, with tape_free_training and fused_backward_split): the forward also keeps mlp_base's 16 output rows
     (64 B per sample, 54 floats per sample in all) and the backward's colour and thermal launches read them instead of
     recomputing mlp_base from the hash features — 48 of a head tile's ~330 MFMAs (DESIGN §5.6)."""
+    store_position_jacobian: bool = True
+    """Training with ray gradients (camera-pose optimisation; round 5, with tape_free_training and fused_backward_split): the forward
+    also writes d hash features / d position (96 floats per sample) while the eight corner values of every level are in its
+    registers, and the backward's position gradient is 12 streamed reads per lane instead of 32 table reads (DESIGN §5.6)."""
     backward_bf16_pieces: bool = True
     """Training (round 5, with store_base_output): the 64 x 64 products of the backward's two head launches — the second layer's
     recomputed forward and its dx — on the bf16 matrix cores as six-product splits of three exact bf16 pieces per operand

@@ -503,11 +503,18 @@ class RenderTrain(torch.autograd.Function):
             # recomputing mlp_base (the split form only: the one-launch form needs the hidden layer anyway)
             keep_base = bool(getattr(cfg, "store_base_output", True)) and bool(getattr(cfg, "fused_backward_split", True))
             base_out = _f32((N, 16), dev) if keep_base else None
+            # (round 5) camera-pose optimisation: d hash features / d position while the corner values are in registers (384 B per
+            # sample) — the backward's position gradient then reads no table
+            keep_jac = (o.requires_grad or d.requires_grad) and bool(getattr(cfg, "store_position_jacobian", True)) \
+                and bool(getattr(cfg, "fused_backward_split", True))
+            jac = _f32(((N + 63) // 64 * 64, 96), dev) if keep_jac else None
             _hip.check(lib.tn_field_fwd_train(fused, f.pos.data_ptr(), ray_bias.data_ptr(), R, S, f.enc.data_ptr(), f.sel.data_ptr(),
-                                              f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _hip.ptr(base_out), _stream()),
+                                              f.density.data_ptr(), rgb_s.data_ptr(), th_s.data_ptr(), _hip.ptr(base_out),
+                                              _hip.ptr(jac), _stream()),
                        "tn_field_fwd_train")
             bo = ray_bias  # (slot reuse in ctx.acts: the tape-free backward reads (ray_bias, rgb_s) ...
-            h1 = base_out  # ... and mlp_base's output rows, if kept)
+            h1 = base_out  # ... mlp_base's output rows, if kept ...
+            cin = jac      # ... and the position Jacobian, if kept)
         elif fused is not None and cfg.fused_train_forward:
             # the whole field forward of the level in one launch; every tensor of the tape in the layout the adjoints read
             f.enc, f.sel, f.density = _f32((N, 32), dev), _f32((N,), dev), _f32((N,), dev)
@@ -670,7 +677,7 @@ class RenderTrain(torch.autograd.Function):
                                               _hip.ptr(g_rgb_s), _hip.ptr(g_th_s), g_density.data_ptr(),
                                               1 if model.field.pass_thermal_gradients else 0, exp_min,
                                               split_form, g_enc.data_ptr(),
-                                              _hip.ptr(g_ray), f.pos.data_ptr() if ray_grads else None, _hip.ptr(g_pos),
+                                              _hip.ptr(g_ray), f.pos.data_ptr() if ray_grads else None, _hip.ptr(cin), _hip.ptr(g_pos),
                                               C.byref(gr), ws.data_ptr(), ws.numel(), _stream()),
                        "tn_field_bwd_fused")
             zeros("field.mlp_base.encoder.hash_table")

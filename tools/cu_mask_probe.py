@@ -65,7 +65,7 @@ def main():
     _hip.check(lib.tn_ray_head_fwd(fld, dirs.data_ptr(), cam.data_ptr(), R, ray_bias.data_ptr(), st), "tn_ray_head_fwd")
     enc, sel, dens, rgb, th = f32((N + 63) // 64 * 64, 32), f32(N), f32(N), f32(N, 3), f32(N, 1)
     _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc.data_ptr(), sel.data_ptr(),
-                                      dens.data_ptr(), rgb.data_ptr(), th.data_ptr(), None, st), "fwd")
+                                      dens.data_ptr(), rgb.data_ptr(), th.data_ptr(), None, None, st), "fwd")
     g_rgb, g_th, g_dens = torch.randn(N, 3, device=dev) * 1e-3, torch.randn(N, device=dev) * 1e-3, torch.randn(N, device=dev) * 1e-3
     g_enc, g_ray, g_pos = f32(N, 32), torch.zeros(R, 64, device=dev), f32(N, 3)
     grads = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
@@ -84,7 +84,7 @@ def main():
     def bwd(stream):
         _hip.check(lib.tn_field_bwd_fused(fld, R, S, enc.data_ptr(), sel.data_ptr(), None, ray_bias.data_ptr(), rgb.data_ptr(),
                                           g_rgb.data_ptr(), g_th.data_ptr(), g_dens.data_ptr(), 1, -15.0, 1, g_enc.data_ptr(),
-                                          g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
+                                          g_ray.data_ptr(), pos.data_ptr(), None, g_pos.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
                                           stream.cuda_stream), "bwd")
 
     def scatter(stream):

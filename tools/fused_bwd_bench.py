@@ -38,9 +38,12 @@ def main():
     enc, sel, dens, rgb, th = f32((N + 63) // 64 * 64, 32), f32(N), f32(N), f32(N, 3), f32(N, 1)
     bo = f32(N, 16)
 
-    def fwd(keep_base=True):
+    jac = f32((N + 63) // 64 * 64, 96)
+
+    def fwd(keep_base=True, keep_jac=False):
         _hip.check(lib.tn_field_fwd_train(fld, pos.data_ptr(), ray_bias.data_ptr(), R, S, enc.data_ptr(), sel.data_ptr(),
-                                          dens.data_ptr(), rgb.data_ptr(), th.data_ptr(), bo.data_ptr() if keep_base else None, st), "fwd")
+                                          dens.data_ptr(), rgb.data_ptr(), th.data_ptr(), bo.data_ptr() if keep_base else None,
+                                          jac.data_ptr() if keep_jac else None, st), "fwd")
 
     g_rgb, g_th, g_dens = torch.randn(N, 3, device=dev) * 1e-3, torch.randn(N, device=dev) * 1e-3, torch.randn(N, device=dev) * 1e-3
     g_enc, g_ray, g_pos = f32(N, 32), torch.zeros(R, 64, device=dev), f32(N, 3)
@@ -55,11 +58,11 @@ def main():
             setattr(gr, k + "_b", grads[nme + ".bias"].data_ptr())
     ws = torch.empty(lib.tn_field_bwd_fused_workspace_bytes(R, S), dtype=torch.uint8, device=dev)
 
-    def bwd(split, stored=False):
+    def bwd(split, stored=False, from_jac=False):
         _hip.check(lib.tn_field_bwd_fused(fld, R, S, enc.data_ptr(), sel.data_ptr(), bo.data_ptr() if stored else None,
                                           ray_bias.data_ptr(), rgb.data_ptr(),
                                           g_rgb.data_ptr(), g_th.data_ptr(), g_dens.data_ptr(), 1, -15.0, split, g_enc.data_ptr(),
-                                          g_ray.data_ptr(), pos.data_ptr(), g_pos.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(), st), "bwd")
+                                          g_ray.data_ptr(), pos.data_ptr(), jac.data_ptr() if from_jac else None, g_pos.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(), st), "bwd")
 
     def time(fn, *args):
         for _ in range(3):
@@ -73,12 +76,12 @@ def main():
         return e0.elapsed_time(e1) / a.iters * 1e3
 
     flops = 33024.0 * N
-    for keep in (False, True):
-        t = time(fwd, keep)
-        print(f"N {N}: tn_field_fwd_train base_out={keep} {t:8.1f} us  ({flops / t / 1e6:.1f} TF of the 1x forward)")
-    for split, stored in ((1, False), (1, True), (2, True), (0, False)):
-        t = time(bwd, split, stored)
-        print(f"N {N}: tn_field_bwd_fused split={split} stored_base={stored} {t:8.1f} us  ({3 * flops / t / 1e6:.1f} TF of recompute + dx + dW = 3x forward)")
+    for keep, kj in ((False, False), (True, False), (True, True)):
+        t = time(fwd, keep, kj)
+        print(f"N {N}: tn_field_fwd_train base_out={keep} jacobian={kj} {t:8.1f} us  ({flops / t / 1e6:.1f} TF of the 1x forward)")
+    for split, stored, fj in ((1, False, False), (1, True, False), (2, True, False), (2, True, True), (0, False, False)):
+        t = time(bwd, split, stored, fj)
+        print(f"N {N}: tn_field_bwd_fused split={split} stored_base={stored} pose_from_jacobian={fj} {t:8.1f} us  ({3 * flops / t / 1e6:.1f} TF of recompute + dx + dW = 3x forward)")
 
 
 if __name__ == "__main__":

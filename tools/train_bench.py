@@ -39,6 +39,7 @@ def main():
                          "(is the slow start of a run a host-bound mode that sustains itself?)")
     ap.add_argument("--no-store-base", action="store_true", help="config.store_base_output = False (the head launches recompute mlp_base)")
     ap.add_argument("--f32-backward", action="store_true", help="config.backward_bf16_pieces = False")
+    ap.add_argument("--no-jacobian", action="store_true", help="config.store_position_jacobian = False")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
@@ -47,7 +48,8 @@ def main():
                                  bucketed_table_scatter=not a.atomic_scatter, tape_free_training=not a.taped,
                                  fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread,
                                  overlap_table_scatter=not a.no_overlap, overlap_regularisers=(False if a.no_reg_overlap else "auto"),
-                                 store_base_output=not a.no_store_base, backward_bf16_pieces=not a.f32_backward)
+                                 store_base_output=not a.no_store_base, backward_bf16_pieces=not a.f32_backward,
+                                 store_position_jacobian=not a.no_jacobian)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
