@@ -502,10 +502,11 @@ int tn_field_fwd_taped(const tn_thermal_field *field, const float *positions, co
  * two-sided clamp, -INFINITY = upper clamp only).  pass_thermal_gradients = 0 keeps the thermal branch from the geo
  * features [REF thermal_field.py:171-172].  split = 0: one launch for the whole field (one wave per SIMD: its ~210 gradient
  * accumulators); 1: the colour head and (thermal head + mlp_base) as two launches of two waves per SIMD each, the colour
- * head's adjoint of mlp_base's outputs passing through the workspace; 2 (round 5, with base_out; 1 without): the split form
- * with the 64 x 64 products of the two head launches (second layer: recomputed forward and dx) on v_mfma_f32_16x16x32_bf16 as
- * six products of three exact bf16 pieces per operand — fp32's rounding size per product (see tn_bf16x6_split_product).  The
- * reference geometry only (16 levels, geo 15, appearance 32). */
+ * head's adjoint of mlp_base's outputs passing through the workspace; 2 (round 5): the split form with the products whose K
+ * is a multiple of 32 features — the 64 x 64 ones of the two head launches (second layer: recomputed forward and dx; with
+ * base_out only) and mlp_base.0's forward and dx in the mlp_base launch — on v_mfma_f32_16x16x32_bf16 as six products of three
+ * exact bf16 pieces per operand: fp32's rounding size per product (see tn_bf16x6_split_product).  The parameter gradients of
+ * all launches leave through ONE slab reduction at the end.  The reference geometry only (16 levels, geo 15, appearance 32). */
 /* One proposal level of a step on which the proposal networks take gradient, forward and backward in one launch each
  * [HashMLPDensityField built at REF thermal_nerf_model.py:127-149: 5 levels -> Linear(10,16)+ReLU -> Linear(16,1) -> trunc_exp]:
  * forward writes what tn_hash_encode_fwd + 2 x tn_linear_fwd + tn_density_act_fwd write (enc [n,10], selector, raw, density

@@ -824,7 +824,9 @@ __device__ __forceinline__ void tape_store(float *dst, long long row0, long long
 // TAPE == false (tn_field_fwd_train): nothing but enc / selector / density / rgb / thermal leaves the kernel, and the per-ray
 // constant part of the colour layer (SH(direction), appearance embedding: 24 of its 32 k-steps) arrives as a per-ray bias.
 #ifndef TN_TRAIN_JAC_LG
-#define TN_TRAIN_JAC_LG LG
+// hash levels in flight per group in the Jacobian forward: with its 16 stores per group of four levels on top of two groups of 32
+// gathers a wave has more memory operations outstanding than the 6-bit counter holds; two levels per group: 429 -> 413 us at S=192
+#define TN_TRAIN_JAC_LG 2
 #endif
 template <bool TAPE, bool JAC = false>
 __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a) {

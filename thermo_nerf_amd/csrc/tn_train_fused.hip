@@ -54,12 +54,14 @@ constexpr int LDT = 68;  // row stride of the transpose buffers (16-byte row wri
 constexpr int LD_B0 = 40, LD_64 = 72, LD_G = 24;
 // B6 (round 5): the 64 x 64 layers as MFMA fragments of their three bf16 pieces, [ob 4][k pair 2][piece 3][lane 64] x 16 bytes
 constexpr int FRAG_64 = 4 * 2 * 3 * 64 * 4;
+constexpr int FRAG_B0 = 4 * 1 * 3 * 64 * 4;  // mlp_base.0 [64][32]: 4 output blocks x 1 k pair (and its transpose: 2 x 2)
 template <int MODE, bool B6 = false>
 struct Lay {  // a launch stages only the matrices its branches read
-    static constexpr bool C = (MODE & 1) != 0, T = (MODE & 2) != 0;
+    static constexpr bool C = (MODE & 1) != 0, T = (MODE & 2) != 0, B = (MODE & 4) != 0;
     static constexpr int M64 = B6 ? FRAG_64 : 64 * LD_64;
-    static constexpr int B0R = 0;                              // mlp_base.0      [64][40]
-    static constexpr int B1R = B0R + 64 * LD_B0;               // mlp_base.1      [16][72]
+    static constexpr int B0R = 0;                              // mlp_base.0      [64][40]; B6 mlp_base launch: fragments of W | of W^T
+    static constexpr int B0T = B0R + FRAG_B0;                  //   (B6 mlp_base launch only)
+    static constexpr int B1R = B0R + (B6 && B ? 2 * FRAG_B0 : 64 * LD_B0);  // mlp_base.1      [16][72]
     static constexpr int C0R = B1R + 16 * LD_64;               // mlp_head.0, columns of bo's rows: [64][24], column 0 (raw density) zero
     static constexpr int C1R = C0R + (C ? 64 * LD_G : 0);      // mlp_head.1      [64][72]
     static constexpr int C1T = C1R + (C ? M64 : 0);            //   transposed    [64][72]
@@ -102,8 +104,11 @@ static_assert((Lay<1>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024 && (Lay
               "LDS budget (split, 8 waves)");
 static_assert((Lay<1, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024 && (Lay<2, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024,
               "LDS budget (split, bf16 pieces, 8 waves)");
-static_assert(Lay<1, true>::C1R % 4 == 0 && Lay<1, true>::C1T % 4 == 0 && Lay<2, true>::T1R % 4 == 0 && Lay<2, true>::T1T % 4 == 0,
+static_assert(Lay<1, true>::C1R % 4 == 0 && Lay<1, true>::C1T % 4 == 0 && Lay<2, true>::T1R % 4 == 0 && Lay<2, true>::T1T % 4 == 0 &&
+                  Lay<4, true>::B0R % 4 == 0 && Lay<4, true>::B0T % 4 == 0,
               "fragment arrays are read 16 bytes at a time");
+static_assert((Lay<4, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * 4 <= 160 * 1024 && IMG_FLOATS <= Lay<4, true>::SCRATCH + 8 * SCRATCH_PER_WAVE,
+              "LDS budget (mlp_base launch, bf16 pieces)");
 
 constexpr int kFusedBlocks = 256;  // one persistent block per CU
 
@@ -186,12 +191,12 @@ __device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned (&p
     const f2 r2 = {r1[0] - __uint_as_float(pk[1] << 16), r1[1] - __uint_as_float(pk[1] & 0xffff0000u)};  // exact, 8 bits left
     pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
 }
-// stage W (R form source: element (o, i) = w[o * 64 + i]; TRANSPOSED: the fragments of W^T) as fragments at `dst`
-template <bool TRANSPOSED>
-__device__ __forceinline__ void stage_frag64(float *dst, const float *__restrict__ w, int tid, int threads) {
+// stage a matrix as fragments at `dst`: NOB output blocks x NKP k pairs; element (row, k) = w[row * ld + k], TRANSPOSED: w[k * ld + row]
+template <bool TRANSPOSED, int NOB, int NKP>
+__device__ __forceinline__ void stage_frag(float *dst, const float *__restrict__ w, int ld, int tid, int threads) {
     u32x4 *d = reinterpret_cast<u32x4 *>(dst);
-    for (int e = tid; e < 4 * 2 * 64; e += threads) {  // (ob, kp, lane)
-        const int lane = e & 63, kp = (e >> 6) & 1, ob = e >> 7, n = lane & 15, sl = lane >> 4;
+    for (int e = tid; e < NOB * NKP * 64; e += threads) {  // (ob, kp, lane)
+        const int lane = e & 63, kp = (e >> 6) % NKP, ob = (e >> 6) / NKP, n = lane & 15, sl = lane >> 4;
         const int row = 16 * ob + n;
         unsigned pk[4][3];
 #pragma unroll
@@ -199,22 +204,22 @@ __device__ __forceinline__ void stage_frag64(float *dst, const float *__restrict
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 const int k0 = 16 * (2 * kp + h) + 4 * sl + 2 * pr;
-                const float x0 = TRANSPOSED ? w[k0 * 64 + row] : w[row * 64 + k0];
-                const float x1 = TRANSPOSED ? w[(k0 + 1) * 64 + row] : w[row * 64 + k0 + 1];
+                const float x0 = TRANSPOSED ? w[k0 * ld + row] : w[row * ld + k0];
+                const float x1 = TRANSPOSED ? w[(k0 + 1) * ld + row] : w[row * ld + k0 + 1];
                 split_pair_bf16(x0, x1, pk[2 * h + pr]);
             }
         }
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) d[((ob * 2 + kp) * 3 + pc) * 64 + lane] = u32x4{pk[0][pc], pk[1][pc], pk[2][pc], pk[3][pc]};
+        for (int pc = 0; pc < 3; ++pc) d[((ob * NKP + kp) * 3 + pc) * 64 + lane] = u32x4{pk[0][pc], pk[1][pc], pk[2][pc], pk[3][pc]};
     }
 }
 #define MFMA_B6(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), (acc), 0, 0, 0)
-// out[ob] += W . act(in), 64 inputs, 64 outputs
-template <bool RELU_IN>
-__device__ __forceinline__ void mm64_b6(const float *W, int lane, const f32x4 *in, f32x4 *out) {
+// out[ob] += W . act(in): 32 NKP inputs (in[2 kp], in[2 kp + 1] = the k pair's two 16-feature blocks), 16 NOB outputs
+template <int NOB, int NKP, bool RELU_IN>
+__device__ __forceinline__ void mm_b6(const float *W, int lane, const f32x4 *in, f32x4 *out) {
     const u32x4 *wf = reinterpret_cast<const u32x4 *>(W) + lane;
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
+    for (int kp = 0; kp < NKP; ++kp) {
         const f32x4 x0 = RELU_IN ? relu4(in[2 * kp]) : in[2 * kp], x1 = RELU_IN ? relu4(in[2 * kp + 1]) : in[2 * kp + 1];
         unsigned pk[4][3];
         split_pair_bf16(x0[0], x0[1], pk[0]);
@@ -225,8 +230,8 @@ __device__ __forceinline__ void mm64_b6(const float *W, int lane, const f32x4 *i
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) b[pc] = u32x4{pk[0][pc], pk[1][pc], pk[2][pc], pk[3][pc]};
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            const u32x4 a0 = wf[((ob * 2 + kp) * 3 + 0) * 64], a1 = wf[((ob * 2 + kp) * 3 + 1) * 64], a2 = wf[((ob * 2 + kp) * 3 + 2) * 64];
+        for (int ob = 0; ob < NOB; ++ob) {
+            const u32x4 a0 = wf[((ob * NKP + kp) * 3 + 0) * 64], a1 = wf[((ob * NKP + kp) * 3 + 1) * 64], a2 = wf[((ob * NKP + kp) * 3 + 2) * 64];
             // small terms first
             MFMA_B6(out[ob], a0, b[2]);
             MFMA_B6(out[ob], a2, b[0]);
@@ -237,6 +242,8 @@ __device__ __forceinline__ void mm64_b6(const float *W, int lane, const f32x4 *i
         }
     }
 }
+template <bool RELU_IN>
+__device__ __forceinline__ void mm64_b6(const float *W, int lane, const f32x4 *in, f32x4 *out) { mm_b6<4, 2, RELU_IN>(W, lane, in, out); }
 
 // a [16 NB features x 16 samples] matrix in the C/D layout -> rows of a transpose buffer: buf[sample][feature]
 template <int NB, bool RELU>
@@ -334,13 +341,13 @@ __device__ __forceinline__ void tile_load(TileIn &t, const FusedBwdArgs &a, long
 // STORED (head launches of the split form, round 5): mlp_base's 16 output rows come from the forward's copy (a.bo, 64 B per
 // sample) instead of being recomputed from the hash features — 48 of a head tile's ~330 MFMAs, the 128 B feature read and the
 // staging of mlp_base's weights go away.
-// B6 (head launches, round 5): the four 64 x 64 products of a head (forward and dx of its second layer) on the bf16 matrix cores as
-// fp32-exact six-product splits (mm64_b6); the weight-gradient products (K = the tile's 16 samples) stay on the fp32 MFMA.
+// B6 (round 5): the products whose K is a multiple of 32 features — a head's two 64 x 64 ones (forward and dx of its second layer),
+// mlp_base.0's forward (K = 32 hash features) and dx (K = 64) — on the bf16 matrix cores as fp32-exact six-product splits (mm_b6);
+// the weight-gradient products (K = the tile's 16 samples) and the 16-wide layers stay on the fp32 MFMA.
 template <int MODE, int WAVES, bool STORED = false, bool B6 = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(FusedBwdArgs a) {
     constexpr bool COLOUR = (MODE & 1) != 0, THERMAL = (MODE & 2) != 0, BASE = (MODE & 4) != 0;
     static_assert(!STORED || !BASE, "the mlp_base launch needs its hidden layer: it recomputes");
-    static_assert(!B6 || !BASE, "bf16 pieces: the head launches only");
     constexpr int kThreads = WAVES * 64;
     using L = Lay<MODE, B6>;
     constexpr int O_B0R = L::B0R, O_B1R = L::B1R, O_C0R = L::C0R, O_C1R = L::C1R, O_C1T = L::C1T, O_C2 = L::C2, O_T0R = L::T0R,
@@ -349,7 +356,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- stage the weights -----------------------------------------------------------------------------------------------
     if (!STORED) {
-        for (int e = threadIdx.x; e < 64 * 32; e += kThreads) lds[O_B0R + (e >> 5) * LD_B0 + (e & 31)] = a.b0w[e];
+        if (B6 && BASE) {
+            stage_frag<false, 4, 1>(lds + O_B0R, a.b0w, 32, threadIdx.x, kThreads);
+            stage_frag<true, 2, 2>(lds + L::B0T, a.b0w, 32, threadIdx.x, kThreads);
+        } else {
+            for (int e = threadIdx.x; e < 64 * 32; e += kThreads) lds[O_B0R + (e >> 5) * LD_B0 + (e & 31)] = a.b0w[e];
+        }
         for (int e = threadIdx.x; e < 16 * 64; e += kThreads) lds[O_B1R + (e >> 6) * LD_64 + (e & 63)] = a.b1w[e];
     }
     for (int e = threadIdx.x; e < 64 * 16; e += kThreads) {
@@ -359,12 +371,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
     }
     if (B6) {
         if (COLOUR) {
-            stage_frag64<false>(lds + O_C1R, a.h1w, threadIdx.x, kThreads);
-            stage_frag64<true>(lds + O_C1T, a.h1w, threadIdx.x, kThreads);
+            stage_frag<false, 4, 2>(lds + O_C1R, a.h1w, 64, threadIdx.x, kThreads);
+            stage_frag<true, 4, 2>(lds + O_C1T, a.h1w, 64, threadIdx.x, kThreads);
         }
         if (THERMAL) {
-            stage_frag64<false>(lds + O_T1R, a.t1w, threadIdx.x, kThreads);
-            stage_frag64<true>(lds + O_T1T, a.t1w, threadIdx.x, kThreads);
+            stage_frag<false, 4, 2>(lds + O_T1R, a.t1w, 64, threadIdx.x, kThreads);
+            stage_frag<true, 4, 2>(lds + O_T1T, a.t1w, 64, threadIdx.x, kThreads);
         }
     } else {
         for (int e = threadIdx.x; e < 64 * 64; e += kThreads) {
@@ -460,7 +472,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
         } else {
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) h1[ob] = ld4(lds + O_BB0 + 16 * ob + 4 * sl);
-            mm<4, 2, LD_B0, false>(lds + O_B0R, n, sl, cur.e, h1);
+            if (B6 && BASE) mm_b6<4, 1, false>(lds + O_B0R, lane, cur.e, h1);
+            else mm<4, 2, LD_B0, false>(lds + O_B0R, n, sl, cur.e, h1);
             if (!BASE && tile + stride < tiles) tile_load_enc(cur.e, a, tile + stride, n, sl);
             G[0] = ld4(lds + O_BB1 + 4 * sl);
             mm<1, 4, LD_64, true>(lds + O_B1R, n, sl, h1, G);
@@ -648,7 +661,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
             rows_store<4, false>(D, n, sl, dh);
             rows_store<2, false>(X, n, sl, cur.e);
             f32x4 de[2] = {zero4(), zero4()};  // d_enc^T [32 features][16 samples] = W_b0^T . dh
-            mm_t_from_r<2, 4, LD_B0>(lds + O_B0R, n, sl, dh, de);
+            if (B6) mm_b6<2, 2, false>(lds + L::B0T, lane, dh, de);
+            else mm_t_from_r<2, 4, LD_B0>(lds + O_B0R, n, sl, dh, de);
             if (live) {
                 st4(a.g_enc + (i0 + n) * 32 + 4 * sl, de[0]);
                 st4(a.g_enc + (i0 + n) * 32 + 16 + 4 * sl, de[1]);
@@ -772,12 +786,12 @@ struct RedSeg {
     int off, rows, cols, src_ld, src_col0;  // slab segment [rows][src_ld], columns src_col0 .. src_col0 + cols - 1 used
     int dst_ld, dst_col0;
     float *dst;
+    const float *slabs;  // the slabs of the launch that accumulated this segment (round 5: ONE reduction behind the split form's
+    int blocks;          // three launches instead of one behind each — two 6 us launches less on the step's critical path)
 };
 constexpr int kRedSegs = 15;
 struct RedArgs {
     RedSeg seg[kRedSegs];
-    const float *slabs;
-    int blocks;
 };
 constexpr int kRedSplit = 8;   // slices of the block range (one atomic per entry and slice)
 constexpr int kRedUnroll = 8;  // independent slab reads in flight per thread: the kernel is bound by load latency, not bytes
@@ -787,11 +801,11 @@ __global__ void __launch_bounds__(kBlock) field_bwd_reduce_kernel(RedArgs a) {
     const RedSeg &sg = a.seg[blockIdx.y];
     if (!sg.dst) return;
     const int total = sg.rows * sg.cols;
-    const int per = (a.blocks + kRedSplit - 1) / kRedSplit;
-    const int b0 = blockIdx.z * per, b1 = min(a.blocks, b0 + per);
+    const int per = (sg.blocks + kRedSplit - 1) / kRedSplit;
+    const int b0 = blockIdx.z * per, b1 = min(sg.blocks, b0 + per);
     for (int e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
         const int r = e / sg.cols, c = e - r * sg.cols;
-        const float *p = a.slabs + sg.off + r * sg.src_ld + sg.src_col0 + c;
+        const float *p = sg.slabs + sg.off + r * sg.src_ld + sg.src_col0 + c;
         float s = 0.0f;
         for (int b = b0; b < b1; b += kRedUnroll) {
             float v[kRedUnroll];
@@ -1096,7 +1110,9 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
     const hipStream_t st = (hipStream_t)stream;
     const bool c = d_rgb != nullptr, t = d_thermal != nullptr;
     int which = 0;
-    // one launch (+ its slab reduction) of the branches in `mode`
+    RedArgs red;
+    for (int i = 0; i < kRedSegs; ++i) red.seg[i] = RedSeg{0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, 0};
+    // one launch of the branches in `mode`; the segments of the slab it accumulates are noted for the reduction at the end
     auto launch = [&](auto kernel, int mode, int waves, size_t smem) -> int {
         const long long need = (tiles + waves - 1) / waves;
         const int blocks = (int)(need < kFusedBlocks ? need : kFusedBlocks);
@@ -1104,37 +1120,37 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
         ++which;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * 64), smem, st, a);
         if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
-        RedArgs r;
-        r.slabs = a.slabs;
-        r.blocks = blocks;
-        auto seg = [&](int idx, int off, int rows, int cols, int src_ld, int src_col0, float *dst, int dst_ld, int dst_col0) {
-            r.seg[idx] = RedSeg{off, rows, cols, src_ld, src_col0, dst_ld, dst_col0, dst};
+        auto seg = [&](bool mine, int idx, int off, int rows, int cols, int src_ld, int src_col0, float *dst, int dst_ld, int dst_col0) {
+            if (mine) red.seg[idx] = RedSeg{off, rows, cols, src_ld, src_col0, dst_ld, dst_col0, dst, a.slabs, blocks};
         };
         const bool cc = c && (mode & 1), tt = t && (mode & 2), bb = (mode & 4) != 0;
-        seg(0, S_WB0, 64, 32, 32, 0, bb ? grads->base0_w : nullptr, 32, 0);
-        seg(1, S_BB0, 1, 64, 64, 0, bb ? grads->base0_b : nullptr, 64, 0);
-        seg(2, S_WB1, 16, 64, 64, 0, bb ? grads->base1_w : nullptr, 64, 0);
-        seg(3, S_BB1, 1, 16, 16, 0, bb ? grads->base1_b : nullptr, 16, 0);
-        seg(4, S_WC0, 64, GF, 16, 1, cc ? grads->head0_w : nullptr, IN0, 16);
-        seg(5, S_WC1, 64, 64, 64, 0, cc ? grads->head1_w : nullptr, 64, 0);
-        seg(6, S_BC1, 1, 64, 64, 0, cc ? grads->head1_b : nullptr, 64, 0);
-        seg(7, S_WC2, 3, 64, 64, 0, cc ? grads->head2_w : nullptr, 64, 0);
-        seg(8, S_BC2, 1, 3, 4, 0, cc ? grads->head2_b : nullptr, 3, 0);
-        seg(9, S_WT0, 64, GF, 16, 1, tt ? grads->th0_w : nullptr, GF, 0);
-        seg(10, S_BT0, 1, 64, 64, 0, tt ? grads->th0_b : nullptr, 64, 0);
-        seg(11, S_WT1, 64, 64, 64, 0, tt ? grads->th1_w : nullptr, 64, 0);
-        seg(12, S_BT1, 1, 64, 64, 0, tt ? grads->th1_b : nullptr, 64, 0);
-        seg(13, S_WTH, 1, 64, 64, 0, tt ? grads->thead_w : nullptr, 64, 0);
-        seg(14, S_BTH, 1, 1, 4, 0, tt ? grads->thead_b : nullptr, 1, 0);
-        hipLaunchKernelGGL(field_bwd_reduce_kernel, dim3(16, kRedSegs, kRedSplit), dim3(kBlock), 0, st, r);
-        if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
+        seg(bb, 0, S_WB0, 64, 32, 32, 0, grads->base0_w, 32, 0);
+        seg(bb, 1, S_BB0, 1, 64, 64, 0, grads->base0_b, 64, 0);
+        seg(bb, 2, S_WB1, 16, 64, 64, 0, grads->base1_w, 64, 0);
+        seg(bb, 3, S_BB1, 1, 16, 16, 0, grads->base1_b, 16, 0);
+        seg(cc, 4, S_WC0, 64, GF, 16, 1, grads->head0_w, IN0, 16);
+        seg(cc, 5, S_WC1, 64, 64, 64, 0, grads->head1_w, 64, 0);
+        seg(cc, 6, S_BC1, 1, 64, 64, 0, grads->head1_b, 64, 0);
+        seg(cc, 7, S_WC2, 3, 64, 64, 0, grads->head2_w, 64, 0);
+        seg(cc, 8, S_BC2, 1, 3, 4, 0, grads->head2_b, 3, 0);
+        seg(tt, 9, S_WT0, 64, GF, 16, 1, grads->th0_w, GF, 0);
+        seg(tt, 10, S_BT0, 1, 64, 64, 0, grads->th0_b, 64, 0);
+        seg(tt, 11, S_WT1, 64, 64, 64, 0, grads->th1_w, 64, 0);
+        seg(tt, 12, S_BT1, 1, 64, 64, 0, grads->th1_b, 64, 0);
+        seg(tt, 13, S_WTH, 1, 64, 64, 0, grads->thead_w, 64, 0);
+        seg(tt, 14, S_BTH, 1, 1, 4, 0, grads->thead_b, 1, 0);
         return TN_OK;
+    };
+    auto reduce = [&]() -> int {
+        hipLaunchKernelGGL(field_bwd_reduce_kernel, dim3(16, kRedSegs, kRedSplit), dim3(kBlock), 0, st, red);
+        return hipGetLastError() == hipSuccess ? TN_OK : TN_ERR_LAUNCH;
     };
     a.g_bo_c = a.g_bo_t = nullptr;
     if (!split) {
         constexpr size_t smem = (size_t)(Lay<7>::SCRATCH + 4 * SCRATCH_PER_WAVE) * sizeof(float);
         if (!tn_ensure_dynamic_lds<field_bwd_fused_kernel<7, 4>>(smem)) return TN_ERR_LAUNCH;
-        return launch(field_bwd_fused_kernel<7, 4>, 7, 4, smem);
+        TN_TRY(launch(field_bwd_fused_kernel<7, 4>, 7, 4, smem));
+        return reduce();
     }
     constexpr size_t smem1 = (size_t)(Lay<1>::SCRATCH + 8 * SCRATCH_PER_WAVE) * sizeof(float);
     constexpr size_t smem2 = (size_t)(Lay<2>::SCRATCH + 8 * SCRATCH_PER_WAVE) * sizeof(float);
@@ -1162,7 +1178,14 @@ int tn_field_bwd_fused(const tn_thermal_field *f, int64_t num_rays, int32_t n, c
         else if (base_out) TN_TRY(launch(field_bwd_fused_kernel<2, 8, true>, 2, 8, smem2));
         else TN_TRY(launch(field_bwd_fused_kernel<2, 8>, 2, 8, smem2));
     }
-    return launch(field_bwd_fused_kernel<4, 8>, 4, 8, smem4);
+    constexpr size_t smem4b = (size_t)(Lay<4, true>::SCRATCH + 8 * SCRATCH_PER_WAVE) * sizeof(float);
+    if (split == 2) {  // mlp_base.0's two K >= 32 products as bf16 pieces (this launch recomputes mlp_base either way)
+        if (!tn_ensure_dynamic_lds<field_bwd_fused_kernel<4, 8, false, true>>(smem4b)) return TN_ERR_LAUNCH;
+        TN_TRY(launch(field_bwd_fused_kernel<4, 8, false, true>, 4, 8, smem4b));
+    } else {
+        TN_TRY(launch(field_bwd_fused_kernel<4, 8>, 4, 8, smem4));
+    }
+    return reduce();
 }
 
 int tn_ray_head_fwd(const tn_thermal_field *f, const float *directions, const int32_t *camera_indices, int64_t num_rays,
