@@ -546,7 +546,10 @@ def test_bench_two_ranks_prints_one_parseable_line():
     assert line["unit"] == "rays/s" and line["value"] > 1e6 and line["dtype"] == "f32"
     assert line["value"] == pytest.approx(2 * 640000 / (line["ms_per_step"] * 1e-3), rel=1e-3)  # whole-job rays over the slowest rank's time
     assert line["rccl"]["backend"] == "gloo" and line["rccl"]["world_size"] == 2 and len(line["rccl"]["device_ids"]) == 2
-    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] == "mfma"
+    # (two ranks share this box's one GPU: a rank's proposal launch can sit behind the other rank's field launch, and then the
+    # event-timed "dominant kernel" of the line is the proposal pass with its HBM roofline — one run in ten; on a GPU of its own
+    # the field kernel dominates, tests/test_bench_line.py and the N=1 bench line)
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] in ("mfma", "hbm")
     for tag in ("strong_frame_1080p_S48", "strong_frame_800_S192"):
         v = line["variants"][tag]
         assert v["n_gpus"] == 2 and v["scaling"] == "strong" and v["value"] > 1e6 and v["ms_per_step"] > 0
