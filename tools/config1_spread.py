@@ -1,0 +1,47 @@
+"""Run-to-run spread of the HIP path's config-1 loss curve (tests/test_gpu_training.py::test_config1_...): the 100-step window means
+of N runs next to the recorded CPU run's.   usage: python tools/config1_spread.py [runs=6] [extra config key=value ...]"""
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from tests import helpers  # noqa: E402
+from thermo_nerf_amd import training as TR  # noqa: E402
+from thermo_nerf_amd.rays import RayBundle  # noqa: E402
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+over = dict(kv.split("=") for kv in sys.argv[2:])
+DEV = "cuda:0"
+prob = helpers.config1_problem()
+steps = helpers.CONFIG1["steps"]
+gold = np.load(os.path.join("tests", "golden", "config1_oracle.npz"))
+ww = gold["losses"].reshape(10, 100).mean(axis=1)
+print("cpu  " + " ".join(f"{x:.5f}" for x in ww))
+o, d, cam = prob["o"].to(DEV), prob["d"].to(DEV), prob["cam"].to(DEV)
+img, th, idx = prob["image"].to(DEV), prob["thermal"].to(DEV), prob["idx"].to(DEV)
+jitter = prob["jitter"].squeeze(-1).to(DEV)
+for r in range(runs):
+    gm = copy.deepcopy(prob["model"]).to(DEV)
+    for k, v in over.items():
+        setattr(gm.config, k, v == "True")
+    gm.train()
+    params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
+    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, fused=True)
+    got = []
+    for i in range(steps):
+        gm.set_step(i)
+        ix = idx[i]
+        rb = gm.collider(RayBundle(origins=o[ix], directions=d[ix], camera_indices=cam[ix]))
+        out = TR.get_outputs_train(gm, rb, jitter=jitter[i].contiguous())
+        b = {"image": img[ix], "thermal": th[ix]}
+        loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        got.append(loss.detach())
+    gw = torch.stack(got).cpu().numpy().reshape(10, 100).mean(axis=1)
+    bad = np.abs(gw[:6] - ww[:6]) > 0.5 * ww[:6]
+    print(f"hip{r} " + " ".join(f"{x:.5f}" for x in gw) + ("   <-- outside the 50 % band in window(s) " + str(np.nonzero(bad)[0].tolist()) if bad.any() else ""))
