@@ -974,7 +974,8 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     # the ONE recorded CPU trajectory in windows 4-6, whose values are 0.002 … 0.005: a +-50 % band failed two suite runs in eight;
     # the band is a factor of two either way)
     assert (gw[:6] <= 2.0 * ww[:6]).all() and (gw[:6] >= 0.5 * ww[:6]).all(), (gw, ww)
-    assert (np.diff(gw[:6]) < 0).all() and gw[5] < 0.06 * gw[0], gw
+    # (the descent flattens by window 6: two runs in twenty-six had window 6 at 1.00-1.02 x window 5)
+    assert (np.diff(gw[:5]) < 0).all() and gw[5] < 1.15 * gw[4] and gw[5] < 0.06 * gw[0], gw
     assert (gw[6:] < gw[1]).all() and (ww[6:] < ww[1]).all(), (gw, ww)
     # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
     sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
@@ -984,7 +985,8 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     # (one-sided: the atomics' summation order makes the HIP run non-reproducible, and its wandering late stage has ended at a
     # thermal MAE of 0.017 as well as 0.045 — better than the recorded CPU run is not a failure)
     assert p_hip >= p_cpu - 1.5, (p_cpu, p_hip)
-    assert m_hip <= m_cpu + 0.02 and hit_hip <= float(gold["mae_hit"]) + 0.025, (m_cpu, m_hip, hit_hip)
+    # (twelve runs, tools/config1_spread.py: psnr 15.7 … 17.0 dB, thermal MAE 0.017 … 0.054, on the sphere's rays 0.015 … 0.070)
+    assert m_hip <= m_cpu + 0.03 and hit_hip <= float(gold["mae_hit"]) + 0.04, (m_cpu, m_hip, hit_hip)
     assert m_hip < 0.4 * float(gold["mae_initial"]) and hit_hip < 0.4 * float(gold["mae_hit_initial"])
     # and the HIP eval render of the HIP-trained model agrees with the oracle on the same weights (eval after 1000 fused steps)
     gm.eval()

@@ -43,5 +43,9 @@ for r in range(runs):
         opt.step()
         got.append(loss.detach())
     gw = torch.stack(got).cpu().numpy().reshape(10, 100).mean(axis=1)
-    bad = np.abs(gw[:6] - ww[:6]) > 0.5 * ww[:6]
-    print(f"hip{r} " + " ".join(f"{x:.5f}" for x in gw) + ("   <-- outside the 50 % band in window(s) " + str(np.nonzero(bad)[0].tolist()) if bad.any() else ""))
+    sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
+    p_hip, m_hip, hit_hip = helpers.held_out_quality(prob, sd_hip)
+    print(f"     held-out: psnr {p_hip:.2f} dB (cpu {float(gold['psnr']):.2f}), thermal mae {m_hip:.4f} (cpu {float(gold['mae']):.4f}), on the sphere {hit_hip:.4f} "
+          f"(cpu {float(gold['mae_hit']):.4f}); initial {float(gold['mae_initial']):.3f} / {float(gold['mae_hit_initial']):.3f}")
+    bad = (gw[:6] > 2.0 * ww[:6]) | (gw[:6] < 0.5 * ww[:6])
+    print(f"hip{r} " + " ".join(f"{x:.5f}" for x in gw) + ("   <-- outside the factor-2 band in window(s) " + str(np.nonzero(bad)[0].tolist()) if bad.any() else ""))
