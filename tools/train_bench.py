@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--no-store-base", action="store_true", help="config.store_base_output = False (the head launches recompute mlp_base)")
     ap.add_argument("--f32-backward", action="store_true", help="config.backward_bf16_pieces = False")
     ap.add_argument("--no-jacobian", action="store_true", help="config.store_position_jacobian = False")
+    ap.add_argument("--update-every", type=int, default=5, help="config.proposal_update_every (5 = the reference: the proposal networks take "
+                    "gradient on every 6th step after warm-up; 0: on every step; 1000000: never in a run)")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
@@ -49,7 +51,7 @@ def main():
                                  fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread,
                                  overlap_table_scatter=not a.no_overlap, overlap_regularisers=(False if a.no_reg_overlap else "auto"),
                                  store_base_output=not a.no_store_base, backward_bf16_pieces=not a.f32_backward,
-                                 store_position_jacobian=not a.no_jacobian)
+                                 store_position_jacobian=not a.no_jacobian, proposal_update_every=a.update_every)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
