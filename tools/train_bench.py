@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--no-jacobian", action="store_true", help="config.store_position_jacobian = False")
     ap.add_argument("--update-every", type=int, default=5, help="config.proposal_update_every (5 = the reference: the proposal networks take "
                     "gradient on every 6th step after warm-up; 0: on every step; 1000000: never in a run)")
+    ap.add_argument("--high-priority-main", action="store_true", help="run the step on a high-priority stream (the step's side "
+                    "streams come from the default-priority pool): main-chain kernels are dispatched ahead of the side streams'")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     a = ap.parse_args()
@@ -106,6 +108,8 @@ def main():
         except Exception as e:  # pragma: no cover - informational
             return f"rocm-smi unavailable ({type(e).__name__})"
 
+    if a.high_priority_main:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     for i in range(a.warmup):
         step(a.start_step + i)
     torch.cuda.synchronize()
