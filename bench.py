@@ -62,7 +62,9 @@ def algorithmic_flops_per_ray(S: int) -> int:
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU).  Without a launcher (WORLD_SIZE unset) and N > 1, bench.py starts the N ranks itself "
+                         "through torch.distributed.run; under a launcher it must equal WORLD_SIZE (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--atomic-scatter", action="store_true",
@@ -137,8 +139,11 @@ def physical_cores() -> int:
 
 
 def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int, S: int):
-    """the torch-CPU oracle on a strided sample of the same frame; reports the best torch pool size and the
-    one-thread figure, with the CPU model and the thread counts actually used."""
+    """the torch-CPU oracle on a strided sample of the same frame.  `value` is the FASTEST configuration this box
+    offers the oracle — torch pool size x rays per oracle call, both probed (its ops are small: a large pool or a large call
+    collapses it; round 5 measured 1 048 rays/s at 16 threads x 4 096-ray calls, 1 152 at one thread x 256, 2 493 at 16 x 512 and
+    reported the first) — timed over the whole sample; the 4 096-ray-call figure at that pool size, the one-thread figure and the
+    all-physical-cores figure are reported beside it, with the CPU model and every probe."""
     from oracle import hotpath as H
 
     n = min(rays_per_rep, o.shape[0])
@@ -146,55 +151,78 @@ def cpu_baseline(sd, ocfg, o, d, rays_per_rep: int, S: int):
     idx = torch.linspace(0, o.shape[0] - 1, n).long()
     oc, dc = o[idx].contiguous(), d[idx].contiguous()
     avail = os.cpu_count() or 1
+    phys = min(physical_cores(), avail)
+
+    def run(first, count):
+        return H.get_outputs(sd, oc[first:first + count], dc[first:first + count], None, ocfg)
+
+    def sweep(call):
+        """the whole sample in oracle calls of `call` rays -> (seconds, rgb, thermal)"""
+        t = time.perf_counter()
+        parts = [run(a, min(call, n - a)) for a in range(0, n, call)]
+        return time.perf_counter() - t, torch.cat([p["rgb"] for p in parts]), torch.cat([p["thermal"] for p in parts])
+
     with torch.no_grad():
-        # torch's intra-op pool collapses when oversubscribed on these op sizes (256 threads on the GPU box's host
-        # measured 50 rays/s): probe a few thread counts on 512 rays and keep the fastest; `cores` reports it.
-        best, cores, probed = 0.0, 1, {}
-        phys = min(physical_cores(), avail)
-
-        def probe(c):
+        probed = {}  # (threads, rays per call) -> rays/s of one call after a warm-up call at that pool size
+        best, cores, call_rays = 0.0, 1, min(512, n)
+        for c in [c for c in (1, 8, 16, 32, 64, 128) if c <= avail] or [avail]:
             torch.set_num_threads(c)
-            H.get_outputs(sd, oc[:128], dc[:128], None, ocfg)  # warm-up at this pool size
+            run(0, min(128, n))
+            row = 0.0
+            for call in [k for k in (256, 512, 1024) if k <= n] or [n]:
+                t = time.perf_counter()
+                run(n - call, call)
+                probed[(c, call)] = call / (time.perf_counter() - t)
+                row = max(row, probed[(c, call)])
+                if probed[(c, call)] > best:
+                    best, cores, call_rays = probed[(c, call)], c, call
+            if c > 1 and row < 0.7 * best:
+                break  # the pool has collapsed: larger ones are slower still (128 threads: 177-400 rays/s)
+        if not any(k[0] == phys for k in probed):  # BASELINE.md §4 asks for the all-physical-cores figure: measured and reported, whatever it is
+            torch.set_num_threads(phys)
+            run(0, min(128, n))
             t = time.perf_counter()
-            H.get_outputs(sd, oc[:512], dc[:512], None, ocfg)
-            probed[c] = 512 / (time.perf_counter() - t)
-            return probed[c]
-
-        for c in [c for c in (8, 16, 32, 64, 128) if c <= avail] or [avail]:
-            rate = probe(c)
-            if rate > best:
-                best, cores = rate, c
-            elif rate < 0.7 * best:
-                break
-        if phys not in probed:  # BASELINE.md §4 asks for the all-physical-cores figure: measured and reported, whatever it is
-            probe(phys)
+            run(n - min(512, n), min(512, n))
+            probed[(phys, min(512, n))] = min(512, n) / (time.perf_counter() - t)
+        phys_key = max((k for k in probed if k[0] == phys), key=lambda k: probed[k])
+        # the timed leg: the whole sample in calls of the fastest size at the fastest pool, repeated for >= 10 s
         torch.set_num_threads(cores)
-        reps, t_total, out = 0, 0.0, None
-        while reps < 2 or (t_total < 10.0 and reps < 10):
-            t = time.perf_counter()
-            out = H.get_outputs(sd, oc, dc, None, ocfg)
-            t_total += time.perf_counter() - t
+        reps, t_total, rgb, th = 0, 0.0, None, None
+        while reps < 1 or (t_total < 10.0 and reps < 10):
+            dt, rgb, th = sweep(call_rays)
+            t_total += dt
             reps += 1
-        # one thread (BASELINE.md §4 asks for both): a smaller sample, one warm-up + timed repeats of ~5 s in total
+        # beside it: ONE oracle call over the whole sample at the same pool (what rounds 1-5 reported as `value`) ...
+        multi = [c for (c, _) in probed if c > 1]
+        torch.set_num_threads(cores if cores > 1 else (min(multi, key=lambda c: abs(c - 16)) if multi else 1))
+        big_threads = torch.get_num_threads()
+        t = time.perf_counter()
+        run(0, n)
+        big = n / (time.perf_counter() - t)
+        # ... and one thread (BASELINE.md §4 asks for both), at its own best call size
         torch.set_num_threads(1)
-        n1 = min(256, n)
-        H.get_outputs(sd, oc[:32], dc[:32], None, ocfg)
+        call1 = max((k for k in probed if k[0] == 1), key=lambda k: probed[k])[1] if any(k[0] == 1 for k in probed) else min(256, n)
+        n1 = min(2 * call1, n)
         reps1, t1 = 0, 0.0
-        while reps1 < 1 or (t1 < 5.0 and reps1 < 4):
+        while reps1 < 1 or (t1 < 4.0 and reps1 < 4):
             t = time.perf_counter()
-            H.get_outputs(sd, oc[:n1], dc[:n1], None, ocfg)
+            for a in range(0, n1, call1):
+                run(a, min(call1, n1 - a))
             t1 += time.perf_counter() - t
             reps1 += 1
         torch.set_num_threads(cores)
-    return {"value": n * reps / t_total, "unit": "rays/s", "cores": cores, "kind": "port",
+    out = {"rgb": rgb, "thermal": th}
+    return {"value": n * reps / t_total, "unit": "rays/s", "cores": cores, "call_rays": call_rays, "kind": "port",
             "cpu_model": cpu_model_name(), "host_threads": avail,
-            "physical_cores": {"value": probed[phys], "unit": "rays/s", "cores": phys,
-                               "sample": "1 x 512 rays of the same strided sample, torch.set_num_threads(%d)" % phys},
-            "probed_rays_per_s_by_threads": {str(k): v for k, v in sorted(probed.items())},
-            "single_thread": {"value": n1 * reps1 / t1, "unit": "rays/s", "cores": 1,
-                              "sample": f"{reps1} x {n1} rays of the same strided sample, torch.set_num_threads(1)"},
-            "sample": f"{reps} x {n} rays strided over the same 800x800 frame at {S} samples/ray, one oracle call per {n} rays, "
-                      f"torch fp32 CPU oracle, {cores} of {avail} host threads (fastest of the probed pool sizes)"}, idx, out
+            "one_call_of_the_sample": {"value": big, "unit": "rays/s", "cores": big_threads, "call_rays": n,
+                                       "sample": "1 x %d rays in ONE oracle call, torch.set_num_threads(%d)" % (n, big_threads)},
+            "physical_cores": {"value": probed[phys_key], "unit": "rays/s", "cores": phys, "call_rays": phys_key[1],
+                               "sample": "1 x %d rays of the same strided sample, torch.set_num_threads(%d)" % (phys_key[1], phys)},
+            "probed_rays_per_s_by_threads_x_call_rays": {"%dx%d" % k: v for k, v in sorted(probed.items())},
+            "single_thread": {"value": n1 * reps1 / t1, "unit": "rays/s", "cores": 1, "call_rays": call1,
+                              "sample": f"{reps1} x {n1} rays of the same strided sample in calls of {call1}, torch.set_num_threads(1)"},
+            "sample": f"{reps} x {n} rays strided over the same 800x800 frame at {S} samples/ray, in oracle calls of {call_rays} rays on "
+                      f"{cores} of {avail} host threads (the fastest of the probed threads x call-size grid), torch fp32 CPU oracle"}, idx, out
 
 
 def load_profile_json(name: str):
@@ -465,18 +493,36 @@ def measure_train_config3(dev, samples: int = 192, steps: int = 30000, window: i
     return res_d
 
 
+BROADCAST = {}  # N > 1: what distributed.broadcast_model_ moved at the last model build (the line's `rccl.weights_broadcast`)
+
+
 def build_render(dev, S, chunk, args, want_cpu_sd=False, streams=None):
+    """the eval model + engine of one rank.  Under torch.distributed (N > 1) only rank 0 fills the weights; every other rank
+    receives them through distributed.broadcast_model_ — the "one broadcast at load" of SURVEY §8e."""
+    import torch.distributed as dist
+
     from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig, synthetic
     from thermo_nerf_amd.engine import RayRenderEngine
+
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=S, eval_num_rays_per_chunk=chunk,
                                  dense_grid_budget_mb=args.dense_mb, field_dense_grid_budget_mb=args.field_dense_mb, use_mfma=not args.no_mfma,
                                  mlp_precision=args.precision, early_termination_eps=args.early_eps)
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
-    synthetic.fill_model_(model, args.weights)  # identical bits on every rank / box
+    if not sharded or dist.get_rank() == 0:
+        synthetic.fill_model_(model, args.weights)  # a counter hash: identical bits on every box
     model.eval()
     sd_cpu = synthetic.model_state_dict_cpu(model) if want_cpu_sd else None
     model = model.to(dev)
+    if sharded:
+        from thermo_nerf_amd.distributed import broadcast_model_
+
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        nbytes = broadcast_model_(model, src=0)
+        torch.cuda.synchronize()
+        BROADCAST.update(bytes=nbytes, ms=(time.perf_counter() - t) * 1e3)
     return model, cfg, sd_cpu, RayRenderEngine(model, chunk=chunk, streams=streams)
 
 
@@ -647,6 +693,13 @@ def measure_shard_proxy(dev, args, reps: int = 4):
 
 
 def rccl_info(dist, world, dev):
+    info = _rccl_info(dist, world, dev)
+    if BROADCAST:
+        info["weights_broadcast"] = dict(BROADCAST)
+    return info
+
+
+def _rccl_info(dist, world, dev):
     """What the line says about the transport: the backend torch.distributed reports, the world size it sees, every rank's device."""
     name = torch.cuda.get_device_name(dev)
     if world == 1:
@@ -747,10 +800,10 @@ def _r(x, sig=6):
 
 
 def _variant_frac(v: dict):
-    """the one fraction a variant is judged by: its serial-phase fraction (training), else its roofline's binding fraction"""
+    """the one fraction a variant is judged by: its roofline's — for a training step SURVEY §8(d)'s "3 x bytes" HBM fraction (the
+    MFMA view and the builder's serial-phase number go out under their own keys, compact_line), for a render its path's fraction
+    of the binding ceiling"""
     roof = v.get("roofline") or {}
-    if "serial_phase_view" in roof:
-        return roof["serial_phase_view"].get("frac")
     if "path" in roof and "path_frac_of_binding_ceiling" in roof["path"]:
         return roof["path"]["path_frac_of_binding_ceiling"]
     return roof.get("frac")
@@ -784,7 +837,8 @@ def compact_line(full: dict, detail_file: str = "bench_detail.json") -> dict:
     if cb:
         line["cpu_baseline"] = {
             "value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "cpu_model": cb.get("cpu_model"),
-            "single_thread": _r((cb.get("single_thread") or {}).get("value")),
+            "call_rays": cb.get("call_rays"), "single_thread": _r((cb.get("single_thread") or {}).get("value")),
+            "one_call_4096_rays": _r((cb.get("one_call_of_the_sample") or {}).get("value")),
             "physical_cores": (cb.get("physical_cores") or {}).get("cores"),
             "physical_cores_value": _r((cb.get("physical_cores") or {}).get("value")),
             "sample": str(cb.get("sample", ""))[:160]}
@@ -801,6 +855,8 @@ def compact_line(full: dict, detail_file: str = "bench_detail.json") -> dict:
         line["rccl"] = {"backend": info.get("backend"), "world_size": info.get("world_size"), "rccl_version": info.get("rccl_version"),
                         "devices": sorted({str(d).split(" (cuda")[0] for d in devs}), "device_ids": [
                             int(str(d).split("cuda:")[1].rstrip(")")) for d in devs if "cuda:" in str(d)]}
+        if info.get("weights_broadcast"):  # distributed.broadcast_model_ at load: bytes moved from rank 0
+            line["rccl"]["weights_broadcast_mb"] = _r(info["weights_broadcast"]["bytes"] / 1e6, 4)
     variants = {}
     for name, v in (full.get("variants") or {}).items():
         if name == "shard_proxy":  # strong scaling predicted on one GPU: efficiency of the N = 8 shard per frame
@@ -813,6 +869,11 @@ def compact_line(full: dict, detail_file: str = "bench_detail.json") -> dict:
         frac = _variant_frac(v)
         if frac is not None:
             c["frac"] = _r(frac, 4)
+        roof_v = v.get("roofline") or {}
+        if "mfma_view" in roof_v:  # training steps: SURVEY 8(d) "3 x flops" against the fp32-MFMA peak, beside the HBM `frac`
+            c["mfma_frac"] = _r(roof_v["mfma_view"].get("frac"), 4)
+        if "serial_phase_view" in roof_v:  # phase-by-phase view against measured line rates (profiles/train_kernels.json): not a roofline fraction
+            c["serial_phase_frac"] = _r(roof_v["serial_phase_view"].get("frac"), 4)
         if "held_out" in v:  # config 3's quantities: sustained step, held-out quality, parity on the trained weights
             c["steps"] = v.get("steps")
             c["rgb_psnr_db"] = _r(v["held_out"].get("rgb_psnr_db"), 4)
@@ -875,9 +936,42 @@ def emit(full: dict) -> None:
     print(out, flush=True)
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run (one process per GPU, rendezvous
+    on 127.0.0.1 at a free port) with this very command line; rank 0 prints the one line, the children's stdout / stderr pass through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def resolve_world(args) -> int:
+    """--gpus against the launcher's WORLD_SIZE: equal, or one of them absent.  Returns the world size of THIS process, or -1 when
+    the ranks have to be started first (launch_ranks); a contradiction is an error, never a silent one-GPU run."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus is None or args.gpus <= 1:
+            args.gpus = 1
+            return 1
+        return -1
+    world = int(env_world)
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d contradicts the launcher's WORLD_SIZE=%d" % (args.gpus, world))
+    args.gpus = world
+    return world
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = resolve_world(args)
+    if world < 0:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None

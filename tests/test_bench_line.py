@@ -67,6 +67,12 @@ def test_compact_line_shows_config3_and_every_variant_as_numbers(full):
     for k in ("value", "ms_per_step", "frac", "steps", "rgb_psnr_db", "thermal_mae_degC", "parity_rgb_mae", "parity_thermal_mae"):
         assert isinstance(c3[k], (int, float)), k
     assert c3["steps"] == 30000 and c3["ms_per_step"] == pytest.approx(full["variants"]["train_config3_S192"]["ms_per_step"], rel=1e-4)
+    # a training variant's `frac` is SURVEY 8(d)'s fraction (3 x B(S) bytes per ray against 8 TB/s), recomputable from the line itself;
+    # the fp32-MFMA view and the builder's serial-phase number sit beside it under their own names
+    roof3 = full["variants"]["train_config3_S192"]["roofline"]
+    assert c3["frac"] == pytest.approx(3 * 309320 * 4096 / (c3["ms_per_step"] * 1e-3) / 8e12, rel=2e-3) == pytest.approx(roof3["frac"], rel=1e-3)
+    assert c3["mfma_frac"] == pytest.approx(roof3["mfma_view"]["frac"], rel=1e-3)
+    assert c3["serial_phase_frac"] == pytest.approx(roof3["serial_phase_view"]["frac"], rel=1e-3) and c3["serial_phase_frac"] != c3["frac"]
     for name, c in v.items():
         assert all(not isinstance(x, (dict, list)) for x in c.values()), name
     for name in full["variants"]:

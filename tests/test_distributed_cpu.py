@@ -270,3 +270,85 @@ def test_fine_sharding_hands_every_rank_the_same_sample_split():
         assert planes == [None, None, ((mine,), (mine,))]
         ks.add(got[0])
     assert len(ks) == 1
+
+
+def _broadcast_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from thermo_nerf_amd import SceneBox, ThermalNerfModel, ThermalNerfModelConfig
+
+        cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=8, log2_hashmap_size=10)
+        model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=3)
+        # rank 0 holds "the checkpoint" (a counter-hash fill); every other rank starts from its own random initialisation
+        torch.manual_seed(100 + rank)
+        if rank == 0:
+            synthetic.fill_model_(model, "stress")
+        else:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.normal_()
+        calls = []
+        real = dist.broadcast
+
+        def counting(t, *a, **k):
+            calls.append(t.numel() * t.element_size())
+            return real(t, *a, **k)
+
+        dist.broadcast = counting
+        try:
+            moved = D.broadcast_model_(model, src=0)
+        finally:
+            dist.broadcast = real
+        want = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=3)
+        synthetic.fill_model_(want, "stress")
+        got, ref = dict(model.named_parameters()), dict(want.named_parameters())
+        ok = set(got) == set(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
+        bufs = dict(model.named_buffers())
+        ok = ok and all(torch.equal(bufs[k], b) for k, b in want.named_buffers())
+        n_param_bytes = sum(p.numel() * p.element_size() for p in model.parameters()) + sum(
+            b.numel() * b.element_size() for b in model.buffers())
+        q.put((rank, ok, moved, n_param_bytes, len(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_model_makes_every_rank_hold_rank_zeros_weights():
+    """SURVEY §8e: weights replicated through ONE broadcast at load (distributed.broadcast_model_): only rank 0 has the weights;
+    after the call every parameter and buffer of both ranks equals rank 0's bit for bit, and it took one collective per dtype,
+    not one per tensor."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_broadcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, moved, total, n_calls in res:
+        assert ok, f"rank {rank}: weights differ from rank 0's"
+        assert moved == total and n_calls <= 3, (moved, total, n_calls)
+
+
+def test_bench_gpus_flag_against_the_launchers_world_size(monkeypatch):
+    """bench.py: --gpus N without a launcher asks for N ranks to be started (-1); under a launcher it must equal WORLD_SIZE — a
+    contradiction is an error, never a silent one-GPU run (VERDICT r5 #8)."""
+    import argparse
+
+    import bench
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    for given, want in ((None, 1), (1, 1), (2, -1), (8, -1)):
+        a = argparse.Namespace(gpus=given)
+        assert bench.resolve_world(a) == want
+        assert a.gpus == (given or 1)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    a = argparse.Namespace(gpus=None)
+    assert bench.resolve_world(a) == 4 and a.gpus == 4
+    assert bench.resolve_world(argparse.Namespace(gpus=4)) == 4
+    for bad in (1, 2, 8):
+        with pytest.raises(SystemExit):
+            bench.resolve_world(argparse.Namespace(gpus=bad))

@@ -555,3 +555,29 @@ def test_bench_two_ranks_prints_one_parseable_line():
         assert v["n_gpus"] == 2 and v["scaling"] == "strong" and v["value"] > 1e6 and v["ms_per_step"] > 0
     detail = json.loads(lines[-2])["bench_detail"]  # the full tree went out on the line before
     assert detail["variants"]["strong_frame_800_S192"]["config"]["rays_per_step"] == 640000
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """plain `python bench.py --gpus 2` — the command shape the driver uses, with NO launcher around it: bench.py starts the two ranks
+    itself (torch.distributed.run, rendezvous on 127.0.0.1), rank 0 prints the one line with n_gpus 2, and ranks other than 0 got their
+    weights through distributed.broadcast_model_ (the line says how many bytes).  gloo: both ranks share this box's one GPU.  And a
+    --gpus that contradicts the launcher's WORLD_SIZE exits non-zero instead of measuring one GPU in silence."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-variants"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["value"] == pytest.approx(2 * 640000 / (line["ms_per_step"] * 1e-3), rel=1e-3)
+    assert 70 < line["rccl"]["weights_broadcast_mb"] < 90  # main table 64 MiB + 2 x 5 MiB proposal tables + MLPs, embeddings
+
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=root,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "contradicts" in (bad.stderr + bad.stdout)

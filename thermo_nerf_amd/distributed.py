@@ -25,6 +25,38 @@ OUTPUT_KEYS = ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0",
 OUTPUT_WIDTHS = (3, 1, 1, 1, 1, 1, 1)
 
 
+def broadcast_model_(model: torch.nn.Module, src: int = 0, group=None) -> int:
+    """The one collective of model loading (weights replicated, "one RCCL broadcast of ~78 MB at load"): every
+    parameter and buffer of ``model`` on every rank becomes rank ``src``'s, through ONE broadcast per dtype of a flat staging
+    buffer (fp32: hash tables 64 + 2 x 5 MiB, MLPs, embeddings, pose adjustments) instead of one collective per tensor — over
+    xGMI a broadcast is per-link bound, and ~40 small ones pay ~40 launch latencies.  Only rank ``src`` needs to have read the
+    checkpoint.  Derived copies (dense re-layouts, MFMA blobs) are dropped so that the next forward rebuilds them from the
+    received weights.  Returns the bytes broadcast.  The reference has no counterpart: it renders on one device
+    [REF thermo_nerf/render/renderer.py:182-187] and trains through nerfstudio's DDP, whose constructor broadcasts module
+    states the same way [REF thermo_nerf/nerfstudio_config/pipeline_tracking.py:26-27,44]."""
+    tensors = [p.data for _, p in sorted(model.named_parameters(), key=lambda kv: kv[0])]
+    tensors += [b for _, b in sorted(model.named_buffers(), key=lambda kv: kv[0]) if b is not None]
+    total = 0
+    by_kind: Dict = {}
+    for t in tensors:
+        if t.numel():
+            by_kind.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, dev), group_t in sorted(by_kind.items(), key=lambda kv: (str(kv[0][0]), str(kv[0][1]))):
+        flat = torch.empty(sum(t.numel() for t in group_t), dtype=dtype, device=dev)
+        if dist.get_rank(group) == src:
+            torch.cat([t.reshape(-1) for t in group_t], out=flat)
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in group_t:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        total += flat.numel() * flat.element_size()
+    invalidate = getattr(model, "invalidate_prepared", None)
+    if invalidate is not None:
+        invalidate()
+    return total
+
+
 def row_block(height: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [start, end) of an image owned by ``rank``: contiguous blocks, sizes differ by at most one row."""
     base, extra = divmod(height, world)
