@@ -238,8 +238,8 @@ def _split_worker(rank, world, port, q):
         o, d, _ = synthetic.orbit_camera_rays(16, 12, view=1)
         n = 16 * 12
         eng = SplitRecordingEngine(50)
-        D.render_frame_sharded_fine(eng, o, d, align=4)                      # default: the k that suits ONE rank's run
-        D.render_frame_sharded_fine(eng, o, d, align=4, sample_split=None)   # the frame's own choice: nothing passed on
+        D.render_frame_sharded_fine(eng, o, d, align=4, sample_split="shard")  # opt-in: the k that suits ONE rank's run
+        D.render_frame_sharded_fine(eng, o, d, align=4)                        # default: the frame's own choice, nothing passed on
         D.render_frame_sharded_fine(eng, o, d, align=4, sample_split=3, nears=torch.zeros(16, 12, 1), fars=torch.ones(16, 12, 1))
         r0, r1 = D.ray_block(n, rank, world, 4)
         q.put((rank, eng.asked, eng.got, eng.planes, D.ray_block(n, 0, world, 4)[1], r1 - r0))
@@ -249,7 +249,8 @@ def _split_worker(rank, world, port, q):
 
 def test_fine_sharding_hands_every_rank_the_same_sample_split():
     """render_frame_sharded_fine: sample_split="shard" asks the engine ONCE per frame for the k of RANK 0's run size (so every rank
-    passes the same k, whatever its own run), None passes nothing (the engine's frame-level default), an integer is forced; per-ray
+    passes the same k, whatever its own run), the default (None) passes nothing (the engine's frame-level choice: the sharded frame
+    is the default single-device frame bit for bit, whatever the world size — ADVICE r5), an integer is forced; per-ray
     planes are sliced like the rays."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

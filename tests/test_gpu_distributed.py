@@ -340,6 +340,45 @@ def test_shards_of_a_frame_cut_into_several_launches_on_one_stream():
     assert eng.frame_launch_rays(1080 * 1920) == 8 * CHUNK and eng.frame_launch_rays(800 * 800) == 10 * CHUNK
 
 
+def test_launch_forms_do_not_depend_on_the_previous_piece():
+    """``_forms`` asked the library for a piece's kernel form with whatever ``rc.sample_split`` the PREVIOUS piece's
+    launch had left behind — piece 0 of a frame was decided with 0, later pieces with the frame's split, and `sample_split == 1` moves
+    the field's lane = ray threshold from 8 192 to 57 344 rays.  One stream, launches of 24 576 rays (between the two thresholds), a
+    forced ``sample_split=1`` and the library's own choice: every full-size piece gets the same forms, a shard that STARTS in a later
+    launch gets the form ``render`` used there, the shards equal the frame bit for bit, and ``config.sample_split`` reaches the engine."""
+    from thermo_nerf_amd import synthetic
+    from thermo_nerf_amd.engine import RayRenderEngine
+
+    model, _, _ = _model()
+    h, w = 250, 400  # 100 000 rays, chunk 8192: 13 chunks
+    n = h * w
+    o3, d3, _ = synthetic.orbit_camera_rays(h, w, view=5)
+    o, d = o3.reshape(-1, 3).contiguous().to(DEV), d3.reshape(-1, 3).contiguous().to(DEV)
+    eng = RayRenderEngine(model, chunk=8192, streams=1, max_workspace_bytes=45 << 20)
+    L = eng.frame_launch_rays(n)
+    assert 8192 <= L < 57344 and len(eng._launch_pieces(0, n, n)) >= 4
+    _, _, fld = model._c_structs()
+    for split in (1, None, 2):
+        forms = [eng._forms(fld, n, i, split) for i, j in eng._launch_pieces(0, n, n) if j - i == L]
+        assert len(set(forms)) == 1, (split, forms)
+        eng.rc.sample_split = 7  # whatever a previous launch left behind must not matter ...
+        assert eng._forms(fld, n, 0, split) == forms[0]
+        assert eng.rc.sample_split == 7  # ... and is restored
+        eng.rc.sample_split = 0
+        _shards_against_the_frame(eng, o, d, n, 3, sample_split=split)
+    assert eng._forms(fld, n, 0, 1)[2] == 1 and eng._forms(fld, n, 0, 1)[1] != eng._forms(fld, n, 0, None)[1]  # 24 576 rays: serial march -> one ray per wave
+    # config.sample_split = 1 ("never": the serial march's bits) is the engine's default request, as it is model.get_outputs'
+    want = {k: v.clone() for k, v in eng.render(o, d, sample_split=1).items()}
+    model.config.sample_split = 1
+    try:
+        got = eng.render(o, d)
+        torch.cuda.synchronize()
+        assert all(torch.equal(got[k], want[k]) for k in want)
+        assert eng._forms(fld, n, 0, None) == eng._forms(fld, n, 0, 1)
+    finally:
+        model.config.sample_split = 0
+
+
 def test_more_ranks_than_tiles_and_planes_on_the_bundle():
     """(a) 130 rays over 8 ranks = 3 tiles: five ranks own EMPTY runs that start at the frame's end (130: not a multiple of 64) —
     render_shard returns empty outputs and neutral bounds instead of raising while its peers wait in the all-reduce.
@@ -382,16 +421,20 @@ def _fine_worker(rank, world, port, q):
         model, _, _ = _model()
         o3, d3 = _frame_rays(55)
         eng = RayRenderEngine(model, chunk=CHUNK)
-        got = D.render_frame_sharded_fine(eng, o3, d3, device=torch.device(DEV))
+        got = D.render_frame_sharded_fine(eng, o3, d3, device=torch.device(DEV))  # default: the DEFAULT single-device frame's bits
+        got_k = D.render_frame_sharded_fine(eng, o3, d3, device=torch.device(DEV), sample_split="shard")
         torch.cuda.synchronize()
         res = {}
         if rank == 0:
-            # (the default sample_split="shard": the segments per tile that suit one rank's run — a property of the frame)
+            flat = o3.reshape(-1, 3).contiguous(), d3.reshape(-1, 3).contiguous()
+            want = eng.render(*flat)
+            # (sample_split="shard": the segments per tile that suit one rank's run — a property of the frame at that world size)
             k = eng.shard_sample_split(D.ray_block(1080 * 1920, 0, world)[1])
-            want = eng.render(o3.reshape(-1, 3).contiguous(), d3.reshape(-1, 3).contiguous(), sample_split=k)
+            want_k = eng.render(*flat, sample_split=k)
             torch.cuda.synchronize()
-            for k in D.OUTPUT_KEYS:
-                res[k] = bool(torch.equal(got[k].reshape(want[k].shape), want[k]))
+            for key in D.OUTPUT_KEYS:
+                res[key] = bool(torch.equal(got[key].reshape(want[key].shape), want[key]))
+                res[key + "@shard_split"] = bool(torch.equal(got_k[key].reshape(want_k[key].shape), want_k[key]))
         dist.barrier()
         q.put((rank, res, None))
     except Exception:  # pragma: no cover - surfaced by the parent

@@ -162,19 +162,21 @@ def ray_block(num_rays: int, rank: int, world: int, align: int = 64) -> Tuple[in
 
 def render_frame_sharded_fine(engine, origins: Tensor, directions: Tensor, group=None, device: Optional[torch.device] = None,
                               align: int = 64, nears: Optional[Tensor] = None, fars: Optional[Tensor] = None,
-                              sample_split="shard") -> Dict[str, Tensor]:
-    """``render_frame_sharded`` with EVEN shards (``ray_block``) that still reproduces the single-device frame bit for bit.  The
+                              sample_split=None) -> Dict[str, Tensor]:
+    """``render_frame_sharded`` with EVEN shards (``ray_block``) that still reproduces the single-device frame bit for bit (with the
+    default ``sample_split``; see below).  The
     one cross-ray quantity — the expected-depth clip to the [min, max] sample mid-point of each ``engine.chunk``-ray chunk of
     the frame — is restored by exchanging the per-chunk bounds: a rank renders the pieces of the chunks its run overlaps
     (``engine.render_shard``), ONE all-reduce(min) of 2 floats per chunk of the frame (max as min of the negation) joins the
     bounds of chunks split between ranks, ``engine.apply_depth_bounds`` clips, and the pixels are all-gathered as before.
     ``nears`` / ``fars`` [H,W,1] (or [H*W]): per-ray planes the bundle already carries, sliced like the origins (absent: the
     engine's collider planes, as in ``RayRenderEngine.render``).
-    ``sample_split``: segments per 64-ray tile of the field pass.  "shard" (default): what suits the size of ONE RANK's run
-    (``engine.shard_sample_split``: an 80 000-ray run is 1 250 tiles on 2 048 wave slots — marched whole it lasts as long as 2 048;
-    in 8 segments each it lasts 5 short rounds), the same value on every rank, and the frame equals
-    ``engine.render(frame, sample_split=k)`` bit for bit; None: the unsharded frame's own choice (1: bit-equal to the default
-    single-device frame); k: forced.
+    ``sample_split``: segments per 64-ray tile of the field pass.  None (default): the unsharded frame's own choice, so the result
+    is ``engine.render(frame)`` bit for bit whatever the number of ranks.  "shard": a PERFORMANCE opt-in — what suits the size of ONE
+    RANK's run (``engine.shard_sample_split``: an 80 000-ray run is 1 250 tiles on 2 048 wave slots — marched whole it lasts as long
+    as 2 048; in 8 segments each it lasts 5 short rounds), the same value on every rank; the frame then equals
+    ``engine.render(frame, sample_split=k)`` bit for bit, and since k follows the WORLD SIZE the last bits of a pixel change with the
+    number of ranks (another association of the same sum, within 3e-6 of the serial march).  k: forced.
     ``engine``: a RayRenderEngine (or anything with its ``render_shard`` / ``apply_depth_bounds``)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     h, w = origins.shape[:2]

@@ -82,7 +82,7 @@ class RayRenderEngine:
         if slots > 1 and (len(self._streams) < self.num_streams or self._streams[0].device != self._ws.device):
             # (only a frame of several launches needs them) streams on distinct hardware queues: two pool streams may share one
             # and run their launches back to back
-            self._streams = _hip.concurrent_streams(dev, self.num_streams)
+            self._streams = _hip.concurrent_streams(dev, self.num_streams, with_main=False)
         self._ws_rays = max(self._ws_rays, rays)
         # NS NearFarCollider in eval: near plane reset to 0; keyed on the planes, so a collider edited after
         # the first render is picked up
@@ -131,21 +131,36 @@ class RayRenderEngine:
         family = KERNEL_FAMILY[self.model.config.kernel_family]
         k = piece_start // L
         whole = min((k + 1) * L, frame_rays) - k * L
-        if family == 0 and self.num_streams > 1 and frame_rays > L and L >= 49152:
-            # launches overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
-            prop = field = 1
-        else:
-            self.rc.kernel_family = family
-            prop, field = (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)),
-                           int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
-        # segments per tile: ONE value per frame, whatever launches it is cut into (a ray's bits must not depend on the launch that
-        # holds it, nor on the number of streams): the library's choice for a call of the WHOLE frame's size — 1 for a frame of
-        # 400 k rays or more, several for the small frames whose tiles would leave most wave slots idle
-        self.rc.kernel_family = field
-        self.rc.sample_split = 0 if sample_split is None else max(int(sample_split), 1)
-        split = int(self.lib.tn_render_sample_split(fld, self.rc, frame_rays))
-        self.rc.kernel_family, self.rc.sample_split = family, 0
+        # STATELESS: both library queries see the caller's REQUEST (0 = the library decides, k = forced) — never the split `render`
+        # left in self.rc for the previous piece's launch (piece 0 was decided with 0, later pieces with the frame's
+        # split, which moves the field's lane = ray threshold from 8 192 to 57 344 rays when it is 1); self.rc is restored on exit
+        request = self._split_request(sample_split)
+        saved = self.rc.kernel_family, self.rc.sample_split
+        try:
+            self.rc.sample_split = request
+            if family == 0 and self.num_streams > 1 and frame_rays > L and L >= 49152:
+                # launches overlapping on several streams fill the chip together: the lane = ray kernels pay from ~50 k rays in flight
+                prop = field = 1
+            else:
+                self.rc.kernel_family = family
+                prop, field = (int(self.lib.tn_render_kernel_form(None, self.rc, whole, 0)),
+                               int(self.lib.tn_render_kernel_form(fld, self.rc, whole, 1)))
+            # segments per tile: ONE value per frame, whatever launches it is cut into (a ray's bits must not depend on the launch
+            # that holds it, nor on the number of streams): the library's choice for a call of the WHOLE frame's size — 1 for a frame
+            # of 400 k rays or more, several for the small frames whose tiles would leave most wave slots idle
+            self.rc.kernel_family = field
+            split = int(self.lib.tn_render_sample_split(fld, self.rc, frame_rays))
+        finally:
+            self.rc.kernel_family, self.rc.sample_split = saved
         return prop, field, split
+
+    def _split_request(self, sample_split: Optional[int]) -> int:
+        """tn_render_config.sample_split for a call: the per-call argument, else the model's config.sample_split (0 = the library
+        decides, 1 = never: the serial march's bits, as model.get_outputs honours it), else 0"""
+        if sample_split is None:
+            sample_split = int(getattr(self.model.config, "sample_split", 0) or 0)
+            return max(sample_split, 0)
+        return max(int(sample_split), 1)
 
     @torch.no_grad()
     def render(self, origins: Tensor, directions: Tensor, out: Optional[Dict[str, Tensor]] = None,
