@@ -45,6 +45,7 @@ MFMA_16BIT_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 / f16 MFMA (AMD's 5 PF
 FIELD_FLOPS_PER_SAMPLE = 2 * (32 * 64 + 64 * 16 + 63 * 64 + 64 * 64 + 64 * 3 + 15 * 64 + 64 * 64 + 64 * 1)  # 33 024
 PROP_FLOPS_PER_SAMPLE = 2 * (10 * 16 + 16)  # 352
 P0, P1 = 256, 96
+TORCH_ADAM = False  # --torch-adam: the training variants with torch.optim.Adam(fused=True) and a joined scatter (A/B of round 6's HipAdam + deferred table update)
 ATOMIC_SCATTER = False  # --atomic-scatter: config.bucketed_table_scatter = False in the train-step variants (A/B)
 REF_CHUNK = 1 << 16  # REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:30
 
@@ -69,6 +70,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--atomic-scatter", action="store_true",
                     help="train steps with config.bucketed_table_scatter = False (global atomics on every level): A/B")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="training variants: torch.optim.Adam(fused=True) + joined table scatter instead of HipAdam + deferred table update")
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render (default): the BASELINE metric.  train: one optimisation step per 'step' "
                          "(BASELINE configs 3/5; with N ranks every rank trains its own scene replica, no collective)")
@@ -103,8 +106,9 @@ def parse():
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (profiling runs)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays per CPU-baseline repeat")
     a = ap.parse_args()
-    global ATOMIC_SCATTER
+    global ATOMIC_SCATTER, TORCH_ADAM
     ATOMIC_SCATTER = bool(a.atomic_scatter)
+    TORCH_ADAM = bool(a.torch_adam)
     return a
 
 
@@ -271,8 +275,14 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
     sd_cpu = synthetic.model_state_dict_cpu(model) if cpu else None
     model.to(dev).train()
     groups = model.get_param_groups()
-    opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]},
-                            {"params": groups["camera_opt"], "lr": 6e-4}], lr=1e-2, eps=1e-15, fused=True)
+    pgroups = [{"params": groups["fields"]}, {"params": groups["proposal_networks"]}, {"params": groups["camera_opt"], "lr": 6e-4}]
+    if TORCH_ADAM:  # --torch-adam (A/B): torch's fused Adam on the calling stream, the scatter joined by the backward
+        opt = torch.optim.Adam(pgroups, lr=1e-2, eps=1e-15, fused=True)
+    else:  # as thermo_nerf_amd.trainer.Trainer: HipAdam, the field's table update deferred to the step's side streams
+        from thermo_nerf_amd.optim import HipAdam
+
+        opt = HipAdam(pgroups, lr=1e-2, eps=1e-15, deferred=[model.field.mlp_base.encoder.hash_table])
+        model.config.deferred_table_update = True
     g = torch.Generator().manual_seed(0)
     side = int(rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
@@ -356,6 +366,9 @@ def measure_train_step(dev, samples: int, rays: int = 4096, steps: int = 240, wa
                                "cpu_model": cpu_model_name(),
                                "sample": "1 x %d rays forward+backward (torch autograd over the CPU oracle), no optimizer "
                                          "step" % n}
+    from thermo_nerf_amd import _hip
+
+    _hip.join_pending()  # the last step's deferred table update (and the temporaries it holds)
     del model, opt
     torch.cuda.empty_cache()
     return res
@@ -402,7 +415,8 @@ def measure_train_config3(dev, samples: int = 192, steps: int = 30000, window: i
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=V)
     synthetic.fill_model_(model, "init")
     model.to(dev)
-    tr = Trainer(model, ds, TrainerConfig(max_num_iterations=steps, train_num_rays_per_batch=rays))
+    tr = Trainer(model, ds, TrainerConfig(max_num_iterations=steps, train_num_rays_per_batch=rays,
+                                          optimizer_impl="torch" if TORCH_ADAM else "hip"))
     t_max, t_min = TEMPERATURE_BOUNDS
 
     def evaluate():

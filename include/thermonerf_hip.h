@@ -620,6 +620,33 @@ int tn_interlevel_loss_levels(const float *c, const float *w, int64_t num_rays, 
                               const float *const *cp, const float *const *wp, const int32_t *p, float scale, float *loss_sum,
                               float *const *d_wp, void *stream);
 
+/* ---- optimizer ------------------------------------------------------------------------------------------------------------
+ * torch.optim.Adam as the reference's method config sets it for every parameter group — AdamOptimizerConfig(lr 1e-2,
+ * eps 1e-15), nerfstudio's Optimizers.optimizer_step_all [REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:31-44;
+ * thermo_nerf/nerfacto_config/config_nerfacto.py:28-34 for camera_opt's weight decay] — over a LIST of tensors in ONE launch:
+ *     g = grad + weight_decay * param ;  m += (1 - beta1) (g - m) ;  v = beta2 v + (1 - beta2) g g ;
+ *     param -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * with the step-dependent scalars formed by the caller (step_size = lr / (1 - beta1^t), bias_correction2_sqrt =
+ * sqrt(1 - beta2^t), t = the tensor's own step count): tensors of different groups and step counts share a launch.
+ * `tensors` is a HOST array of `count` <= TN_ADAM_MAX_TENSORS descriptors (device pointers inside); param / exp_avg /
+ * exp_avg_sq are updated in place, grad is read only; tensors with n = 0 are skipped. */
+#define TN_ADAM_MAX_TENSORS 32
+typedef struct tn_adam_tensor {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t n;
+    float step_size;
+    float bias_correction2_sqrt;
+    float one_minus_beta1;
+    float beta2;
+    float one_minus_beta2;
+    float eps;
+    float weight_decay;
+} tn_adam_tensor;
+int tn_adam_step(const tn_adam_tensor *tensors, int32_t count, void *stream);
+
 /* library identification: returns a static string "thermonerf_hip <version> gfx950". */
 const char *tn_version(void);
 

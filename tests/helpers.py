@@ -59,10 +59,16 @@ def rays(h: int = 16, w: int = 16, view: int = 0) -> Tuple[torch.Tensor, torch.T
 CONFIG1 = dict(steps=1000, rays_per_batch=64, views=6, res=20, proposal=(64, 32), S=24, seed=5)
 
 
-def config1_problem():
+# the same problem at config 1's STATED step size [BASELINE.md §5; REF config_thermal_nerf.py:27]: 4096 rays per step, P = (256, 96),
+# S = 48 (the nerfacto default), full-size tables — 30 steps, held step for step (tools/make_config1_golden.py --batch4096)
+CONFIG1_FULL = dict(steps=30, rays_per_batch=4096, views=6, res=48, proposal=(256, 96), S=48, seed=6, small=False)
+
+
+def config1_problem(c=None):
     """Model / oracle config + the ray pool, per-step batch indices and jitter draws shared by the CPU run and the HIP run."""
-    c = CONFIG1
-    cm, sd, ocfg = build("init", c["S"], camera_optimizer_mode="off", num_proposal_samples_per_ray=c["proposal"], num_images=c["views"])
+    c = c or CONFIG1
+    cm, sd, ocfg = build("init", c["S"], small=c.get("small", True), camera_optimizer_mode="off",
+                         num_proposal_samples_per_ray=c["proposal"], num_images=c["views"])
     o, d, cam = [], [], []
     for v in range(c["views"]):
         ov, dv, _ = synthetic.orbit_camera_rays(c["res"], c["res"], view=v, num_views=c["views"], elevation_deg=(-10.0, 20.0, 50.0)[v % 3])

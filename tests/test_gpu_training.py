@@ -430,6 +430,36 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
     assert checked >= (13 if variant == "same_proposal_network" else 18)
 
 
+@pytest.mark.parametrize("pieces", [True, False])
+@pytest.mark.parametrize("S", [48, 192])
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+def test_training_step_gradients_against_the_fp64_oracle(kind, S, pieces):
+    """The whole step's parameter gradients with the oracle's FP64 run as the yardstick (SURVEY §8f-2 "gradcheck vs
+    restatement (fp64 ...)"): a fixed 2e-3 per tensor would let a dropped small term through, and the default backward runs its
+    K >= 32 products as bf16 pieces.  Per tensor: rel(HIP, fp64) <= 2 x rel(fp32 oracle, fp64) + 1e-5 — the HIP step may be at most
+    twice as far from the exact gradient as torch's own fp32 evaluation of the same graph is — with backward_bf16_pieces on (the
+    default: six-product splits of three exact bf16 pieces per operand) AND off (every product on the fp32 MFMA)."""
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, S, backward_bf16_pieces=pieces)
+    assert gm.config.tape_free_training and gm.config.backward_bf16_pieces is pieces
+    _gpu_step(gm, o, d, jit, cam, batch)
+    _, _, g32 = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit)
+    _, _, g64 = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit, dtype=torch.float64)
+    named = dict(gm.named_parameters())
+    rows, bad = [], []
+    for name, gw in g64.items():
+        if gw.numel() == 0 or name.startswith("camera_optimizer") or name.startswith("__") or gw.norm().item() < 1e-10:
+            continue
+        gg = named[name].grad
+        assert gg is not None, name
+        r_hip = float((gg.detach().cpu().double() - gw).norm() / gw.norm())
+        r_32 = float((g32[name].double() - gw).norm() / gw.norm())
+        rows.append((name, r_hip, r_32))
+        if r_hip > 2.0 * r_32 + 1e-5:
+            bad.append((name, r_hip, r_32))
+    print("\n".join(f"{n:58s} hip {a:.2e}  fp32 oracle {b:.2e}  ratio {a / max(b, 1e-30):.2f}" for n, a, b in rows))
+    assert len(rows) >= 18 and not bad, bad
+
+
 @pytest.mark.parametrize("update_step", [True, False])
 @pytest.mark.parametrize("S,hw", [(48, (12, 12)), (192, (7, 5))])
 @pytest.mark.parametrize("kind", ["stress", "scene"])

@@ -54,6 +54,15 @@ class tn_chain_layer(C.Structure):
                 ("d_bias", C.c_void_p)]
 
 
+class tn_adam_tensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("step_size", C.c_float), ("bias_correction2_sqrt", C.c_float), ("one_minus_beta1", C.c_float), ("beta2", C.c_float),
+                ("one_minus_beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+ADAM_MAX_TENSORS = 32  # TN_ADAM_MAX_TENSORS
+
+
 class tn_field_grads(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("base0_w", "base0_b", "base1_w", "base1_b", "head0_w", "head1_w", "head1_b", "head2_w",
                                          "head2_b", "th0_w", "th0_b", "th1_w", "th1_b", "thead_w", "thead_b")]
@@ -242,6 +251,7 @@ SIGNATURES = {
     "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_interlevel_loss_levels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_int32), C.c_float, _vp, C.POINTER(C.c_void_p), _vp]),
+    "tn_adam_step": (C.c_int, [C.POINTER(tn_adam_tensor), _i32, _vp]),
     "tn_version": (C.c_char_p, []),
 }
 
@@ -314,6 +324,9 @@ def current_stream() -> int:
 _CONCURRENT: dict = {}
 
 
+SIDE_STREAM_PRIORITY = 0  # torch.cuda.Stream(priority=...) of the candidates below: 0 = default, -1 = high (tools/train_bench.py --side-priority)
+
+
 def concurrent_streams(device, count: int, candidates: int = 12, with_main: bool = True) -> list:
     """``count`` HIP streams that run CONCURRENTLY with each other and — ``with_main`` — with torch's current stream on ``device``.
     ROCm maps streams onto four hardware queues, and two streams that share one execute their kernels one after the other:
@@ -336,7 +349,7 @@ def concurrent_streams(device, count: int, candidates: int = 12, with_main: bool
     hit = _CONCURRENT.get(key)
     if hit is not None:
         return hit
-    pool = [torch.cuda.Stream(device=dev) for _ in range(max(candidates, count))]
+    pool = [torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY) for _ in range(max(candidates, count))]
     try:
         if torch.cuda.is_current_stream_capturing():  # a synchronise would invalidate the capture
             return pool[:count]
@@ -385,6 +398,53 @@ def calibrate_streams(device, side_streams: int = 2, engine_streams: int = 2) ->
     training step and the chunk streams of RayRenderEngine — outside any timed region or stream capture."""
     concurrent_streams(device, side_streams)
     concurrent_streams(device, engine_streams, with_main=False)
+
+
+# ---- deferred table updates -----------------------------------------------------------------------------------------------------
+# The training step's longest dependent chain is  field backward -> scatter of d(hash table) -> Adam on the table -> next field
+# forward; everything else the step does after the field backward (ray-level adjoints, camera-pose backward, the small tensors'
+# Adam, the NEXT step's ray gather / camera optimizer / proposal pass / level geometry / field_prepare) depends on neither the table
+# nor its gradient.  With config.deferred_table_update the scatter's two halves and the table's Adam are queued on the step's side
+# streams and NOT joined; the calling stream runs on, and whoever next reads the table or its gradient on another stream first calls
+# join_pending — the training forward right before its field launch, the eval struct builders, Module.train()/state_dict(), the
+# Trainer at the end of train().  Temporaries those side launches read (d_enc, positions, the record workspace, the gradient arena)
+# are held here until the join: freed earlier, the caching allocator could hand them to the calling stream while a side kernel is
+# still pending.
+_PENDING: dict = {}
+
+
+def defer(device, streams, keep=()) -> None:
+    """register side-stream work on ``device`` that the current stream has NOT joined: the Stream objects it runs on and the
+    tensors it reads or writes (kept alive until join_pending)"""
+    e = _PENDING.setdefault(torch.device(device), {"streams": [], "keep": [], "scatter_done": []})
+    for s in streams:
+        if all(s.cuda_stream != t.cuda_stream for t in e["streams"]):
+            e["streams"].append(s)
+    e["keep"].extend(keep)
+
+
+def pending(device) -> Optional[dict]:
+    return _PENDING.get(torch.device(device))
+
+
+def join_pending(device=None) -> bool:
+    """torch's current stream on ``device`` (default: every device with deferred work) waits for the deferred table updates; their
+    temporaries are released.  Returns whether anything was pending.  A dictionary look-up when nothing is."""
+    if not _PENDING:
+        return False
+    devs = list(_PENDING) if device is None else [torch.device(device)]
+    hit = False
+    for dev in devs:
+        e = _PENDING.pop(dev, None)
+        if e is None:
+            continue
+        cur = torch.cuda.current_stream(dev)
+        for s in e["streams"]:
+            if s.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(s)
+        e["keep"].clear()
+        hit = True
+    return hit
 
 
 _ZERO_BLOCKS: dict = {}

@@ -134,6 +134,13 @@ class NerfactoModelConfig:
     overlap_table_scatter: bool = True
     """Training: the bucketed part of the field's table-gradient scatter runs on a second HIP stream beside the atomic part —
     disjoint levels of the gradient, one waiting on the memory-side atomic unit, the other on LDS and streaming (DESIGN §5.6)."""
+    deferred_table_update: bool = False
+    """Training (round 6; set by thermo_nerf_amd.trainer.Trainer with its HipAdam optimizer, off for a foreign training loop): the field's
+    table-gradient scatter — both halves — and the table's Adam run on the step's side streams and are NOT joined by the backward:
+    the calling stream goes on with everything that needs neither the table nor its gradient (ray-level adjoints, camera-pose
+    backward, the small tensors' Adam, the next step's ray gather / camera optimizer / proposal pass / field_prepare) and joins right
+    before the next field forward.  Whoever reads ``hash_table`` or its ``.grad`` on another stream in between calls
+    ``thermo_nerf_amd._hip.join_pending()`` first (Module.train / state_dict / the eval paths / Trainer.train's exit do)."""
     overlap_regularisers: Union[bool, str] = "auto"
     """Training: the distortion and interlevel terms are launched by the forward itself, on the step's side streams beside
     the depth renderers and the image losses (they depend on the forward's weights and bins only); get_metrics_dict /

@@ -94,6 +94,7 @@ class ThermalNerfactoTField(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def c_struct(self, prepare: bool = False, precision: str = "f32", dense: bool = True) -> _hip.tn_thermal_field:
+        _hip.join_pending()  # (config.deferred_table_update) the struct's users read the table on the calling stream
         f = _hip.tn_thermal_field()
         f.grid = self.mlp_base.encoder.c_struct(self.dense_budget_bytes if dense else 0)
         f.base0 = _hip.make_linear(self.mlp_base.mlp.layers[0])

@@ -348,7 +348,12 @@ class ThermalNerfModel(ThermalNerfactoModel):
         since they were built (it does not bump Parameter._version), and the eval kernels must never see a stale blob or
         dense re-layout."""
         self.invalidate_prepared()
+        _hip.join_pending()  # config.deferred_table_update: a table update still on the side streams ends here
         return super().train(mode)
+
+    def state_dict(self, *args, **kwargs):
+        _hip.join_pending()  # (the same: the copy a checkpoint takes runs on the calling stream)
+        return super().state_dict(*args, **kwargs)
 
     def invalidate_prepared(self) -> None:
         """Drop every derived copy of the weights (MFMA blobs, dense re-layouts, cached C structs).  The caches key on
@@ -373,6 +378,7 @@ class ThermalNerfModel(ThermalNerfactoModel):
 
     # --- fused: one C-ABI call ------------------------------------------------------------------------
     def _c_structs(self):
+        _hip.join_pending()  # eval launches read the tables on the calling stream
         # (the cached parameter list: walking the module tree costs more than a small eval call's kernels)
         key = tuple([(p.data_ptr(), p._version) for p in self.named_parameter_lists()[1]]) + (self.config.use_mfma,
                                                                                               self.config.mlp_precision)

@@ -18,7 +18,9 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
+from . import _hip
 from .cameras import Cameras
+from .optim import HipAdam
 from .rays import RayBundle
 from .training import backward_total, total_loss
 
@@ -71,6 +73,10 @@ class TrainerConfig:
     CPU).  This path computes in fp32 throughout — the parity target is the fp32 torch path (SURVEY §8f row 2) — so True is
     accepted for config compatibility, changes nothing, and says so once (a warning) instead of silently."""
     seed: int = 0
+    optimizer_impl: str = "hip"
+    """"hip": thermo_nerf_amd.optim.HipAdam — torch.optim.Adam's rule as one hand-written launch per group, the field's hash table
+    on the step's second stream behind its gradient's scatter, not joined until the next field forward (sets the model's
+    config.deferred_table_update).  "torch": torch.optim.Adam(fused=True) on the calling stream, the scatter joined by the backward."""
 
 
 class RayDataset:
@@ -120,8 +126,15 @@ class Trainer:
             oc = self.config.optimizers.get(name)
             if oc is None:
                 raise KeyError(f"no optimizer configured for parameter group '{name}'")
-            fused = all(p.is_cuda for p in params)  # one multi-tensor kernel per group instead of ~10 elementwise passes
-            opt = torch.optim.Adam(params, lr=oc.lr, eps=oc.eps, weight_decay=oc.weight_decay, fused=fused)
+            on_device = all(p.is_cuda for p in params)
+            if self.config.optimizer_impl == "hip" and on_device:
+                # the field's table: its scatter and its Adam stay on the side streams until the next field forward
+                table = [model.field.mlp_base.encoder.hash_table] if name == "fields" else []
+                opt = HipAdam(params, lr=oc.lr, eps=oc.eps, weight_decay=oc.weight_decay, deferred=table)
+                if table:
+                    model.config.deferred_table_update = True
+            else:  # one multi-tensor kernel per group instead of ~10 elementwise passes
+                opt = torch.optim.Adam(params, lr=oc.lr, eps=oc.eps, weight_decay=oc.weight_decay, fused=on_device)
             self.optimizers[name] = opt
             self.schedulers[name] = torch.optim.lr_scheduler.LambdaLR(opt, lambda s, oc=oc: exponential_decay_multiplier(oc, s))
         self.generator = torch.Generator(device=dataset.origins.device)
@@ -158,6 +171,7 @@ class Trainer:
             self.step += 1
             if checkpoint_dir is not None and self.step % self.config.steps_per_save == 0:
                 self.save_checkpoint(checkpoint_dir)
+        _hip.join_pending()  # the last step's table update (config.deferred_table_update): whatever follows may read the table
         return history
 
     # nerfstudio's Trainer.save_checkpoint layout: step, pipeline, optimizers, schedulers (scalers: no AMP here)
@@ -165,6 +179,7 @@ class Trainer:
         directory = Path(directory)
         directory.mkdir(parents=True, exist_ok=True)
         path = directory / f"step-{self.step:09d}.ckpt"
+        _hip.join_pending()
         torch.save({
             "step": self.step,
             "pipeline": {"_model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()},

@@ -104,7 +104,7 @@ def _step_streams(dev) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch
 
 
 def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bucketed=False, spread: bool = True,
-                    overlap: bool = False, side_work=None, keep: Optional[list] = None) -> None:
+                    overlap: bool = False, side_work=None, keep: Optional[list] = None, defer: bool = False) -> bool:
     """d_table += adjoint of the hash encoding.  ``bucketed=False``: the global-atomic scatter (tn_hash_encode_bwd).
     ``True`` (config.bucketed_table_scatter): from the level the library names (scaling >= 200, enough table slices: the
     field's grid, not the proposal grids) the contributions are written out as records bucketed by the owning table slice and
@@ -117,11 +117,15 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
     (the step's ray-level adjoints): queued on the calling stream behind the atomic part, before the join — the bucketed part
     on the second stream is the longer of the two.  ``keep``: the caller queues this call on another stream than the
     allocator's (_STREAM_OVERRIDE) and holds the temporaries appended here — the record workspace — until it has joined that
-    stream (freed on return, the block could be handed to the main stream while the side stream still works in it)."""
+    stream (freed on return, the block could be handed to the main stream while the side stream still works in it).
+    ``defer`` (config.deferred_table_update, with ``overlap`` and a bucketed part): BOTH parts go to side streams — the bucketed one
+    to the second, the atomic one to the third — and the calling stream does not wait for them: it runs ``side_work`` and returns
+    True; the join is the caller's business (_hip.defer / _hip.join_pending hold the temporaries until then).  Returns False when
+    the scatter was joined as usual."""
     if side_work is not None and not overlap:
         hash_encode_bwd(grid, space, pos, d_enc, d_table, bucketed, spread, keep=keep)
         side_work()
-        return
+        return False
     lib = _hip.load()
     n = pos.shape[0]
     first = -1
@@ -134,7 +138,7 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, grid.num_levels, spread)
         if side_work is not None:
             side_work()
-        return
+        return False
     try:
         ws = torch.empty(need, dtype=torch.uint8, device=pos.device)  # 25 B per (sample, level, corner pair): 0.14-0.6 GB, from torch's caching allocator
         if keep is not None:
@@ -145,7 +149,29 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
                                                  grid.num_levels, _stream()), "tn_hash_encode_bwd_levels")
         if side_work is not None:
             side_work()
-        return
+        return False
+    if overlap and first > 0 and defer:
+        main, side, third = _step_streams(pos.device)
+        side.wait_stream(main)  # d_enc, positions and the cleared d_table are the main stream's work so far
+        third.wait_stream(main)
+        _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first,
+                                                 ws.data_ptr(), need, side.cuda_stream), "tn_hash_encode_bwd_sorted")
+        saved = _STREAM_OVERRIDE[0]
+        _STREAM_OVERRIDE[0] = third.cuda_stream  # (the spread copies' workspace is keyed by the stream: the third's own)
+        try:
+            _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
+        finally:
+            _STREAM_OVERRIDE[0] = saved
+        if side_work is not None:
+            side_work()  # on the calling stream, beside both parts
+        # (NOT d_table itself: autograd's AccumulateGrad takes a returned gradient over without a copy only while nobody else
+        # holds that tensor object — a second reference makes it CLONE the table gradient on the calling stream, i.e. before the
+        # side streams have written it.  The caller keeps the storage alive through another view: the arena's flat buffer.)
+        _hip.defer(pos.device, [side, third], [ws, pos, d_enc])
+        done = torch.cuda.Event()
+        done.record(side)  # the bucketed half's end (the table's Adam is queued behind it later): see RenderTrain.forward
+        _hip.pending(pos.device)["scatter_done"] = [done, third]
+        return True
     if overlap and first > 0:
         main, side, _ = _step_streams(pos.device)
         side.wait_stream(main)  # d_enc, positions and the cleared d_table are the main stream's work so far
@@ -155,13 +181,14 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
         if side_work is not None:
             side_work()  # behind the atomic part: the bucketed part is the longer of the two (timeline in DESIGN 5.6)
         main.wait_stream(side)  # also what keeps `ws`, d_enc and pos (main-stream allocations) from being reused too early
-        return
+        return False
     if first > 0:
         _atomic_levels(lib, grid, space, pos, d_enc, d_table, 0, first, spread)
     _hip.check(lib.tn_hash_encode_bwd_sorted(grid, space, pos.data_ptr(), d_enc.data_ptr(), n, d_table.data_ptr(), first, ws.data_ptr(),
                                              need, _stream()), "tn_hash_encode_bwd_sorted")
     if side_work is not None:
         side_work()
+    return False
 
 
 def linear_fwd(x: Tensor, x_off: int, ldx: int, lin, act: int, n: int) -> Tensor:
@@ -448,6 +475,15 @@ class RenderTrain(torch.autograd.Function):
         else:
             # nerfstudio evaluates the proposal densities under no_grad on these steps (5 of 6 after warm-up): no tape is
             # needed, so both levels run as ONE fused kernel (tn_proposal_sample_fwd, train-mode semantics)
+            pend = _hip.pending(dev)
+            if pend is not None and pend.get("scatter_done") and getattr(cfg, "deferred_proposal_after_scatter", False):
+                # the previous step's scatter still runs: its owner blocks need whole CUs (16 waves + 128 KB of LDS each), and a
+                # resident proposal pass keeps them out — wait for the scatter's END (not for the table's Adam behind it, a light
+                # streaming launch this pass then runs beside)
+                ev, third_s = pend["scatter_done"]
+                _step_streams(dev)[0].wait_event(ev)
+                _step_streams(dev)[0].wait_stream(third_s)
+                pend["scatter_done"] = []
             rc = _hip.tn_render_config()
             rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = P[0], P[1], S
             rc.training, rc.pdf_anneal, rc.early_stop_transmittance, rc.kernel_family = 1, anneal, 0.0, 0
@@ -491,6 +527,9 @@ class RenderTrain(torch.autograd.Function):
             # stage-by-stage entry points below
             fused = model.field.train_struct(prepare=True)
         tape_free = tape_free and fused is not None
+        # config.deferred_table_update: the previous step's table scatter + Adam may still be running on the side streams; everything
+        # above (camera optimizer, proposal pass, level geometry, field_prepare) needed neither — the field's table reads do
+        _hip.join_pending(dev)
         h1 = bo = cin = c1 = c2 = t1 = t2 = None
         if tape_free:
             # no activation tape: the per-ray constant inputs of mlp_head.0 (SH(direction), appearance embedding) become a
@@ -703,8 +742,12 @@ class RenderTrain(torch.autograd.Function):
                                                             ray_grads[0].data_ptr(), ray_grads[1].data_ptr(), _stream()),
                                "tn_frustum_positions_bwd")
 
-            hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, grads["field.mlp_base.encoder.hash_table"], bucketed, spread,
-                            getattr(cfg, "overlap_table_scatter", True), ray_level_adjoints)
+            # config.deferred_table_update: both halves on side streams, not joined here (steps whose third stream carries the
+            # proposal levels' backward keep the joined form: that chain and the atomic half would queue behind one another)
+            defer = bool(getattr(cfg, "deferred_table_update", False)) and prop_join is None
+            if hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, grads["field.mlp_base.encoder.hash_table"], bucketed, spread,
+                               getattr(cfg, "overlap_table_scatter", True), ray_level_adjoints, defer=defer):
+                _hip.defer(dev, (), [arena.flat, f.enc, g_density, g_rgb_s, g_th_s])
             return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop, prop_join)
         ldb = bo.shape[1]
         g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass

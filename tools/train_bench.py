@@ -46,8 +46,15 @@ def main():
                     "streams come from the default-priority pool): main-chain kernels are dispatched ahead of the side streams'")
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
+    ap.add_argument("--side-priority", type=int, default=0, help="priority of the step's side streams (-1 = high)")
+    ap.add_argument("--proposal-after-scatter", action="store_true", help="config.deferred_proposal_after_scatter")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) + joined table scatter (rounds 1-5)")
+    ap.add_argument("--joined-table", action="store_true", help="HipAdam, but the table's scatter and Adam joined by the backward / on the calling stream")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    from thermo_nerf_amd import _hip as _H
+
+    _H.SIDE_STREAM_PRIORITY = a.side_priority
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt,
                                  bucketed_table_scatter=not a.atomic_scatter, tape_free_training=not a.taped,
                                  fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread,
@@ -61,7 +68,14 @@ def main():
     pg = [{"params": groups["fields"]}, {"params": groups["proposal_networks"]}]
     if "camera_opt" in groups:
         pg.append({"params": groups["camera_opt"], "lr": 6e-4})
-    opt = torch.optim.Adam(pg, lr=1e-2, eps=1e-15, fused=True)
+    if a.torch_adam:
+        opt = torch.optim.Adam(pg, lr=1e-2, eps=1e-15, fused=True)
+    else:  # as thermo_nerf_amd.trainer.Trainer: HipAdam, the field's table update left on the step's side streams (round 6)
+        from thermo_nerf_amd.optim import HipAdam
+
+        opt = HipAdam(pg, lr=1e-2, eps=1e-15, deferred=[] if a.joined_table else [model.field.mlp_base.encoder.hash_table])
+        model.config.deferred_table_update = not a.joined_table
+        model.config.deferred_proposal_after_scatter = bool(a.proposal_after_scatter)
     g = torch.Generator().manual_seed(0)
     side = int(a.rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
