@@ -30,6 +30,13 @@ def test_config1_one_thousand_cpu_iterations_fit_the_scene(golden_dir):
 
     gold = np.load(os.path.join(golden_dir, "config1_oracle.npz"))
     assert np.abs(loss[:20] - gold["losses"][:20]).max() <= 2e-3 * np.abs(gold["losses"][:20]).max()
+    # round 6: the fixture's SET of valid fp32 runs (thread counts 1 / 2 / 4 / 8, a permuted batch order) — entry 0 is this very run,
+    # and the set's own spread over the descent is what the GPU test's envelope rests on
+    assert [str(x) for x in gold["run_labels"]][0] == "threads1" and gold["losses_set"].shape == (5, 1000)
+    assert np.array_equal(gold["losses_set"][0], gold["losses"])
+    ws = gold["losses_set"].reshape(5, 10, 100).mean(axis=2)
+    spread = ws.max(axis=0) / ws.min(axis=0)
+    assert (spread[:3] < 1.15).all() and (spread[3:6] > 1.15).all() and (spread[3:6] < 1.6).all(), spread
     gw = gold["losses"].reshape(10, 100).mean(axis=1)
     assert (np.abs(windows[:6] - gw[:6]) <= 0.5 * gw[:6]).all(), (windows, gw)
     assert (gw[6:] < gw[1]).all()
@@ -43,3 +50,17 @@ def test_config1_one_thousand_cpu_iterations_fit_the_scene(golden_dir):
     # the sampler's schedule over this horizon: every step below 10, then every second step (update_sched == 1)
     upd = helpers.proposal_updates(1000)
     assert all(upd[:10]) and upd[10:20] == [False, True] * 5 and sum(upd) == 10 + 495
+
+
+def test_config1_full_batch_fixture_is_this_oracles_run(golden_dir):
+    """tests/golden/config1_batch4096.npz (config 1 at its stated step size: 4096 rays x P=(256,96) x S=48, full-size tables, 30 steps;
+    the GPU suite follows it step for step): its first step is reproduced live — the same problem, the same oracle."""
+    import os
+
+    gold = np.load(os.path.join(golden_dir, "config1_batch4096.npz"))
+    c = helpers.CONFIG1_FULL
+    assert gold["losses"].shape == (c["steps"],) and int(gold["rays_per_batch"]) == 4096 and int(gold["S"]) == 48
+    assert np.isfinite(gold["losses"]).all() and gold["losses"][-1] < 0.5 * gold["losses"][0]
+    prob = helpers.config1_problem(c)
+    losses, _ = helpers.config1_oracle_run(prob, steps=1, threads=min(8, torch.get_num_threads()))
+    assert abs(losses[0] - gold["losses"][0]) <= 1e-5 * abs(gold["losses"][0]), (losses[0], gold["losses"][0])

@@ -959,8 +959,8 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     recorded them in tests/golden/config1_oracle.npz — the GPU box's shared host cores can be 40x slower under load) and the
     same 1000 steps on the HIP path: same batches, jitter draws, anneal and proposal-update schedule.  Trajectories of a
     1000-step Adam run separate chaotically at the fp32 rounding level (two CPU runs do), so the claim is: step for step over
-    the first 20 steps (2e-3 relative), the 100-step means of the two loss curves within a factor of two of each other over the descent
-    (600 steps), both staying converged after it, and the same final quality on held-out pixels (1.5 dB, 0.02 of the normalised
+    the first 20 steps (2e-3 relative), the 100-step means of the HIP loss curve inside the envelope x 1.25 of FIVE recorded CPU runs
+    (thread counts 1 / 2 / 4 / 8 and a permuted batch order) over the descent (600 steps), both staying converged after it, and the same final quality on held-out pixels (1.5 dB, 0.02 of the normalised
     thermal range, both improving on the initial thermal MAE by 2.5x)."""
     import os
 
@@ -997,13 +997,16 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     for i in range(20):
         assert abs(got[i] - want[i]) <= 2e-3 * abs(want[i]), (i, got[i], want[i])
     gw, ww = got.reshape(10, 100).mean(axis=1), want.reshape(10, 100).mean(axis=1)
-    # CPU runs that differ only in their thread count agree within 2 % / 5 % / 33 % / 20 % / 20 % on windows 1-5 (window 3:
-    # 0.0039 ... 0.0052) and by up to 5x
-    # on the last windows (64-ray batches at a constant lr of 1e-2: the late stage wanders): the HIP run is held to the same band
-    # (round 5, tools/config1_spread.py: fourteen HIP runs — with the fp32 and with the bf16-piece backward alike — sit at 0.98 … 1.51 x
-    # the ONE recorded CPU trajectory in windows 4-6, whose values are 0.002 … 0.005: a +-50 % band failed two suite runs in eight;
-    # the band is a factor of two either way)
-    assert (gw[:6] <= 2.0 * ww[:6]).all() and (gw[:6] >= 0.5 * ww[:6]).all(), (gw, ww)
+    # Round 6: the fixture holds FIVE valid fp32 runs of the reference path — 1 / 2 / 4 / 8 intra-op threads and the
+    # batches' rays in another order (tools/make_config1_golden.py).  Their 100-step means spread by 1.00 / 1.01 / 1.08 / 1.39 / 1.24 /
+    # 1.32 (max / min) over windows 1-6 and by up to 2.9x afterwards, and the one-thread run the earlier rounds compared with is the
+    # set's MINIMUM in windows 4-6 (0.00367 / 0.00231 / 0.00183 against 0.0037-0.0051 / 0.0025-0.0029 / 0.0022-0.0024): the fourteen
+    # HIP runs at 0.98 ... 1.51 x that one trajectory (round 5's "one-sided" band) sit inside the CPU set's own spread.  Each HIP window
+    # of the descent is held inside the set's [min, max] x 1.25 — a systematic bias of the step beyond a quarter of the envelope fails.
+    ws = gold["losses_set"].reshape(-1, 10, 100).mean(axis=2)
+    assert ws.shape[0] >= 5
+    lo, hi = ws.min(axis=0), ws.max(axis=0)
+    assert (gw[:6] <= 1.25 * hi[:6]).all() and (gw[:6] >= lo[:6] / 1.25).all(), (gw, lo, hi)
     # (the descent flattens by window 6: two runs in twenty-six had window 6 at 1.00-1.02 x window 5)
     assert (np.diff(gw[:5]) < 0).all() and gw[5] < 1.15 * gw[4] and gw[5] < 0.06 * gw[0], gw
     assert (gw[6:] < gw[1]).all() and (ww[6:] < ww[1]).all(), (gw, ww)
@@ -1027,6 +1030,51 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     ref = H.get_outputs(sd_hip, h["o"], h["d"], None, prob["ocfg"], anneal=float(gm.proposal_sampler._anneal))
     assert (out["rgb"].cpu() - ref["rgb"]).abs().mean() <= 1e-4
     assert (out["thermal"].cpu() - ref["thermal"]).abs().mean() <= 1e-4
+
+
+def test_config1_at_its_stated_step_size_follows_the_cpu_path_step_for_step(golden_dir):
+    """BASELINE config 1 at the step size it states [BASELINE.md §5; REF config_thermal_nerf.py:27]: 4096 rays per step, P = (256, 96),
+    S = 48, full-size tables — 30 Adam steps from nerfstudio's initialisation on the HIP path against the same 30 on the CPU
+    reference path (recorded by tools/make_config1_golden.py --batch4096: same batches, jitter, anneal, update schedule).  A
+    4096-ray mean is smooth enough that the two trajectories stay together while rounding differences grow step by step (measured:
+    exactly equal or 1e-7 over the first ten steps, 3e-5 at step 10, 3e-4 at step 20, 7e-4 ... 9e-4 at step 29 — the table scatter's
+    atomics make the HIP run itself vary in the last digit): every loss of the first 20 steps within 1e-3 relative, the last ten within 5e-3."""
+    import os
+
+    import numpy as np
+
+    prob = helpers.config1_problem(helpers.CONFIG1_FULL)
+    gold = np.load(os.path.join(golden_dir, "config1_batch4096.npz"))
+    want = gold["losses"]
+    steps = helpers.CONFIG1_FULL["steps"]
+    assert want.shape == (steps,) and int(gold["rays_per_batch"]) == 4096 and tuple(gold["proposal"]) == (256, 96) and int(gold["S"]) == 48
+    gm = copy.deepcopy(prob["model"]).to(DEV)
+    gm.train()
+    assert gm.field.mlp_base.encoder.hash_table.shape[0] == 16 << 19
+    params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
+    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, fused=True)
+    o, d, cam = prob["o"].to(DEV), prob["d"].to(DEV), prob["cam"].to(DEV)
+    img, th, idx = prob["image"].to(DEV), prob["thermal"].to(DEV), prob["idx"].to(DEV)
+    jitter = prob["jitter"].squeeze(-1).to(DEV)
+    upd = helpers.proposal_updates(steps)
+    got = []
+    for i in range(steps):
+        gm.set_step(i)
+        ix = idx[i]
+        rb = gm.collider(RayBundle(origins=o[ix], directions=d[ix], camera_indices=cam[ix]))
+        out = TR.get_outputs_train(gm, rb, jitter=jitter[i].contiguous())
+        assert (gm.proposal_sampler._steps_since_update == 0) == upd[i], i
+        b = {"image": img[ix], "thermal": th[ix]}
+        loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        got.append(loss.detach())
+    got = torch.stack(got).cpu().numpy()
+    worst = np.abs(got - want) / np.abs(want)
+    print("relative loss difference per step:", " ".join(f"{x:.1e}" for x in worst))
+    assert np.isfinite(got).all() and worst[:20].max() <= 1e-3 and worst.max() <= 5e-3, (worst.argmax(), worst.max(), got, want)
+    assert got[-1] < 0.5 * got[0]  # and it descends
 
 
 @pytest.mark.parametrize("sh_grad", [False, True])
