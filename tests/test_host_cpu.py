@@ -81,6 +81,31 @@ def test_no_cpu_fallback():
         model.proposal_networks[0].density_fn(torch.rand(5, 3))
 
 
+def test_predict_normals_ends_where_the_reference_ends(golden_dir):
+    """G9 (tests/golden/predict_normals.json: the reference's own get_outputs executed with config.predict_normals=True,
+    tools/make_golden_g9.py): its field override never evaluates nerfstudio's predicted-normals head — the field returns RGB /
+    THERMAL / DENSITY / NORMALS — and the model ends in KeyError(FieldHeadNames.PRED_NORMALS) right after rendering the analytic
+    normals, in every forward.  The product raises the same exception with the same key, in eval and in training, before any
+    device work; it does not invent outputs the reference cannot produce."""
+    import json
+
+    gold = json.load(open(os.path.join(golden_dir, "predict_normals.json")))
+    assert gold["field_output_keys"] == ["RGB", "THERMAL", "DENSITY", "NORMALS"]
+    exc = gold["exception"]
+    assert exc["type"] == "KeyError" and exc["raised_after"][-1] == "renderer_normals"
+    model, _, _ = helpers.build("init", 8, predict_normals=True)
+    assert model.config.predict_normals is True
+    o, d = helpers.rays(2, 2)
+    rb = tna.RayBundle(origins=o, directions=d, camera_indices=torch.zeros(4, 1, dtype=torch.long))
+    for training in (False, True):
+        model.train(training)
+        with pytest.raises(KeyError) as err:
+            model(rb)
+        key = err.value.args[0]
+        assert key is tna.fields.FieldHeadNames.PRED_NORMALS and key.name == exc["key_name"] and key.value == exc["key_value"]
+    model.eval()
+
+
 def test_packed_samples_rejected_like_reference():
     r = tna.ThermalRenderer()
     with pytest.raises(NotImplementedError):

@@ -15,7 +15,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "populate_modules.jso
 
 # built by the reference, not by the product, and why
 NOT_BUILT = {
-    "NormalsRenderer": "predict_normals raises on this path (off in every reference config)",
+    "NormalsRenderer": "predict_normals=True ends in KeyError(PRED_NORMALS) in the reference itself (G9, tests/golden/predict_normals.json): never used",
     "NormalsShader": "same",
     "MSELoss": "both MSE terms come from tn_image_losses (one launch with the PSNR)",
     "PeakSignalNoiseRatio": "thermo_nerf_amd.cameras.psnr / tn_image_losses",

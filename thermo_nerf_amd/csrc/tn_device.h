@@ -325,25 +325,7 @@ __device__ __forceinline__ void dense_gather(const G &g, int l, const HashTaps &
 __device__ __forceinline__ void hash_hold(HashTaps &t) {
     asm volatile("" : "+v"(t.ox), "+v"(t.oy), "+v"(t.oz)::"memory");
 }
-#ifndef TN_BLEND_PACKED
-// 1: the trilinear blend's two features per corner as packed fp32 (14 v_pk_add + v_pk_fma pairs per level instead of 28 scalar
-// pairs).  Measured (round 5, tools/ab_run.sh, two repeats): field kernel 30.42 against 30.36 ms (256 registers, 44 B of scratch),
-// proposal kernel 2.84 against 2.87 ms: off.
-#define TN_BLEND_PACKED 0
-#endif
 __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f)[8]) {
-#if TN_BLEND_PACKED
-    // both features of a corner in one packed instruction (v_pk_add_f32 + v_pk_fma_f32 per lerp instead of 2 + 2): the same
-    // roundings, bit for bit; the corner pairs arrive as aligned register pairs from the 8-byte gathers
-    typedef float v2 __attribute__((ext_vector_type(2)));
-    auto L = [](v2 a, v2 b, float o) { return __builtin_elementwise_fma(v2{o, o}, a - b, b); };
-    auto V = [](const float2 &x) { return v2{x.x, x.y}; };
-    const v2 f03 = L(V(f[0]), V(f[3]), t.ox), f12 = L(V(f[1]), V(f[2]), t.ox);
-    const v2 f56 = L(V(f[5]), V(f[6]), t.ox), f47 = L(V(f[4]), V(f[7]), t.ox);
-    const v2 f0312 = L(f03, f12, t.oy), f4756 = L(f47, f56, t.oy);
-    const v2 r = L(f0312, f4756, t.oz);
-    return make_float2(r[0], r[1]);
-#else
     float2 r;
     {
         const float f03 = lerp_t<true>(f[0].x, f[3].x, t.ox), f12 = lerp_t<true>(f[1].x, f[2].x, t.ox);
@@ -358,7 +340,6 @@ __device__ __forceinline__ float2 hash_blend(const HashTaps &t, const float2 (&f
         r.y = lerp_t<true>(f0312, f4756, t.oz);
     }
     return r;
-#endif
 }
 
 // NL hashed levels of one position (FAST flavour), software-pipelined over groups of LG levels: the 8*LG gathers of group
@@ -550,9 +531,6 @@ __device__ __forceinline__ void depth_bounds_flush(const DepthSlots &m, long lon
 }
 
 // ---- wave64 collectives ------------------------------------------------------------------------------
-#ifndef TN_WAVE_SCAN_DPP
-#define TN_WAVE_SCAN_DPP 1
-#endif
 // The wave scans on the vector unit's data-parallel primitives instead of ds_bpermute steps (six dependent LDS round trips per
 // scan in kernels that are one latency chain per ray): row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast:15 into rows 1
 // and 3, row_bcast:31 into rows 2 and 3 — the GCN wave64 scan; a lane without a source keeps its value.  All lanes must be active.
@@ -561,33 +539,19 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
 }
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#if TN_WAVE_SCAN_DPP
     v = dpp_add<0x111, 0xf>(v);
     v = dpp_add<0x112, 0xf>(v);
     v = dpp_add<0x114, 0xf>(v);
     v = dpp_add<0x118, 0xf>(v);
     v = dpp_add<0x142, 0xa>(v);
     v = dpp_add<0x143, 0xc>(v);
-#else
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-#endif
     return v;
 }
 // PRECONDITION (DPP form): every lane of the wave is active — lane 63 in particular, whose scan value is read back; a
 // caller inside divergent control flow must hoist the call out of it (all ~40 call sites sit at wave-uniform points: the
 // per-ray kernels run one ray per FULL wave and mask lanes by value, not by branch).
 __device__ __forceinline__ float wave_sum(float v) {
-#if TN_WAVE_SCAN_DPP
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_scan(v, 0)), 63));
-#else
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-#endif
 }
 
 // one lane's value in every lane (v_readlane_b32: a scalar move, no LDS round trip; the lane must be active)
@@ -598,12 +562,7 @@ __device__ __forceinline__ float lane_value(float v) {
 
 // exclusive prefix from an inclusive one (robust to inf entries: no inf - inf)
 __device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
-#if TN_WAVE_SCAN_DPP
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(incl), 0x138, 0xf, 0xf, false));  // wave_shr:1, lane 0 <- 0
-#else
-    const float up = __shfl_up(incl, 1, 64);
-    return lane == 0 ? 0.0f : up;
-#endif
 }
 
 }  // namespace tn

@@ -24,9 +24,6 @@
 #ifndef TN_PROP_SPLIT
 #define TN_PROP_SPLIT 1  // calls under 3 072 tiles: the lane = ray proposal pass as density segments + per-tile resampling (same bits)
 #endif
-#ifndef TN_PROP_GROUPS
-#define TN_PROP_GROUPS 32  // levels per gather stage of the lean proposal density: 3 + 2 (32) or 2 + 2 + 1 (221)
-#endif
 // s_setprio of a proposal wave while it computes a level group's indices and issues its gathers (0 = none): four waves share a
 // SIMD, and the one whose memory requests can go out goes ahead of the others' interpolation / MLP arithmetic —
 // proposal_rays_kernel 2.93 -> 2.89 ms per 640 k rays at S=192, 2.82 -> 2.76 at S=64 (round 4, A/B both orders; same bits).
@@ -317,14 +314,8 @@ __device__ __forceinline__ float proposal_density_kmajor(const Grid &g, const tn
                 for (int l = l0; l < l1; ++l) f[l] = hash_blend(t[l - l0], fv[l - l0]);
                 TN_STAGE_FENCE();
             };
-#if TN_PROP_GROUPS == 221
-            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-            group(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-            group(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
-#else
             group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
             group(std::integral_constant<int, 3>{}, std::integral_constant<int, 5>{});
-#endif
         } else {
 #pragma unroll
             for (int l = 0; l < 5; ++l) f[l] = (l < ND) ? encode_level<true, FAST>(g, l, px, py, pz) : encode_level<false, FAST>(g, l, px, py, pz);

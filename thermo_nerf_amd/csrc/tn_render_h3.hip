@@ -34,20 +34,6 @@ constexpr int LG = 4;
 #ifndef TN_SPLIT_MLP_PRIO
 #define TN_SPLIT_MLP_PRIO 1
 #endif
-#ifndef TN_BF16_PK_SUB
-#define TN_BF16_PK_SUB 0
-#endif
-#ifndef TN_WAVES32
-#define TN_WAVES32 12
-#endif
-#ifndef TN_SPLIT_WAVE32
-// 1: main_split_rays32_kernel (one 32-ray tile per wave) where the grid allows it.  Built, parity-green and MEASURED SLOWER (round 5,
-// profiles/micro/round5_split_wave32_ab.txt): bf16x6 field kernel 28.2 ms with three waves per SIMD (168 registers, 64-80 spilled
-// dwords), 22.7 with two, against 21.8 for the 64-ray kernel on the same box (f16x3: 19.7 / 16.9 / 14.9) — the SIMD's time is its
-// MFMA time plus its un-hidden vector instructions whatever the number of waves they come from, and a 32-ray wave reads every A
-// fragment for one tile instead of two.  Off: the kernel and its four extra A-fragment combos are not compiled.
-#define TN_SPLIT_WAVE32 0
-#endif
 
 // ---- the two splits ------------------------------------------------------------------------------------------------------------
 // piece 0 is the leading one.  A block's LDS holds the A fragments of all 30 (layer, tile, k-step) combos: 16 B per lane, combo
@@ -76,13 +62,6 @@ struct F16x3 {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
     }
     static __device__ __forceinline__ void mma(f32x16 &acc, const vec (&a)[NP], const vec (&b)[NP]) {
-#ifdef TN_H3_PROBE_SIX_PRODUCTS
-        // timing probe only: the matrix-pipe load of a SIX-product split — three more MFMAs per step that add zeros
-        const v8h z = {0, 0, 0, 0, 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, b[0], acc, 0, 0, 0);
-#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
@@ -109,20 +88,11 @@ struct BF16x6 {
         const b2 p1 = __builtin_convertvector(v, b2);
         pk[0] = __builtin_bit_cast(unsigned, p1);
         // (scalar subtractions: as one v_pk_add_f32 per pair the kernel took 23.2 instead of 21.5 ms in round 4 — aligned register
-        // pairs, more spills — and 21.9 against 21.0 with round 5's pipelined layers: -DTN_BF16_PK_SUB=1)
-#if TN_BF16_PK_SUB
-        const f2 q1 = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u)};
-        const f2 r1 = v - q1;
-        const b2 p2 = __builtin_convertvector(r1, b2);
-        pk[1] = __builtin_bit_cast(unsigned, p2);
-        const f2 q2 = {__uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
-        const f2 r2 = r1 - q2;
-#else
+        // pairs, more spills — and 21.9 against 21.0 with round 5's pipelined layers; that variant is in git history, HISTORY.md)
         const f2 r1 = {x0 - __uint_as_float(pk[0] << 16), x1 - __uint_as_float(pk[0] & 0xffff0000u)};
         const b2 p2 = __builtin_convertvector(r1, b2);
         pk[1] = __builtin_bit_cast(unsigned, p2);
         const f2 r2 = {r1[0] - __uint_as_float(pk[1] << 16), r1[1] - __uint_as_float(pk[1] & 0xffff0000u)};
-#endif
         pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2));
     }
     static constexpr int NPROD = 6;  // (0,2) (2,0) (1,1) (0,1) (1,0) (0,0): small terms first
@@ -145,9 +115,7 @@ struct BF16x6 {
 // ---- blob / LDS layout ------------------------------------------------------------------------------------
 // A fragments: [30 combos][64 lanes][NP pieces][8 elements] = 16 NP bytes per lane and combo; then the fp32 biases / output rows
 constexpr int C_BASE1 = 0, C_BASE2 = 4, C_C1 = 8, C_T1 = 12, C_C2 = 14, C_T2 = 22;
-// + mlp_base layer 0 once more with its K index in the PAIRED level order of the 32-ray kernel (main_split_rays32_kernel: lane half h
-// of a ray evaluates the levels 2 p + h, so K index 8 h + e of k-step ks is feature (e & 1) of level 8 ks + 2 (e >> 1) + h)
-constexpr int C_BASE1P = 30, N_COMBOS = TN_SPLIT_WAVE32 ? 34 : 30;
+constexpr int N_COMBOS = 30;
 template <int NP>
 struct Lay {
     static constexpr int A_FLOATS = N_COMBOS * 64 * 4 * NP;
@@ -191,10 +159,6 @@ __device__ __forceinline__ float frag_weight(const RawField &w, int combo, int i
     if (combo < C_C2) {  // mlp_thermal layer 0 [64,15]
         const int mt = combo - C_T1, row = krow(0, e, h);
         return row >= 1 ? w.t0w[(i + 32 * mt) * GF + row - 1] : 0.0f;
-    }
-    if (combo >= C_BASE1P) {  // mlp_base layer 0 [64,32], paired level order
-        const int c = combo - C_BASE1P, mt = c >> 1, ks = c & 1;
-        return w.b0w[(i + 32 * mt) * 32 + 2 * (8 * ks + 2 * (e >> 1) + h) + (e & 1)];
     }
     const bool thermal = combo >= C_T2;
     const int c = combo - (thermal ? C_T2 : C_C2), mt = c >> 2, ks = c & 3;
@@ -355,9 +319,6 @@ __device__ __forceinline__ void pack_step(const float (&v)[16], Pieces<P> &t0, P
 // of work per 24 k-cycle pass.  Here the split of k-step ks + 1 is placed UNDER the MFMAs of k-step ks: one scheduling region per
 // k-step (sched_barrier on both sides) with an explicit issue pattern — one MFMA, then a few vector instructions — so a wave's own
 // vector work rides in its own MFMA shadow and only the first split of a layer is exposed.
-#ifndef TN_SPLIT_PIPELINE
-#define TN_SPLIT_PIPELINE 1
-#endif
 // A [64 x 64] x relu(in) product, NMT output tiles of 32 features (layer64: 2, mlp_base's second layer: 1), as a software pipeline
 // over (k-step, ray tile): the 2 NMT NPROD ... MFMAs of one (ks, nt) in four chunks, each followed by the split of ONE value pair of the
 // NEXT (ks, nt)'s B operand, a scheduling fence after every chunk — the order below is the order in the binary.  Only the very
@@ -403,20 +364,7 @@ __device__ __forceinline__ void layer64(const float *lds, int combo0, const floa
         out[mt][0] = bias_frag(bias, mt, h);
         out[mt][1] = out[mt][0];
     }
-#if TN_SPLIT_PIPELINE
     layer_pipelined<P, 2>(lds, combo0, lane, in, out);
-#else
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const Pieces<P> b0 = split8<P, true>(in[ks >> 1][0], ks & 1), b1 = split8<P, true>(in[ks >> 1][1], ks & 1);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const Pieces<P> a = load_a<P>(lds, combo0 + mt * 4 + ks, lane);
-            mma<P>(out[mt][0], a, b0);
-            mma<P>(out[mt][1], a, b1);
-        }
-    }
-#endif
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -602,16 +550,7 @@ __global__ void __launch_bounds__(P::kBlock, P::kBlocksPerCU) main_split_rays_ke
             f32x16 g[1][2];
             g[0][0] = bias_frag(lds + LY::B_BASE2, 0, h);
             g[0][1] = g[0][0];
-#if TN_SPLIT_PIPELINE
             layer_pipelined<P, 1>(lds, C_BASE2, lane, h1, g);
-#else
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const HL aw = load_a<P>(lds, C_BASE2 + ks, lane);
-                mma<P>(g[0][0], aw, split8<P, true>(h1[ks >> 1][0], ks & 1));
-                mma<P>(g[0][1], aw, split8<P, true>(h1[ks >> 1][1], ks & 1));
-            }
-#endif
             float raw, unused;
             swap32(g[0][0][0], g[0][1][0], raw, unused);
             const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
@@ -704,354 +643,6 @@ __global__ void __launch_bounds__(P::kBlock, P::kBlocksPerCU) main_split_rays_ke
     depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
 }
 
-#if TN_SPLIT_WAVE32
-// ================================================================================================================================
-// main_split_rays32_kernel<P> (round 5): the same chain, ONE 32-ray tile per wave, three waves per SIMD.
-//
-// The 64-ray kernel above is not bound by the matrix pipe (48 % busy) nor by the SIMD's vector rate: it is bound by how fast ONE
-// wave issues — a wave gets one instruction out per ~5 cycles (profiles/micro/round2c_valu_rate_packed_vs_scalar.txt: 9.9 cycles per
-// pair of v_fma with one wave per SIMD, 5.0 per SIMD with two, 2.5 with four), a pass of bf16x6 is ~4 200 instructions per wave,
-// and 256 registers allow two waves per SIMD: 2 x 21 k issue cycles for 11.5 k cycles of MFMA work, largely one after the other.
-// A 32x32x16 MFMA spans a 32-ray tile with BOTH halves of the wave (lane (j, h) supplies k = 8 h .. 8 h + 7 of ray j), so a wave
-// that owns 32 rays instead of 64 carries half the accumulators (one N tile), half the splits and half the gathers per lane — each
-// ray's two lanes share its hash levels (lane half h evaluates the levels 2 p + h: both halves run the same dense / hashed code at
-// the same time, and no half-wave swap is needed to build the B operands) — and fits 168 registers: three waves per SIMD, 1.5 x the
-// issue slots per MFMA, and per wave half as many instructions between two MFMAs.  Per-ray scalars (position, compositing) are
-// computed on both lanes of a ray; lane half 0 stores.
-// ================================================================================================================================
-struct LanePair {  // lane half of a ray: which level of every level pair it evaluates
-    bool hi;
-};
-__device__ __forceinline__ void hash_taps_pair(const Grid &g, int p, LanePair lp, float px, float py, float pz, HashTaps &t) {
-    const float s = lp.hi ? g.scal[2 * p + 1] : g.scal[2 * p];
-    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
-    t.ox = __builtin_amdgcn_fractf(sx);
-    t.oy = __builtin_amdgcn_fractf(sy);
-    t.oz = __builtin_amdgcn_fractf(sz);
-    const unsigned fx = (unsigned)(int)sx, fy = (unsigned)(int)sy, fz = (unsigned)(int)sz;
-    const unsigned x0 = fx << 3, x1 = x0 + 8u;
-    const unsigned y0 = fy * (TN_P1 << 3), y1 = y0 + (TN_P1 << 3);
-    const unsigned z0 = fz * (TN_P2 << 3), z1 = z0 + (TN_P2 << 3);
-    const unsigned m8 = g.mask << 3, up = lp.hi ? (g.tsize << 3) : 0u;  // the odd level's table follows the even one's
-    t.off[0] = ((x1 ^ y1 ^ z1) & m8) | up;
-    t.off[1] = ((x1 ^ y0 ^ z1) & m8) | up;
-    t.off[2] = ((x0 ^ y0 ^ z1) & m8) | up;
-    t.off[3] = ((x0 ^ y1 ^ z1) & m8) | up;
-    t.off[4] = ((x1 ^ y1 ^ z0) & m8) | up;
-    t.off[5] = ((x1 ^ y0 ^ z0) & m8) | up;
-    t.off[6] = ((x0 ^ y0 ^ z0) & m8) | up;
-    t.off[7] = ((x0 ^ y1 ^ z0) & m8) | up;
-}
-__device__ __forceinline__ void hash_gather_pair(const Grid &g, int p, const HashTaps &t, float2 (&f)[8]) {
-    const char *tb = reinterpret_cast<const char *>(g.table + (size_t)(2 * p) * g.tsize);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = *reinterpret_cast<const float2 *>(tb + t.off[k]);
-}
-__device__ __forceinline__ void dense_taps_pair(const Grid &g, int p, LanePair lp, float px, float py, float pz, HashTaps &t) {
-    const float s = lp.hi ? g.scal[2 * p + 1] : g.scal[2 * p];
-    const float sx = mul_rn(px, s), sy = mul_rn(py, s), sz = mul_rn(pz, s);
-    t.ox = __builtin_amdgcn_fractf(sx);
-    t.oy = __builtin_amdgcn_fractf(sy);
-    t.oz = __builtin_amdgcn_fractf(sz);
-    const unsigned ures = (unsigned)(lp.hi ? g.dense_res[2 * p + 1] : g.dense_res[2 * p]);
-    const unsigned up = lp.hi ? (unsigned)((g.dense_off[2 * p + 1] - g.dense_off[2 * p]) << 4) : 0u;  // (the dense copies total < 4 GB)
-    const unsigned i00 = __umul24(__umul24((unsigned)(int)sx, ures) + (unsigned)(int)sy, ures) + (unsigned)(int)sz;
-    const unsigned b00 = (i00 << 4) + up, dy = ures << 4, dx = __umul24(ures, ures) << 4;
-    t.off[0] = b00;
-    t.off[1] = b00 + dy;
-    t.off[2] = b00 + dx;
-    t.off[3] = b00 + dx + dy;
-}
-__device__ __forceinline__ void dense_gather_pair(const Grid &g, int p, const HashTaps &t, float2 (&f)[8]) {
-    const char *db = reinterpret_cast<const char *>(reinterpret_cast<const float4 *>(g.dense) + g.dense_off[2 * p]);
-    const float4 v00 = *reinterpret_cast<const float4 *>(db + t.off[0]), v01 = *reinterpret_cast<const float4 *>(db + t.off[1]);
-    const float4 v10 = *reinterpret_cast<const float4 *>(db + t.off[2]), v11 = *reinterpret_cast<const float4 *>(db + t.off[3]);
-    f[6] = make_float2(v00.x, v00.y); f[2] = make_float2(v00.z, v00.w);
-    f[7] = make_float2(v01.x, v01.y); f[3] = make_float2(v01.z, v01.w);
-    f[5] = make_float2(v10.x, v10.y); f[1] = make_float2(v10.z, v10.w);
-    f[4] = make_float2(v11.x, v11.y); f[0] = make_float2(v11.z, v11.w);
-}
-// the lane's eight levels (2 p + hi, p = 0 .. 7; the first NDP pairs from the dense re-layout) as hash_encode_pipelined does it: two
-// groups of two levels in flight, index arithmetic | gathers | interpolation in fenced stages
-template <int NDP, typename Emit>
-__device__ __forceinline__ void hash_encode_pairs(const Grid &g, LanePair lp, float px, float py, float pz, Emit emit) {
-    constexpr int LGP = 2, NG = 4;
-    HashTaps taps[2][LGP];
-    float2 fv[2][LGP][8];
-    auto taps_of = [&](int p, HashTaps &t) {
-        if (p < NDP) dense_taps_pair(g, p, lp, px, py, pz, t); else hash_taps_pair(g, p, lp, px, py, pz, t);
-    };
-    auto gather_of = [&](int p, const HashTaps &t, float2 (&f)[8]) {
-        if (p < NDP) dense_gather_pair(g, p, t, f); else hash_gather_pair(g, p, t, f);
-    };
-#pragma unroll
-    for (int q = 0; q < LGP; ++q) taps_of(q, taps[0][q]);
-    TN_STAGE_FENCE();
-#pragma unroll
-    for (int q = 0; q < LGP; ++q) gather_of(q, taps[0][q], fv[0][q]);
-    TN_STAGE_FENCE();
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int cur = gi & 1, nxt = cur ^ 1;
-        if (gi + 1 < NG) {
-#pragma unroll
-            for (int q = 0; q < LGP; ++q) taps_of((gi + 1) * LGP + q, taps[nxt][q]);
-            TN_STAGE_FENCE();
-#pragma unroll
-            for (int q = 0; q < LGP; ++q) gather_of((gi + 1) * LGP + q, taps[nxt][q], fv[nxt][q]);
-        }
-#pragma unroll
-        for (int q = 0; q < LGP; ++q) hash_hold(taps[cur][q]);
-        TN_STAGE_FENCE();
-#pragma unroll
-        for (int q = 0; q < LGP; ++q) emit(gi * LGP + q, hash_blend(taps[cur][q], fv[cur][q]));
-        TN_STAGE_FENCE();
-    }
-}
-
-template <class P>
-__device__ __forceinline__ Pieces<P> split_arr8(const float (&v)[8]) {
-    unsigned pk[P::NP][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        unsigned pr[P::NP];
-        P::split_pair(v[2 * m], v[2 * m + 1], pr);
-#pragma unroll
-        for (int k = 0; k < P::NP; ++k) pk[k][m] = pr[k];
-    }
-    return pieces_of<P>(pk);
-}
-
-// both lane halves of a ray -> the sum of their two values (v_permlane32_swap of a register with itself: {lo, lo} and {hi, hi})
-__device__ __forceinline__ float sum_halves(float p) {
-    const unsigned u = __float_as_uint(p);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float lower_half(float p) {  // lane (j, 0)'s value on both lanes of ray j
-    const unsigned u = __float_as_uint(p);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]);
-}
-
-template <int ACT>  // 0 relu, 1 fast sigmoid: this lane's 32 features of a 64-wide layer against an output row
-__device__ __forceinline__ float out_dot32(const float *wrow, int h, const f32x16 (&x)[2]) {
-    float p = 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w = *reinterpret_cast<const float4 *>(wrow + 32 * mt + 8 * q + 4 * h);
-            const float ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a0 = x[mt][4 * q + e];
-                p = fmaf(ww[e], ACT ? fast_sigmoid(a0) : relu_bits(a0), p);
-            }
-        }
-    }
-    return p;
-}
-
-// A [32 NMT x 64] x relu(in) product for ONE ray tile as a software pipeline over the four k-steps: a k-step's NMT NPROD MFMAs in four
-// fenced chunks, each followed by the split of one value pair of the next k-step's B operand (see layer_pipelined)
-template <class P, int NMT>
-__device__ __forceinline__ void layer_pipelined32(const float *lds, int combo0, int lane, const f32x16 (&in)[2], f32x16 (&out)[NMT]) {
-    constexpr int NM = NMT * P::NPROD;
-    Pieces<P> bc = split8<P, true>(in[0], 0);
-    Pieces<P> a[2], an;
-    a[0] = load_a<P>(lds, combo0, lane);
-    a[1] = a[0];
-    an = a[0];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        unsigned nx[P::NP][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (NMT == 2 && c == 0) a[1] = load_a<P>(lds, combo0 + 4 + ks, lane);
-            if (NMT == 1 && c == 0 && ks < 3) an = load_a<P>(lds, combo0 + ks + 1, lane);
-#pragma unroll
-            for (int idx = c * NM / 4; idx < (c + 1) * NM / 4; ++idx) {
-                const int mt = idx / P::NPROD, j = idx % P::NPROD;
-                out[mt] = P::mfma(a[mt].p[P::ka(j)], bc.p[P::kb(j)], out[mt]);
-            }
-            if (NMT == 2 && c == 1 && ks < 3) a[0] = load_a<P>(lds, combo0 + ks + 1, lane);  // a[0]'s last MFMA was in this chunk
-            if (ks < 3) split_pair_of<P, true>(in[(ks + 1) >> 1], (ks + 1) & 1, c, nx);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ks < 3) bc = pieces_of<P>(nx);
-        if (NMT == 1) a[0] = an;
-    }
-}
-
-constexpr int kWaves32 = TN_WAVES32;  // 12 = 768 threads: three waves per SIMD (<= 168 registers)
-
-template <class P, int NDP>
-__global__ void __launch_bounds__(kWaves32 * 64, 1) main_split_rays32_kernel(H3Args a) {
-    typedef Lay<P::NP> LY;
-    typedef Pieces<P> HL;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.blob);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < LY::BLOB_FLOATS / 4; i += kWaves32 * 64) dst[i] = src[i];
-    }
-    __syncthreads();
-    const Space sp = make_space(a.space);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const LanePair lp{h != 0};
-    const bool lin = a.lin != 0;
-    const int S = a.S;
-    const long long groups = (a.R + 31) >> 5;
-    const long long stride = (long long)gridDim.x * kWaves32;
-    float smin = INFINITY, smax = -INFINITY;
-    long long mm_slot = 0;
-    for (long long grp = (long long)blockIdx.x * kWaves32 + wave; grp < groups; grp += stride) {
-        if (a.minmax.chunk_rays > 0 && a.minmax.slot(grp * 32) != mm_slot) {
-            depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
-            mm_slot = a.minmax.slot(grp * 32);
-        }
-        const long long r = grp * 32 + (lane & 31);
-        const bool live = r < a.R;
-        const long long rc = live ? r : a.R - 1;
-        const float ox = a.origins[rc * 3], oy = a.origins[rc * 3 + 1], oz = a.origins[rc * 3 + 2];
-        const float dx = a.dirs[rc * 3], dy = a.dirs[rc * 3 + 1], dz = a.dirs[rc * 3 + 2];
-        const float s_near = spacing_fn(a.nears[rc], lin), s_far = spacing_fn(a.fars[rc], lin);
-        const float *tb = a.spacing + tn_ws_bin(rc, 0, S);  // edge e of this lane's ray at tb[e * 64]
-        HL shb;  // this lane's half (components 8 h .. 8 h + 7) of SH(dir): the colour layer's second k-step, constant over the samples
-        {
-            float sx = dx, sy = dy, sz = dz;
-            if (a.sh_shifted) {
-                sx = add_rn(sx, 1.0f) / 2.0f; sy = add_rn(sy, 1.0f) / 2.0f; sz = add_rn(sz, 1.0f) / 2.0f;
-            }
-            float c[16], mine[8];
-            sh16(sx, sy, sz, c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) mine[e] = lp.hi ? c[8 + e] : c[e];
-            shb = split_arr8<P>(mine);
-        }
-        float en = spacing_to_eucl<true>(tb[0], s_near, s_far, lin);
-        float accum = 0.0f, cum_w = 0.0f;
-        float wsum = 0.0f, wr = 0.0f, wg = 0.0f, wbl = 0.0f, wth = 0.0f, wsteps = 0.0f;
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f, th = 0.0f, med = 0.0f, step = 0.0f;
-        bool med_found = false;
-        float sb_next = tb[64];
-        for (int i = 0; i < S; ++i) {
-            const float st = en;
-            en = spacing_to_eucl<true>(sb_next, s_near, s_far, lin);
-            sb_next = tb[(size_t)(i + 2 <= S ? i + 2 : S) * 64];
-            step = add_rn(st, en) / 2.0f;
-            float px, py, pz;
-            const float sel = normalize_position<true>(sp, frustum_pos(ox, dx, st, en), frustum_pos(oy, dy, st, en),
-                                                 frustum_pos(oz, dz, st, en), px, py, pz);
-            // ---- hash grid: this lane's eight levels = its half of both k-steps of mlp_base's first layer ----------------
-            HL e0, e1;
-            {
-                float v0[8], v1[8];
-                hash_encode_pairs<NDP>(a.g, lp, px, py, pz, [&](int p, float2 f) {
-                    if (p < 4) { v0[2 * p] = f.x; v0[2 * p + 1] = f.y; } else { v1[2 * (p - 4)] = f.x; v1[2 * (p - 4) + 1] = f.y; }
-                });
-                e0 = split_arr8<P>(v0);
-                e1 = split_arr8<P>(v1);
-            }
-#if TN_SPLIT_MLP_PRIO
-            __builtin_amdgcn_s_setprio(TN_SPLIT_MLP_PRIO);
-#endif
-            // ---- mlp_base layer 0: 32 -> 64 (A fragments in the paired level order) -------------------------------------
-            f32x16 h1[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) h1[mt] = bias_frag(lds + LY::B_BASE1, mt, h);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const HL aw = load_a<P>(lds, C_BASE1P + mt * 2 + ks, lane);
-                    mma<P>(h1[mt], aw, ks ? e1 : e0);
-                }
-            }
-            // ---- mlp_base layer 1: 64 -> 16 -------------------------------------------------------------------------------
-            f32x16 g[1];
-            g[0] = bias_frag(lds + LY::B_BASE2, 0, h);
-            layer_pipelined32<P, 1>(lds, C_BASE2, lane, h1, g);
-            const float raw = lower_half(g[0][0]);  // row 0 (the raw density) sits in lane half 0's register 0
-            const float dens = mul_rn(mul_rn(a.avg, __expf(raw)), sel);
-            const HL gp = split8<P, false>(g[0], 0);  // geo rows (row 0 has zero weight)
-            {   // colour: [geo | SH] -> 64 -> 64 -> 3
-                f32x16 x1[2], x2[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    x1[mt] = bias_frag(lds + LY::B_C1, mt, h);
-                    const HL ag = load_a<P>(lds, C_C1 + mt * 2, lane), as = load_a<P>(lds, C_C1 + mt * 2 + 1, lane);
-                    mma<P>(x1[mt], ag, gp);
-                    mma<P>(x1[mt], as, shb);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) x2[mt] = bias_frag(lds + LY::B_C2, mt, h);
-                layer_pipelined32<P, 2>(lds, C_C2, lane, x1, x2);
-                const float *w3 = lds + LY::W3;
-                cr = fast_sigmoid(sum_halves(out_dot32<0>(w3, h, x2)) + w3[192]);
-                cg = fast_sigmoid(sum_halves(out_dot32<0>(w3 + 64, h, x2)) + w3[193]);
-                cb = fast_sigmoid(sum_halves(out_dot32<0>(w3 + 128, h, x2)) + w3[194]);
-            }
-            {   // thermal: geo -> 64 -> 64 sigmoid -> 1
-                f32x16 x1[2], x2[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    x1[mt] = bias_frag(lds + LY::B_T1, mt, h);
-                    const HL ag = load_a<P>(lds, C_T1 + mt, lane);
-                    mma<P>(x1[mt], ag, gp);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) x2[mt] = bias_frag(lds + LY::B_T2, mt, h);
-                layer_pipelined32<P, 2>(lds, C_T2, lane, x1, x2);
-                const float *wt = lds + LY::WTH;
-                th = sum_halves(out_dot32<1>(wt, h, x2)) + wt[64];
-            }
-#if TN_SPLIT_MLP_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            cr = nan_to_num(cr); cg = nan_to_num(cg); cb = nan_to_num(cb); th = nan_to_num(th);
-            const float dd = mul_rn(sub_rn(en, st), dens);
-            const float wi = nan_to_num(mul_rn(sub_rn(1.0f, __expf(-dd)), __expf(-accum)));
-            accum += dd;
-            cum_w += wi;
-            if (!med_found && cum_w >= 0.5f) {
-                med_found = true;
-                med = step;
-            }
-            wsum += wi;
-            wr += mul_rn(wi, cr);
-            wg += mul_rn(wi, cg);
-            wbl += mul_rn(wi, cb);
-            wth += mul_rn(wi, th);
-            wsteps += mul_rn(wi, step);
-            smin = fminf(smin, step);
-            smax = fmaxf(smax, step);
-            if (a.early_eps > 0.0f && i + 1 < S && __all(__expf(-accum) < a.early_eps)) {
-                const float e0 = spacing_to_eucl<true>(tb[(size_t)(S - 1) * 64], s_near, s_far, lin);
-                const float e1 = spacing_to_eucl<true>(tb[(size_t)S * 64], s_near, s_far, lin);
-                smax = fmaxf(smax, add_rn(e0, e1) / 2.0f);
-                break;
-            }
-        }
-        if (live && h == 0) {
-            const float bg = sub_rn(1.0f, wsum);
-            const float c0 = add_rn(wr, mul_rn(cr, bg)), c1 = add_rn(wg, mul_rn(cg, bg)), c2 = add_rn(wbl, mul_rn(cb, bg));
-            const float ct = add_rn(wth, mul_rn(th, bg));
-            a.rgb[r * 3 + 0] = fminf(fmaxf(c0, 0.0f), 1.0f);
-            a.rgb[r * 3 + 1] = fminf(fmaxf(c1, 0.0f), 1.0f);
-            a.rgb[r * 3 + 2] = fminf(fmaxf(c2, 0.0f), 1.0f);
-            a.thermal[r] = fminf(fmaxf(ct, 0.0f), 1.0f);
-            a.acc[r] = wsum;
-            a.depth[r] = med_found ? med : step;
-            a.expected[r] = wsteps / add_rn(wsum, 1e-10f);
-        }
-    }
-    depth_bounds_flush(a.minmax, mm_slot, smin, smax, lane);
-}
-
-#endif  // TN_SPLIT_WAVE32
 
 // ---- the split itself, exposed for its unit test (tn_bf16x6_split_product) ---------------------------------------------------------
 // per element: the three bf16 pieces of a and of b (as floats) and the six-product sum p1q3 + p3q1 + p2q2 + p1q2 + p2q1 + p1q1
@@ -1112,26 +703,6 @@ static int launch_main_split(const tn_thermal_field *field, const float *blob, c
     a.rgb = out->rgb; a.acc = out->accumulation; a.depth = out->depth; a.expected = out->expected_depth;
     a.thermal = out->thermal; a.minmax = minmax;
     a.early_eps = fminf(fmaxf(cfg->early_stop_transmittance, 0.0f), 0.25f);
-#if TN_SPLIT_WAVE32
-    {   // one 32-ray tile per wave, three waves per SIMD: the grid's first kFieldDense levels dense (pairs 0 .. kFieldDense / 2 - 1), or none
-        static_assert(kFieldDense % 2 == 0, "a level pair is dense or hashed as a whole");
-        const bool dense = a.g.num_dense >= kFieldDense, hashed = a.g.num_dense == 0;
-        if (dense || hashed) {
-            const size_t smem32 = (size_t)Lay<P::NP>::BLOB_FLOATS * sizeof(float);
-            const long long groups32 = (num_rays + 31) / 32, need32 = (groups32 + kWaves32 - 1) / kWaves32;
-            const unsigned grid32 = (unsigned)(need32 < 256 ? (need32 < 1 ? 1 : need32) : 256);
-            if (dense) {
-                if (!tn_ensure_dynamic_lds<main_split_rays32_kernel<P, kFieldDense / 2>>(smem32)) return TN_ERR_LAUNCH;
-                hipLaunchKernelGGL((main_split_rays32_kernel<P, kFieldDense / 2>), dim3(grid32), dim3(kWaves32 * 64), smem32, stream, a);
-            } else {
-                if (!tn_ensure_dynamic_lds<main_split_rays32_kernel<P, 0>>(smem32)) return TN_ERR_LAUNCH;
-                hipLaunchKernelGGL((main_split_rays32_kernel<P, 0>), dim3(grid32), dim3(kWaves32 * 64), smem32, stream, a);
-            }
-            if (hipGetLastError() != hipSuccess) return TN_ERR_LAUNCH;
-            return TN_OK;
-        }
-    }
-#endif
     constexpr int kWaves = P::kBlock / TN_WAVE;
     const size_t smem = (size_t)Lay<P::NP>::BLOB_FLOATS * sizeof(float) + (P::kShInLds ? (size_t)kWaves * 64 * 2 * P::NP * 16 : 0);
     if (!tn_ensure_dynamic_lds<main_split_rays_kernel<P>>(smem)) return TN_ERR_LAUNCH;

@@ -41,9 +41,6 @@
 #ifndef TN_TRAIN_GATHER_PRIO
 #define TN_TRAIN_GATHER_PRIO 1
 #endif
-#ifndef TN_TRAIN_FWD_PRIO
-#define TN_TRAIN_FWD_PRIO 0
-#endif
 
 using namespace tn;
 
@@ -891,9 +888,6 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
         }
         if (live) a.sel[ic] = sel;
         // ---- mlp_base layer 0 -------------------------------------------------------------------------------------------
-#if TN_TRAIN_FWD_PRIO
-        __builtin_amdgcn_s_setprio(TN_TRAIN_FWD_PRIO);
-#endif
         f32x16 h1[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -1040,9 +1034,6 @@ __global__ void __launch_bounds__(kBlock, 2) field_fwd_taped_kernel(TapedArgs a)
             const float th = combine_halves(make_float2(p0, p1)) + wt[64];
             if (live) a.thermal[ic] = th;
         }
-#if TN_TRAIN_FWD_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     }
 }
 

@@ -323,10 +323,6 @@ __global__ void __launch_bounds__(kBlock) sort_emit_kernel(SortArgs a) {
     unsigned *off = base + own_pad;    // [own_pad] the run's first slot in the block's LDS staging area
     const Space sp = make_space(a.space);
     const int L = a.g.num_levels;
-#ifndef TN_EMIT_XCD_MAP
-#define TN_EMIT_XCD_MAP 1
-#endif
-#if TN_EMIT_XCD_MAP
     // workgroups go round the 8 XCDs (block b -> XCD b % 8), each with its own L2.  The blocks of one chunk — one per level — read
     // the same 128-byte rows of d_enc (8 bytes each): they are given the same XCD and consecutive turns on it, so that the row
     // comes from HBM / the Infinity Cache once instead of once per level.
@@ -334,10 +330,6 @@ __global__ void __launch_bounds__(kBlock) sort_emit_kernel(SortArgs a) {
     const long long chunk = (turn / a.levels) * 8 + (blockIdx.x & 7);
     const int lb = (int)(turn % a.levels), l = a.level_begin + lb;  // lb: level index inside the bins
     if (chunk * kSortSamples >= a.n) return;
-#else
-    const long long chunk = blockIdx.x / a.levels;
-    const int lb = (int)(blockIdx.x - chunk * a.levels), l = a.level_begin + lb;  // lb: level index inside the bins
-#endif
     for (int o = threadIdx.x; o < own_pad; o += kBlock) hist[o] = 0u;
     __syncthreads();
     constexpr int SPT = kSortSamples / kBlock;
@@ -2061,11 +2053,7 @@ static int hash_encode_bwd_sorted_phases(const tn_hashgrid *grid, const tn_space
     if (phases & 1) {
         if (hipMemsetAsync(ws, 0, (size_t)w.bins * 4, s) != hipSuccess) return TN_ERR_LAUNCH;
         const long long chunks = (n + kSortSamples - 1) / kSortSamples;
-#if TN_EMIT_XCD_MAP
         const long long blocks = ((chunks + 7) / 8) * 8 * a.levels;
-#else
-        const long long blocks = chunks * a.levels;
-#endif
         if (blocks > 0x7fffffffLL) return TN_ERR_SHAPE;
         const size_t emit_smem = (size_t)kSortSamples * 4 * 22 + (size_t)3 * 4 * kBlock * ((w.owners + kBlock - 1) / kBlock);
         if (emit_smem > 64 * 1024 && !tn_ensure_dynamic_lds<sort_emit_kernel>(emit_smem)) return TN_ERR_LAUNCH;

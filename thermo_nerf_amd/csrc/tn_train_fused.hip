@@ -36,9 +36,6 @@
 
 using namespace tn;
 
-#ifndef TN_BWD_POSE_PRIO
-#define TN_BWD_POSE_PRIO 0
-#endif
 
 namespace {
 
@@ -450,9 +447,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
         else if (STORED) bo_next = load_bo(tile);
         else tile_load_enc(cur.e, a, tile, n, sl);
     }
-#if TN_BWD_POSE_PRIO
-    if (BASE) __builtin_amdgcn_s_setprio(TN_BWD_POSE_PRIO);
-#endif
     for (; tile < tiles; tile += stride) {
         const long long i0 = tile * TS;
         const bool live = i0 + n < a.N;
@@ -668,9 +662,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
                 st4(a.g_enc + (i0 + n) * 32 + 16 + 4 * sl, de[1]);
             }
             if (a.d_pos) {
-#if TN_BWD_POSE_PRIO
-                __builtin_amdgcn_s_setprio(0);  // A/B: the gather-bound pose-gradient section behind the partner wave's matrix products
-#endif
                 // camera-pose optimisation: d loss / d position of sample n through the encoding.  The lane holds d_enc of four of
                 // the sample's 16 levels (2 sl, 2 sl + 1, 8 + 2 sl, 9 + 2 sl): 32 table reads per lane, in flight under the
                 // weight-gradient MFMAs below, summed over the sample's four lanes.  (As a kernel of its own — one lane per
@@ -708,9 +699,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
                     position_grad_finish(sp, x, y, z, selp, gx, gy, gz, rx, ry, rz);
                     a.d_pos[(i0 + n) * 3] = rx; a.d_pos[(i0 + n) * 3 + 1] = ry; a.d_pos[(i0 + n) * 3 + 2] = rz;
                 }
-#if TN_BWD_POSE_PRIO
-                __builtin_amdgcn_s_setprio(TN_BWD_POSE_PRIO);
-#endif
             }
             wave_sync();
             dw<4, 2, true>(D, X, n, sl, aw_b0, ab_b0);

@@ -50,9 +50,9 @@ class ThermalNerfactoTField(nn.Module):
         sh_input: Literal["shifted", "unit"] = "shifted",
     ) -> None:
         super().__init__()
-        if use_transient_embedding or use_semantics or use_pred_normals:
+        if use_transient_embedding or use_semantics:
             # REF thermal_nerf_model.py:50-56,106-112 never enables these on the thermal-nerf path
-            raise NotImplementedError("transient / semantics / predicted-normals heads are off on the ThermoNeRF path")
+            raise NotImplementedError("transient / semantics heads are off on the ThermoNeRF path")
         if (num_layers, num_layers_color, num_layers_transient) != (2, 3, 2):
             raise NotImplementedError("kernels implement mlp_base 2, mlp_head 3, mlp_thermal 2 layers (the defaults)")
         if hidden_dim != 64 or hidden_dim_color != 64 or hidden_dim_transient != 64:
@@ -83,6 +83,14 @@ class ThermalNerfactoTField(nn.Module):
         # REF thermal_field.py:90-98: 15 -> 64 -> 64, ReLU, Sigmoid
         self.mlp_thermal = MLP(self.geo_feat_dim, 2, 64, hidden_dim_transient)
         self.field_head_thermal = ThermalFieldHead(in_dim=self.mlp_thermal.get_out_dim())  # REF :100-102
+        if use_pred_normals:
+            # config.predict_normals=True [REF thermal_nerf_model.py:108]: NS NerfactoField builds the predicted-normals head —
+            # NeRFEncoding(3, 2 frequencies) -> MLP(15 + 12, 3 layers of 64, out hidden_dim_transient) -> PredNormalsFieldHead
+            # (Linear -> 3, Tanh) [NS-recall] — and the reference's get_outputs override never evaluates it (G9: the model ends in
+            # KeyError(PRED_NORMALS)).  The parameters exist so that the module tree and state-dict names are the reference's.
+            self.mlp_pred_normals = MLP(self.geo_feat_dim + 12, 3, 64, hidden_dim_transient)
+            self.field_head_pred_normals = nn.Module()
+            self.field_head_pred_normals.net = nn.Linear(self.mlp_pred_normals.get_out_dim(), 3)
         self.pass_thermal_gradients = pass_thermal_gradients
         self.training_iteration = 0
         self.pass_rgb_gradients = True
@@ -237,8 +245,11 @@ class ThermalNerfactoTField(nn.Module):
                 ) -> Dict[Union[FieldHeadNamesT, FieldHeadNames], Tensor]:
         """REF thermal_field.py:183-201."""
         if compute_normals:
-            raise NotImplementedError("analytic normals need autograd through the density; predict_normals is False "
-                                      "on the ThermoNeRF path (REF thermal_nerf_model.py:225-227)")
+            # the only caller that passes True is the model with config.predict_normals, which the reference cannot run
+            # (KeyError on PRED_NORMALS in every forward: G9, tests/golden/predict_normals.json) — the analytic normals it would
+            # compute on the way [REF :195-200] are never returned to anyone
+            raise NotImplementedError("compute_normals=True: the reference's model raises KeyError(PRED_NORMALS) right after asking "
+                                      "for them (G9); analytic normals are not evaluated on this path")
         density, density_embedding = self.get_density(ray_samples)
         field_outputs = self.get_outputs(ray_samples, density_embedding=density_embedding)
         field_outputs[FieldHeadNames.DENSITY] = density

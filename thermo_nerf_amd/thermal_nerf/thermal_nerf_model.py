@@ -152,6 +152,13 @@ class ThermalNerfModel(ThermalNerfactoModel):
     # ------------------------------------------------------------------------------------------------
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """[REF thermal_nerf_model.py:210-275]"""
+        if self.config.predict_normals:
+            # What the REFERENCE does with predict_normals=True, recorded by executing its own code (G9, tests/golden/
+            # predict_normals.json, tools/make_golden_g9.py): its field override [REF thermal_field.py:108-181] never evaluates
+            # nerfstudio's predicted-normals head, so get_outputs ends in KeyError(FieldHeadNames.PRED_NORMALS) at [REF :256-258]
+            # in every forward, train or eval.  The switch belongs to the config surface, not to the reference's working
+            # behaviour: the same exception, instead of outputs the reference cannot produce.
+            raise KeyError(FieldHeadNames.PRED_NORMALS)
         if self.training:
             self.camera_optimizer.apply_to_raybundle(ray_bundle)  # REF :218-219
         if ray_bundle.nears is None or ray_bundle.fars is None:
@@ -251,8 +258,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
             term = getattr(metrics_dict["distortion"], "scaled_term", None)  # the kernel's own mult * metric, when it made one
             loss_dict["distortion_loss"] = term[1] if term is not None and term[0] == self.config.distortion_loss_mult \
                 else self.config.distortion_loss_mult * metrics_dict["distortion"]
-            if self.config.predict_normals:
-                raise NotImplementedError("predict_normals is off on the ThermoNeRF path")
+            if self.config.predict_normals:  # (unreachable through get_outputs, which raised: see there)
+                raise KeyError(FieldHeadNames.PRED_NORMALS)
         thermal_batch = batch[RenderedImageModality.THERMAL.value].to(self.device)
         if self.field.pass_thermal_gradients:
             # the reference gates the thermal LOSS (not only the geo gradient) on this flag [REF :319-323]
