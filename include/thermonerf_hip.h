@@ -620,6 +620,79 @@ int tn_interlevel_loss_levels(const float *c, const float *w, int64_t num_rays, 
                               const float *const *cp, const float *const *wp, const int32_t *p, float scale, float *loss_sum,
                               float *const *d_wp, void *stream);
 
+/* ---- the training step's launch chains as two calls -------------------------------------------------------------------------
+ * What ThermalNerfModel.get_outputs [REF thermal_nerf_model.py:210-275] queues in training mode on a step whose proposal networks
+ * take no gradient (nerfstudio's ProposalNetworkSampler: 5 steps of 6 after warm-up), and the adjoint chain autograd runs for it —
+ * the SAME entry points as above, in the same order and on the same streams as the per-call host path queues them (bit-identical
+ * results), issued from C++: a step is ~20 launches whose Python cost (one ctypes call and ~2 output allocations each) decided the
+ * step at the reference's default S = 48.  Every buffer is the caller's; the cross-stream order is made with events
+ * created and destroyed inside the call (no state is kept).
+ *
+ * tn_train_step_fwd:  tn_field_prepare(field_raw -> field->prepared) | tn_proposal_sample_fwd (train-mode, untaped) |
+ *   tn_frustum_from_edges | tn_ray_head_fwd | [wait for `wait_events`: a deferred table update of the previous step] |
+ *   tn_field_fwd_train | tn_ray_render_fwd | the two regularisers on `second` / `third` behind the level's weights (when their
+ *   loss pointers are set: tn_distortion_loss_term, tn_interlevel_loss_levels) | tn_depth_fwd.
+ * tn_train_step_bwd:  tn_ray_render_bwd | tn_field_bwd_fused | the table scatter — tn_hash_encode_bwd_sorted on `second` beside
+ *   tn_hash_encode_bwd_spread / _levels for the levels below `first_sorted_level` on `stream` (defer == 0: `stream` waits for
+ *   `second` at the end) or on `third` (defer != 0: nobody waits — the caller joins, thermo_nerf_amd/_hip.py) | the ray-level
+ *   adjoints on `stream`: tn_ray_head_bwd (+ tn_color_input_bwd with sh_direction_gradient), tn_frustum_positions_bwd. */
+typedef struct tn_train_step {
+    const tn_density_field *prop0, *prop1;
+    const tn_thermal_field *field_raw;   /* the field as stored (what tn_field_prepare reads)                          */
+    const tn_thermal_field *field;       /* the same with `prepared` -> a buffer of prepared_bytes this call (re)fills  */
+    size_t prepared_bytes;
+    const tn_render_config *cfg;         /* training = 1; sample counts, anneal, initial sampler, jitter form          */
+    const tn_render_inputs *in;          /* rays, planes, camera indices (int32), jitter, bin tables                   */
+    int64_t num_rays;
+    /* kept for the backward (caller-allocated) */
+    float *spacing[3], *eucl[3];         /* [R, n+1] per level                                                          */
+    float *weights[3];                   /* [R, n]                                                                      */
+    float *prop_depth[2];                /* [R]                                                                         */
+    float *positions;                    /* [R S, 3]                                                                    */
+    float *starts, *ends, *deltas;       /* [R, S]                                                                      */
+    float *ray_bias;                     /* [R, 64]                                                                     */
+    float *enc, *selector, *density, *rgb_samples, *thermal_samples, *base_out, *jacobian; /* tn_field_fwd_train's      */
+    float *rgb, *thermal, *accumulation, *depth, *expected_depth, *depth_scratch;          /* [R,3] [R] [R] [R] [R] [2] */
+    void *workspace;                     /* tn_render_workspace_bytes(cfg, num_rays)                                    */
+    size_t workspace_bytes;
+    /* regularisers (optional: loss pointers NULL = not launched); losses are += accumulators the caller zeroed         */
+    float distortion_mult, interlevel_mult;
+    float *distortion_loss_pair, *distortion_grad;   /* [2], [R,S]                                                      */
+    float *interlevel_loss, *interlevel_grad[2];     /* [1], [R,P0], [R,P1]                                             */
+    /* streams; wait_events: hipEvent_t handles `stream` waits for right before the field's first table read            */
+    void *stream, *second, *third;
+    void *const *wait_events;
+    int32_t num_wait_events;
+} tn_train_step;
+int tn_train_step_fwd(const tn_train_step *s);
+
+typedef struct tn_train_step_bwd_args {
+    const tn_thermal_field *field;       /* raw struct (no prepared blob needed)                                        */
+    int64_t num_rays;
+    int32_t n;                           /* samples per ray of the final level                                          */
+    /* the forward's tensors */
+    const float *positions, *starts, *ends, *deltas, *ray_bias, *enc, *selector, *density, *rgb_samples, *thermal_samples;
+    const float *base_out, *jacobian, *accumulation, *directions;
+    const int32_t *camera_indices;
+    /* incoming gradients (any may be NULL) */
+    const float *d_rgb, *d_thermal, *d_accumulation, *d_weights;
+    int32_t use_gradient_scaling, pass_thermal_gradients, split_form, sh_direction_gradient;
+    float trunc_exp_min;
+    /* scratch the call fills: [R S,3] [R S] [R S] [R S,32] [R S,3 or NULL] [R,64 zeroed or NULL] [R,64 or NULL]        */
+    float *d_rgb_samples, *d_thermal_samples, *d_density, *d_enc, *d_positions, *d_ray_sum, *d_ray_inputs;
+    const tn_field_grads *grads;         /* zero-initialised parameter gradients (+=)                                   */
+    float *d_table, *d_appearance, *d_head0_bias; /* zeroed (+=); mlp_head.0's bias gradient is the ray-level adjoint's         */
+    float *d_origins, *d_directions;     /* [R,3] zeroed (+=) or NULL: no ray gradients                                 */
+    void *fused_workspace; size_t fused_workspace_bytes;      /* tn_field_bwd_fused_workspace_bytes                     */
+    int32_t first_sorted_level;          /* tn_hash_encode_bwd_sorted_first_level; < 0: every level with atomics        */
+    void *sorted_workspace; size_t sorted_workspace_bytes;
+    int32_t spread;                      /* config.spread_coarse_scatter                                                */
+    void *spread_workspace; size_t spread_workspace_bytes;    /* of the stream the atomic levels run on                 */
+    int32_t overlap, defer;              /* config.overlap_table_scatter / deferred_table_update                        */
+    void *stream, *second, *third;
+} tn_train_step_bwd_args;
+int tn_train_step_bwd(const tn_train_step_bwd_args *a);
+
 /* ---- optimizer ------------------------------------------------------------------------------------------------------------
  * torch.optim.Adam as the reference's method config sets it for every parameter group — AdamOptimizerConfig(lr 1e-2,
  * eps 1e-15), nerfstudio's Optimizers.optimizer_step_all [REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:31-44;

@@ -62,7 +62,6 @@ class tn_adam_tensor(C.Structure):
 
 ADAM_MAX_TENSORS = 32  # TN_ADAM_MAX_TENSORS
 
-
 class tn_field_grads(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("base0_w", "base0_b", "base1_w", "base1_b", "head0_w", "head1_w", "head1_b", "head2_w",
                                          "head2_b", "th0_w", "th0_b", "th1_w", "th1_b", "thead_w", "thead_b")]
@@ -154,6 +153,39 @@ class tn_render_outputs(C.Structure):
         ("spacing_bins", C.c_void_p * 3),
         ("eucl_bins", C.c_void_p * 3),
     ]
+
+
+_fp = C.c_void_p  # a device pointer
+
+
+class tn_train_step(C.Structure):
+    _fields_ = [("prop0", C.POINTER(tn_density_field)), ("prop1", C.POINTER(tn_density_field)),
+                ("field_raw", C.POINTER(tn_thermal_field)), ("field", C.POINTER(tn_thermal_field)), ("prepared_bytes", C.c_size_t),
+                ("cfg", C.POINTER(tn_render_config)), ("inputs", C.POINTER(tn_render_inputs)), ("num_rays", C.c_int64),
+                ("spacing", _fp * 3), ("eucl", _fp * 3), ("weights", _fp * 3), ("prop_depth", _fp * 2),
+                ("positions", _fp), ("starts", _fp), ("ends", _fp), ("deltas", _fp), ("ray_bias", _fp),
+                ("enc", _fp), ("selector", _fp), ("density", _fp), ("rgb_samples", _fp), ("thermal_samples", _fp), ("base_out", _fp),
+                ("jacobian", _fp),
+                ("rgb", _fp), ("thermal", _fp), ("accumulation", _fp), ("depth", _fp), ("expected_depth", _fp), ("depth_scratch", _fp),
+                ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+                ("distortion_mult", C.c_float), ("interlevel_mult", C.c_float),
+                ("distortion_loss_pair", _fp), ("distortion_grad", _fp), ("interlevel_loss", _fp), ("interlevel_grad", _fp * 2),
+                ("stream", _fp), ("second", _fp), ("third", _fp), ("wait_events", C.POINTER(C.c_void_p)), ("num_wait_events", C.c_int32)]
+
+
+class tn_train_step_bwd_args(C.Structure):
+    _fields_ = [("field", C.POINTER(tn_thermal_field)), ("num_rays", C.c_int64), ("n", C.c_int32)] + [
+        (k, _fp) for k in ("positions", "starts", "ends", "deltas", "ray_bias", "enc", "selector", "density", "rgb_samples",
+                           "thermal_samples", "base_out", "jacobian", "accumulation", "directions", "camera_indices",
+                           "d_rgb", "d_thermal", "d_accumulation", "d_weights")] + [
+        ("use_gradient_scaling", C.c_int32), ("pass_thermal_gradients", C.c_int32), ("split_form", C.c_int32),
+        ("sh_direction_gradient", C.c_int32), ("trunc_exp_min", C.c_float)] + [
+        (k, _fp) for k in ("d_rgb_samples", "d_thermal_samples", "d_density", "d_enc", "d_positions", "d_ray_sum", "d_ray_inputs")] + [
+        ("grads", C.POINTER(tn_field_grads)), ("d_table", _fp), ("d_appearance", _fp), ("d_head0_bias", _fp), ("d_origins", _fp),
+        ("d_directions", _fp), ("fused_workspace", _fp), ("fused_workspace_bytes", C.c_size_t), ("first_sorted_level", C.c_int32),
+        ("sorted_workspace", _fp), ("sorted_workspace_bytes", C.c_size_t), ("spread", C.c_int32), ("spread_workspace", _fp),
+        ("spread_workspace_bytes", C.c_size_t), ("overlap", C.c_int32), ("defer", C.c_int32), ("stream", _fp), ("second", _fp),
+        ("third", _fp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/thermonerf_hip.h
@@ -252,6 +284,8 @@ SIGNATURES = {
     "tn_interlevel_loss_levels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_int32), C.c_float, _vp, C.POINTER(C.c_void_p), _vp]),
     "tn_adam_step": (C.c_int, [C.POINTER(tn_adam_tensor), _i32, _vp]),
+    "tn_train_step_fwd": (C.c_int, [C.POINTER(tn_train_step)]),
+    "tn_train_step_bwd": (C.c_int, [C.POINTER(tn_train_step_bwd_args)]),
     "tn_version": (C.c_char_p, []),
 }
 
@@ -416,7 +450,7 @@ _PENDING: dict = {}
 def defer(device, streams, keep=()) -> None:
     """register side-stream work on ``device`` that the current stream has NOT joined: the Stream objects it runs on and the
     tensors it reads or writes (kept alive until join_pending)"""
-    e = _PENDING.setdefault(torch.device(device), {"streams": [], "keep": [], "scatter_done": []})
+    e = _PENDING.setdefault(torch.device(device), {"streams": [], "keep": []})
     for s in streams:
         if all(s.cuda_stream != t.cuda_stream for t in e["streams"]):
             e["streams"].append(s)
@@ -425,6 +459,12 @@ def defer(device, streams, keep=()) -> None:
 
 def pending(device) -> Optional[dict]:
     return _PENDING.get(torch.device(device))
+
+
+def take_pending(device) -> Optional[dict]:
+    """remove and return the device's entry WITHOUT waiting: the caller orders its stream behind entry["streams"] itself (events
+    handed to tn_train_step_fwd) and keeps entry["keep"] alive until that order is queued"""
+    return _PENDING.pop(torch.device(device), None)
 
 
 def join_pending(device=None) -> bool:

@@ -134,6 +134,11 @@ class NerfactoModelConfig:
     overlap_table_scatter: bool = True
     """Training: the bucketed part of the field's table-gradient scatter runs on a second HIP stream beside the atomic part —
     disjoint levels of the gradient, one waiting on the memory-side atomic unit, the other on LDS and streaming (DESIGN §5.6)."""
+    fused_step_calls: bool = True
+    """Training (round 6): on the steps whose proposal networks take no gradient (5 of 6 after warm-up) the forward's launch chain and
+    the backward's are ONE C-ABI call each (tn_train_step_fwd / tn_train_step_bwd: the same entry points, order and streams as the
+    per-call host path, issued from C++; the step's per-sample tensors in one slab) — ~20 ctypes calls and ~45 allocations per step
+    less on the host, which decides the step at the reference's default S = 48.  False: one call per launch (the cross-check)."""
     deferred_table_update: bool = False
     """Training (round 6; set by thermo_nerf_amd.trainer.Trainer with its HipAdam optimizer, off for a foreign training loop): the field's
     table-gradient scatter — both halves — and the table's Adam run on the step's side streams and are NOT joined by the backward:

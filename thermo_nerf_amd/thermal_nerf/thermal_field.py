@@ -190,6 +190,8 @@ class ThermalNerfactoTField(nn.Module):
             prep = self.__dict__["_tn_train_prepared"] = (ptrs[-1], buf, st, nbytes)
         if prep[3] == 0:
             return None
+        if prepare == "struct":  # (raw, the struct whose `prepared` blob the caller refills — tn_train_step_fwd does —, its size)
+            return raw, prep[2], prep[3]
         _hip.check(lib.tn_field_prepare(raw, prep[1].data_ptr(), prep[3], _hip.current_stream()), "tn_field_prepare")
         return prep[2]
 

@@ -168,9 +168,6 @@ def hash_encode_bwd(grid, space, pos: Tensor, d_enc: Tensor, d_table: Tensor, bu
         # holds that tensor object — a second reference makes it CLONE the table gradient on the calling stream, i.e. before the
         # side streams have written it.  The caller keeps the storage alive through another view: the arena's flat buffer.)
         _hip.defer(pos.device, [side, third], [ws, pos, d_enc])
-        done = torch.cuda.Event()
-        done.record(side)  # the bucketed half's end (the table's Adam is queued behind it later): see RenderTrain.forward
-        _hip.pending(pos.device)["scatter_done"] = [done, third]
         return True
     if overlap and first > 0:
         main, side, _ = _step_streams(pos.device)
@@ -475,15 +472,9 @@ class RenderTrain(torch.autograd.Function):
         else:
             # nerfstudio evaluates the proposal densities under no_grad on these steps (5 of 6 after warm-up): no tape is
             # needed, so both levels run as ONE fused kernel (tn_proposal_sample_fwd, train-mode semantics)
-            pend = _hip.pending(dev)
-            if pend is not None and pend.get("scatter_done") and getattr(cfg, "deferred_proposal_after_scatter", False):
-                # the previous step's scatter still runs: its owner blocks need whole CUs (16 waves + 128 KB of LDS each), and a
-                # resident proposal pass keeps them out — wait for the scatter's END (not for the table's Adam behind it, a light
-                # streaming launch this pass then runs beside)
-                ev, third_s = pend["scatter_done"]
-                _step_streams(dev)[0].wait_event(ev)
-                _step_streams(dev)[0].wait_stream(third_s)
-                pend["scatter_done"] = []
+            if _step_call_applies(model, cfg):
+                # ... and the whole forward chain of such a step as ONE C-ABI call (tn_train_step_fwd, round 6)
+                return _StepCall.forward(ctx, model, o, d, nears, fars, cam, jitter, params, prop_structs, anneal, uniform, single)
             rc = _hip.tn_render_config()
             rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = P[0], P[1], S
             rc.training, rc.pdf_anneal, rc.early_stop_transmittance, rc.kernel_family = 1, anneal, 0.0, 0
@@ -626,6 +617,8 @@ class RenderTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_th, g_acc, g_w0, g_w1, g_w2, *unused):
+        if getattr(ctx, "step_call", None) is not None:
+            return _StepCall.backward(ctx, g_rgb, g_th, g_acc, g_w2)
         lib = _hip.load()
         model, f = ctx.model, ctx.field_tape
         cfg = model.config
@@ -826,6 +819,268 @@ class RenderTrain(torch.autograd.Function):
         g_o, g_d = ray_grads if ray_grads else (None, None)
         result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)
         ctx.tapes = ctx.field_tape = ctx.acts = ctx.acc = None  # the tape is dead after one backward
+        return result
+
+
+# --------------------------------------------------------------------------------------------------
+# the step's launch chains as two C-ABI calls (tn_train_step_fwd / tn_train_step_bwd)
+# --------------------------------------------------------------------------------------------------
+def _step_call_applies(model, cfg) -> bool:
+    """config.fused_step_calls (default on) on the default training configuration: tape-free final level, split backward; any
+    other setting keeps the per-call path above (which is also the cross-check: same launches, same streams, same bits)."""
+    return bool(getattr(cfg, "fused_step_calls", True)) and bool(getattr(cfg, "tape_free_training", True)) \
+        and bool(getattr(cfg, "fused_backward_split", True)) and cfg.num_proposal_iterations == 2
+
+
+def _al(n: int) -> int:
+    return (n + 63) // 64 * 64  # 256-byte aligned carve-outs
+
+
+class _StepCall:
+    """RenderTrain's forward / backward on a step whose proposal networks take no gradient, each as ONE library call.  The
+    per-sample tensors of the step live in one slab (they are only ever passed on as addresses), the per-ray outputs in another
+    (the tensors autograd hands back to the caller must not keep ~150 B per sample alive)."""
+
+    @staticmethod
+    def forward(ctx, model, o, d, nears, fars, cam, jitter, params, prop_structs, anneal, uniform, single):
+        lib = _hip.load()
+        cfg = model.config
+        dev = o.device
+        R = o.shape[0]
+        P0, P1 = cfg.num_proposal_samples_per_ray
+        S = cfg.num_nerf_samples_per_ray
+        N, NP = R * S, (R * S + 63) // 64 * 64
+        hit = model.field.train_struct(prepare="struct")
+        if hit is None:
+            raise RuntimeError("config.fused_step_calls needs the reference field geometry (the MFMA chain); set it to False")
+        raw, prepared, prepared_bytes = hit
+        main, second, third = _step_streams(dev)
+        rays_grad = o.requires_grad or d.requires_grad
+        keep_base = bool(getattr(cfg, "store_base_output", True))
+        keep_jac = rays_grad and bool(getattr(cfg, "store_position_jacobian", True))
+        # ---- per-ray slab: everything that leaves as a tensor --------------------------------------------------------------------
+        ns = (P0, P1, S)
+        shapes = [("rgb", (R, 3)), ("thermal", (R, 1)), ("acc", (R, 1)), ("depth", (R, 1)), ("expected", (R, 1)), ("pd0", (R, 1)),
+                  ("pd1", (R, 1))]
+        for i, n in enumerate(ns):
+            shapes += [("w%d" % i, (R, n)), ("sp%d" % i, (R, n + 1)), ("eu%d" % i, (R, n + 1))]
+        want = getattr(cfg, "overlap_regularisers", "auto")
+        if want == "auto":
+            want = N >= 4096 * 96
+        mult_d, mult_i = float(cfg.distortion_loss_mult), float(cfg.interlevel_loss_mult)
+        if want:
+            shapes += [("g_dist", (R, S)), ("g_i0", (R, P0)), ("g_i1", (R, P1))]
+        off, total = {}, 0
+        for name, shp in shapes:
+            off[name] = total
+            total += _al(shp[0] * shp[1])
+        ray_slab = torch.empty((total,), dtype=torch.float32, device=dev)
+        t = {name: ray_slab[off[name]:off[name] + shp[0] * shp[1]].view(shp) for name, shp in shapes}
+        # ---- per-sample slab: addresses only -------------------------------------------------------------------------------------
+        need_ws = 0
+        rc = _hip.tn_render_config()
+        rc.num_proposal_samples[0], rc.num_proposal_samples[1], rc.num_nerf_samples = P0, P1, S
+        rc.training, rc.pdf_anneal, rc.early_stop_transmittance, rc.kernel_family = 1, anneal, 0.0, 0
+        rc.initial_sampler = uniform
+        rc.per_sample_jitter = 0 if single else 1
+        need_ws = lib.tn_render_workspace_bytes(rc, R)
+        sizes = [("pos", N * 3), ("starts", N), ("ends", N), ("deltas", N), ("ray_bias", R * 64), ("enc", NP * 32), ("sel", N),
+                 ("density", N), ("rgb_s", N * 3), ("th_s", N), ("base_out", N * 16 if keep_base else 0),
+                 ("jac", NP * 96 if keep_jac else 0), ("scratch", 2), ("ws", (need_ws + 3) // 4)]
+        so, stotal = {}, 0
+        for name, n in sizes:
+            so[name] = stotal
+            stotal += _al(n)
+        slab = torch.empty((stotal,), dtype=torch.float32, device=dev)
+        base = slab.data_ptr()
+
+        def ptr(name):
+            return base + 4 * so[name]
+
+        st = _hip.tn_train_step()
+        st.prop0, st.prop1 = C.pointer(prop_structs[0]), C.pointer(prop_structs[1])
+        st.field_raw, st.field, st.prepared_bytes = C.pointer(raw), C.pointer(prepared), prepared_bytes
+        ins = _hip.tn_render_inputs()
+        ins.origins, ins.directions, ins.nears, ins.fars = o.data_ptr(), d.data_ptr(), nears.data_ptr(), fars.data_ptr()
+        ins.camera_indices, ins.jitter = cam.data_ptr(), jitter.data_ptr()
+        ins.lin_bins0 = linspace_bins(P0, dev).data_ptr()
+        ins.u1 = pdf_positions(P1 + 1, dev, True).data_ptr()
+        ins.u2 = pdf_positions(S + 1, dev, True).data_ptr()
+        st.cfg, st.inputs, st.num_rays = C.pointer(rc), C.pointer(ins), R
+        for i in range(3):
+            st.spacing[i], st.eucl[i], st.weights[i] = t["sp%d" % i].data_ptr(), t["eu%d" % i].data_ptr(), t["w%d" % i].data_ptr()
+        st.prop_depth[0], st.prop_depth[1] = t["pd0"].data_ptr(), t["pd1"].data_ptr()
+        st.positions, st.starts, st.ends, st.deltas, st.ray_bias = ptr("pos"), ptr("starts"), ptr("ends"), ptr("deltas"), ptr("ray_bias")
+        st.enc, st.selector, st.density, st.rgb_samples, st.thermal_samples = ptr("enc"), ptr("sel"), ptr("density"), ptr("rgb_s"), ptr("th_s")
+        st.base_out = ptr("base_out") if keep_base else None
+        st.jacobian = ptr("jac") if keep_jac else None
+        st.rgb, st.thermal, st.accumulation = t["rgb"].data_ptr(), t["thermal"].data_ptr(), t["acc"].data_ptr()
+        st.depth, st.expected_depth, st.depth_scratch = t["depth"].data_ptr(), t["expected"].data_ptr(), ptr("scratch")
+        st.workspace, st.workspace_bytes = ptr("ws"), need_ws
+        slot = (dev, _hip.current_stream())
+        _drop_precomputed(slot)
+        entry = None
+        if want:
+            st.distortion_mult, st.interlevel_mult = mult_d, mult_i
+            entry = {"hold": (ray_slab,)}
+            w2, c2 = t["w2"], t["sp2"]
+            if mult_d:
+                loss_d = _hip.fresh_zeros((2,), dev)
+                st.distortion_loss_pair, st.distortion_grad = loss_d.data_ptr(), t["g_dist"].data_ptr()
+                entry["dist"] = ((_tensor_key(w2), _tensor_key(c2), mult_d), (loss_d, t["g_dist"]), second)
+            loss_i = _hip.fresh_zeros((1,), dev)
+            st.interlevel_loss = loss_i.data_ptr()
+            st.interlevel_grad[0], st.interlevel_grad[1] = t["g_i0"].data_ptr(), t["g_i1"].data_ptr()
+            key = (_tensor_key(w2), _tensor_key(c2), mult_i) + tuple((_tensor_key(t["w%d" % i]), _tensor_key(t["sp%d" % i])) for i in range(2))
+            entry["inter"] = (key, (loss_i, [t["g_i0"], t["g_i1"]]), third)
+        st.stream, st.second, st.third = main.cuda_stream, second.cuda_stream, third.cuda_stream
+        # a deferred table update of the previous step (config.deferred_table_update): the call waits for it right before the
+        # field launch; the registry entry (and the temporaries it holds) is released here — the events carry the order
+        pend = _hip.take_pending(dev)
+        events = []
+        if pend is not None:
+            for s_ in pend["streams"]:
+                if s_.cuda_stream != main.cuda_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(s_)
+                    events.append(ev)
+        if events:
+            arr = (C.c_void_p * len(events))(*[ev.cuda_event for ev in events])
+            st.wait_events, st.num_wait_events = arr, len(events)
+        _hip.check(lib.tn_train_step_fwd(C.byref(st)), "tn_train_step_fwd")
+        # (the deferred update's temporaries — pend["keep"] — may go now: whatever reuses their memory is queued on the calling
+        # stream behind the events just waited for)
+        pend = None
+        if entry is not None:
+            _REG_PRE[slot] = entry
+
+        ctx.set_materialize_grads(False)
+        ctx.model, ctx.o, ctx.d, ctx.cam = model, o, d, cam
+        ctx.step_call = (slab, so, ray_slab, off, R, S, keep_base, keep_jac)
+        ctx.updated, ctx.tape_free = False, True
+        ctx.tapes = ctx.field_tape = ctx.acts = ctx.acc = None
+        ctx.param_names = model.named_parameter_lists()[0]
+        ctx.params = dict(zip(ctx.param_names, params))
+        # (fresh views: ctx must not hold a tensor OBJECT that is also returned, see RenderTrain.forward)
+        outs = (t["rgb"], t["thermal"], t["acc"], t["w0"][..., None], t["w1"][..., None], t["w2"][..., None], t["depth"], t["expected"],
+                t["pd0"], t["pd1"], t["sp0"], t["sp1"], t["sp2"], t["eu0"], t["eu1"], t["eu2"])
+        ctx.mark_non_differentiable(*outs[3:5], *outs[6:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_th, g_acc, g_w2):
+        lib = _hip.load()
+        model = ctx.model
+        cfg = model.config
+        slab, so, ray_slab, off, R, S, keep_base, keep_jac = ctx.step_call
+        dev = slab.device
+        N = R * S
+        _drop_precomputed((dev, _hip.current_stream()))
+        fld = model.field.train_struct()
+        like = ctx.params
+        arena = _GradArena(like, dev, extra=R * (64 + 2 * 64 + S) + 1024)
+        ray_grads = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            ray_grads = (arena.zeros(tuple(ctx.o.shape)), arena.zeros(tuple(ctx.d.shape)))
+        sh_grads = ray_grads is not None and bool(cfg.sh_direction_gradient)
+        grads: Dict[str, Tensor] = {}
+        base, rbase = slab.data_ptr(), ray_slab.data_ptr()
+
+        def ptr(name):
+            return base + 4 * so[name]
+
+        a = _hip.tn_train_step_bwd_args()
+        a.field, a.num_rays, a.n = C.pointer(fld), R, S
+        a.positions, a.starts, a.ends, a.deltas, a.ray_bias = ptr("pos"), ptr("starts"), ptr("ends"), ptr("deltas"), ptr("ray_bias")
+        a.enc, a.selector, a.density, a.rgb_samples, a.thermal_samples = ptr("enc"), ptr("sel"), ptr("density"), ptr("rgb_s"), ptr("th_s")
+        a.base_out = ptr("base_out") if keep_base else None
+        a.jacobian = ptr("jac") if keep_jac else None
+        a.accumulation = rbase + 4 * off["acc"]
+        a.directions, a.camera_indices = ctx.d.data_ptr(), ctx.cam.data_ptr()
+        hold = []  # contiguous copies of the incoming gradients live until the call has been queued (same stream: no race)
+        for name, g in (("d_rgb", g_rgb), ("d_thermal", g_th), ("d_accumulation", g_acc), ("d_weights", g_w2)):
+            if g is not None:
+                g = _hip.require_device_tensor(g, name)
+                hold.append(g)
+                setattr(a, name, g.data_ptr())
+        a.use_gradient_scaling = 1 if cfg.use_gradient_scaling else 0
+        a.pass_thermal_gradients = 1 if model.field.pass_thermal_gradients else 0
+        a.split_form = 2 if getattr(cfg, "backward_bf16_pieces", True) else 1
+        a.sh_direction_gradient = 1 if sh_grads else 0
+        a.trunc_exp_min = float(getattr(cfg, "trunc_exp_clamp_min", -15.0))
+        # scratch of the backward: one slab (addresses only)
+        first = -1
+        if getattr(cfg, "bucketed_table_scatter", True):
+            first = lib.tn_hash_encode_bwd_sorted_first_level(fld.grid, N)
+        need_sorted = lib.tn_hash_encode_bwd_sorted_workspace_bytes(fld.grid, N, first) if first >= 0 else 0
+        sizes = [("g_rgb_s", N * 3 if g_rgb is not None else 0), ("g_th_s", N if g_th is not None else 0), ("g_density", N), ("g_enc", N * 32),
+                 ("g_pos", N * 3 if ray_grads else 0), ("g_cin", R * 64 if (sh_grads and g_rgb is not None) else 0),
+                 ("sorted", (need_sorted + 3) // 4)]
+        bo, btotal = {}, 0
+        for name, n in sizes:
+            bo[name] = btotal
+            btotal += _al(n)
+        try:
+            bslab = torch.empty((btotal,), dtype=torch.float32, device=dev)
+        except torch.cuda.OutOfMemoryError:  # no room for the records: the same sums through the global atomics
+            btotal -= _al(sizes[-1][1])
+            bslab, first, need_sorted = torch.empty((btotal,), dtype=torch.float32, device=dev), -1, 0
+        bb = bslab.data_ptr()
+        a.d_rgb_samples = bb + 4 * bo["g_rgb_s"] if g_rgb is not None else None
+        a.d_thermal_samples = bb + 4 * bo["g_th_s"] if g_th is not None else None
+        a.d_density, a.d_enc = bb + 4 * bo["g_density"], bb + 4 * bo["g_enc"]
+        a.d_positions = bb + 4 * bo["g_pos"] if ray_grads else None
+        a.d_ray_inputs = bb + 4 * bo["g_cin"] if (sh_grads and g_rgb is not None) else None
+        gr = _hip.tn_field_grads()
+        names = {"base0": "field.mlp_base.mlp.layers.0", "base1": "field.mlp_base.mlp.layers.1",
+                 "head0": "field.mlp_head.layers.0", "head1": "field.mlp_head.layers.1", "head2": "field.mlp_head.layers.2",
+                 "th0": "field.mlp_thermal.layers.0", "th1": "field.mlp_thermal.layers.1", "thead": "field.field_head_thermal.net"}
+
+        def zeros(name: str) -> Tensor:
+            grads[name] = arena.get(name)
+            return grads[name]
+
+        for key, name in names.items():
+            if key.startswith("head") and g_rgb is None:
+                continue
+            if key.startswith("th") and g_th is None:
+                continue
+            setattr(gr, key + "_w", zeros(name + ".weight").data_ptr())
+            if key != "head0":
+                setattr(gr, key + "_b", zeros(name + ".bias").data_ptr())
+        a.grads = C.pointer(gr)
+        if g_rgb is not None:
+            a.d_ray_sum = arena.zeros((R, 64)).data_ptr()
+            a.d_head0_bias = zeros("field.mlp_head.layers.0.bias").data_ptr()
+            a.d_appearance = zeros("field.embedding_appearance.embedding.weight").data_ptr()
+        a.d_table = zeros("field.mlp_base.encoder.hash_table").data_ptr()
+        if ray_grads:
+            a.d_origins, a.d_directions = ray_grads[0].data_ptr(), ray_grads[1].data_ptr()
+        ws = _fused_bwd_workspace(dev, R, S)
+        a.fused_workspace, a.fused_workspace_bytes = ws.data_ptr(), ws.numel()
+        a.first_sorted_level = first
+        if need_sorted:
+            a.sorted_workspace, a.sorted_workspace_bytes = bb + 4 * bo["sorted"], need_sorted
+        main, second, third = _step_streams(dev)
+        overlap = bool(getattr(cfg, "overlap_table_scatter", True))
+        defer = bool(getattr(cfg, "deferred_table_update", False)) and overlap and first > 0
+        a.spread = 1 if getattr(cfg, "spread_coarse_scatter", True) else 0
+        if a.spread:
+            need = lib.tn_hash_encode_bwd_spread_workspace_bytes(fld.grid)
+            if need:
+                key = (dev, third.cuda_stream if defer else main.cuda_stream, need)
+                sws = _SPREAD_WS.get(key)
+                if sws is None:
+                    sws = _SPREAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+                a.spread_workspace, a.spread_workspace_bytes = sws.data_ptr(), need
+        a.overlap, a.defer = (1 if overlap else 0), (1 if defer else 0)
+        a.stream, a.second, a.third = main.cuda_stream, second.cuda_stream, third.cuda_stream
+        _hip.check(lib.tn_train_step_bwd(C.byref(a)), "tn_train_step_bwd")
+        if defer:  # both halves of the scatter are still out: whoever reads the table (or its gradient) joins (_hip.join_pending)
+            _hip.defer(dev, [second, third], [bslab, slab, ray_slab, arena.flat])
+        g_o, g_d = ray_grads if ray_grads else (None, None)
+        result = (None, g_o, g_d) + (None,) * 5 + tuple(grads.get(n) for n in ctx.param_names)
+        ctx.step_call = None
         return result
 
 

@@ -3,7 +3,7 @@
 SEC=${1:-6}; shift
 SS=${@:-192 48}
 for S in $SS; do
-  for mode in "" "--proposal-after-scatter" "--side-priority -1" "--side-priority -1 --proposal-after-scatter" "--joined-table" "--torch-adam"; do
+  for mode in "" "--per-call" "--joined-table" "--per-call --joined-table" "--per-call --torch-adam"; do
     echo "== S=$S ${mode:-deferred (default)}"
     python tools/train_bench.py --samples $S --ray-batch random --seconds $SEC $mode 2>&1 | tail -1
   done

@@ -22,8 +22,11 @@ model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(
 synthetic.fill_model_(model, "scene")
 model.to(dev).train()
 groups = model.get_param_groups()
-opt = torch.optim.Adam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}, {"params": groups["camera_opt"], "lr": 6e-4}],
-                       lr=1e-2, eps=1e-15, fused=True)
+from thermo_nerf_amd.optim import HipAdam  # noqa: E402
+
+opt = HipAdam([{"params": groups["fields"]}, {"params": groups["proposal_networks"]}, {"params": groups["camera_opt"], "lr": 6e-4}],
+              lr=1e-2, eps=1e-15, deferred=[model.field.mlp_base.encoder.hash_table])
+model.config.deferred_table_update = True
 o, d, cam = (t.to(dev) for t in synthetic.random_pixel_rays(4096))
 g = torch.Generator().manual_seed(0)
 batch = {"image": torch.rand(4096, 3, generator=g).to(dev), "thermal": torch.rand(4096, 1, generator=g).to(dev)}

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--start-step", type=int, default=5000,
                     help="training step the timed region starts at (>= proposal_warmup: proposal nets update every 6th step)")
     ap.add_argument("--side-priority", type=int, default=0, help="priority of the step's side streams (-1 = high)")
-    ap.add_argument("--proposal-after-scatter", action="store_true", help="config.deferred_proposal_after_scatter")
+    ap.add_argument("--per-call", action="store_true", help="config.fused_step_calls = False: one ctypes call per launch (rounds 1-5)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) + joined table scatter (rounds 1-5)")
     ap.add_argument("--joined-table", action="store_true", help="HipAdam, but the table's scatter and Adam joined by the backward / on the calling stream")
     a = ap.parse_args()
@@ -64,6 +64,7 @@ def main():
     model = ThermalNerfModel(cfg, metadata={"thermal": []}, scene_box=SceneBox.unit(), num_train_data=8)
     synthetic.fill_model_(model, a.weights)
     model.to(dev).train()
+    model.config.fused_step_calls = not a.per_call
     groups = model.get_param_groups()
     pg = [{"params": groups["fields"]}, {"params": groups["proposal_networks"]}]
     if "camera_opt" in groups:
@@ -75,7 +76,6 @@ def main():
 
         opt = HipAdam(pg, lr=1e-2, eps=1e-15, deferred=[] if a.joined_table else [model.field.mlp_base.encoder.hash_table])
         model.config.deferred_table_update = not a.joined_table
-        model.config.deferred_proposal_after_scatter = bool(a.proposal_after_scatter)
     g = torch.Generator().manual_seed(0)
     side = int(a.rays ** 0.5)
     o, d, _ = synthetic.orbit_camera_rays(side, side, view=1)
