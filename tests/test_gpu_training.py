@@ -432,6 +432,32 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
     assert checked >= (13 if variant == "same_proposal_network" else 18)
 
 
+@pytest.mark.parametrize("widths", [(32, 16, 48), (16, 64, 8)])
+@pytest.mark.parametrize("kind", ["stress", "scene"])
+def test_training_step_with_other_mlp_widths(kind, widths):
+    """hidden_dim / hidden_dim_color / hidden_dim_transient other than 64 (field.staged): the training step takes the stage-by-stage
+    forward and one tn_linear_bwd per layer; outputs, losses and every parameter gradient against torch autograd over the oracle."""
+    hd, hc, ht = widths
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, 48, hidden_dim=hd, hidden_dim_color=hc, hidden_dim_transient=ht)
+    assert gm.field.staged
+    out, loss_dict = _gpu_step(gm, o, d, jit, cam, batch)
+    want_out, want_loss, want_grads = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit)
+    for k in ("rgb", "thermal", "accumulation"):
+        assert (out[k].detach().cpu() - want_out[k].detach()).abs().max().item() <= 2e-5, k
+    for k, v in want_loss.items():
+        assert abs(loss_dict[k].item() - v.item()) <= 2e-5 * abs(v.item()) + 1e-8, (k, loss_dict[k].item(), v.item())
+    named = dict(gm.named_parameters())
+    checked = 0
+    for name, gw in want_grads.items():
+        if gw.numel() == 0 or name.startswith("camera_optimizer") or name.startswith("__") or gw.norm().item() < 1e-10:
+            continue
+        gg = named[name].grad
+        assert gg is not None and gg.shape == gw.shape, name
+        assert rel(gg, gw) <= 2e-3, f"{name}: rel {rel(gg, gw):.2e}"
+        checked += 1
+    assert checked >= 18
+
+
 @pytest.mark.parametrize("variant", ["default", "pose", "pose_sh", "gradient_scaling", "no_thermal_gradients", "deferred"])
 @pytest.mark.parametrize("S", [48, 192])
 def test_step_calls_equal_the_per_call_path(S, variant):

@@ -35,6 +35,9 @@ class RayRenderEngine:
         the number of streams (``frame_launch_rays``: 1080p at S=48 and the default 2 GiB -> 4 launches of 8 chunks, 1.6 GiB)."""
         if model.training:
             raise RuntimeError("RayRenderEngine renders in eval mode; call model.eval() first")
+        if getattr(model.field, "staged", False):
+            raise RuntimeError("RayRenderEngine drives the fused kernels (64-wide MLP layers); this field is staged (other widths): "
+                               "render it through model.get_outputs_for_camera_ray_bundle")
         self.model = model
         self.chunk = int(chunk or model.config.eval_num_rays_per_chunk)
         self.lib = _hip.load()

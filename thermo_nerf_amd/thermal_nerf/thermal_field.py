@@ -55,8 +55,13 @@ class ThermalNerfactoTField(nn.Module):
             raise NotImplementedError("transient / semantics heads are off on the ThermoNeRF path")
         if (num_layers, num_layers_color, num_layers_transient) != (2, 3, 2):
             raise NotImplementedError("kernels implement mlp_base 2, mlp_head 3, mlp_thermal 2 layers (the defaults)")
-        if hidden_dim != 64 or hidden_dim_color != 64 or hidden_dim_transient != 64:
-            raise NotImplementedError("kernels implement 64-wide mlp_base / mlp_head / mlp_thermal (the defaults)")
+        widths = (int(hidden_dim), int(hidden_dim_color), int(hidden_dim_transient))
+        if min(widths) < 1 or max(widths) > 64:
+            raise NotImplementedError("hidden_dim / hidden_dim_color / hidden_dim_transient [REF thermal_nerf_model.py:96-114] up to 64 "
+                                      "(the Linear kernels hold a layer's rows in one 64-wide tile); the defaults are 64")
+        # the fused kernels (MFMA chains, one launch per pass) are laid out for the reference's 64-wide layers; any other width runs
+        # the SAME arithmetic stage by stage — hash encode, one tn_linear_fwd / tn_linear_bwd per layer — in eval and in training
+        self.staged = widths != (64, 64, 64)
         self.register_buffer("aabb", aabb.clone().float())
         self.geo_feat_dim = geo_feat_dim
         self.register_buffer("max_res", torch.tensor(max_res))
@@ -205,6 +210,8 @@ class ThermalNerfactoTField(nn.Module):
         pos = _hip.require_device_tensor(positions, "positions")
         flat = pos.reshape(-1, 3)
         n = flat.shape[0]
+        if self.staged:
+            return self._density_staged(positions, flat, n)
         density = torch.empty((n,), dtype=torch.float32, device=flat.device)
         geo = torch.empty((n, self.geo_feat_dim), dtype=torch.float32, device=flat.device)
         lib = _hip.load()
@@ -212,6 +219,39 @@ class ThermalNerfactoTField(nn.Module):
                                             _hip.current_stream()), "tn_field_density_fwd")
         shape = positions.shape[:-1]
         return density.view(*shape, 1), geo.view(*shape, self.geo_feat_dim)
+
+    # ---- widths other than 64: one launch per nerfstudio module / layer (the training step's stage entry points) --------------
+    def _density_staged(self, positions: Tensor, flat: Tensor, n: int) -> Tuple[Tensor, Tensor]:
+        """NS NerfactoField.get_density as its modules: HashEncoding -> Linear + ReLU -> Linear -> split -> trunc_exp * selector"""
+        from .. import training as TR
+
+        fld = self.train_struct()
+        enc, sel = TR.hash_encode_fwd(fld.grid, fld.space, flat)
+        h1 = TR.linear_fwd(enc, 0, enc.shape[1], fld.base0, TR.ACT_RELU, n)
+        bo = TR.linear_fwd(h1, 0, h1.shape[1], fld.base1, TR.ACT_NONE, n)  # [n, 1 + geo]
+        density = torch.empty((n,), dtype=torch.float32, device=flat.device)
+        _hip.check(_hip.load().tn_density_act_fwd(bo.data_ptr(), bo.shape[1], sel.data_ptr(), fld.average_init_density, n,
+                                                  density.data_ptr(), _hip.current_stream()), "tn_density_act_fwd")
+        shape = positions.shape[:-1]
+        return density.view(*shape, 1), bo[:, 1:].contiguous().view(*shape, self.geo_feat_dim)
+
+    def _heads_staged(self, dirs: Tensor, geo: Tensor, cam: Optional[Tensor], n: int) -> Tuple[Tensor, Tensor]:
+        """[REF thermal_field.py:117-179] as its modules: [SH | geo | appearance] -> mlp_head; geo -> mlp_thermal -> thermal head"""
+        from .. import training as TR
+
+        lib = _hip.load()
+        fld = self.c_struct(prepare=False, dense=False) if not self.training else self.train_struct()
+        cin = torch.empty((n, 64), dtype=torch.float32, device=dirs.device)
+        G = self.geo_feat_dim
+        _hip.check(lib.tn_color_input_fwd(fld, dirs.data_ptr(), geo.data_ptr(), G, _hip.ptr(cam), 1 if self.training else 0, n, 1,
+                                          cin.data_ptr(), _hip.current_stream()), "tn_color_input_fwd")
+        c1 = TR.linear_fwd(cin, 0, 64, fld.head0, TR.ACT_RELU, n)
+        c2 = TR.linear_fwd(c1, 0, c1.shape[1], fld.head1, TR.ACT_RELU, n)
+        rgb = TR.linear_fwd(c2, 0, c2.shape[1], fld.head2, TR.ACT_SIGMOID, n)
+        t1 = TR.linear_fwd(geo, 0, G, fld.th0, TR.ACT_RELU, n)
+        t2 = TR.linear_fwd(t1, 0, t1.shape[1], fld.th1, TR.ACT_SIGMOID, n)
+        thermal = TR.linear_fwd(t2, 0, t2.shape[1], fld.thead, TR.ACT_NONE, n)
+        return rgb, thermal.view(n)
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None
                     ) -> Dict[Union[FieldHeadNamesT, FieldHeadNames], Tensor]:
@@ -229,6 +269,9 @@ class ThermalNerfactoTField(nn.Module):
         if self.training:
             cam = _hip.require_device_tensor(ray_samples.camera_indices.reshape(-1).to(torch.int32), "camera_indices",
                                              torch.int32)
+        if self.staged:
+            rgb, thermal = self._heads_staged(dirs, geo, cam, n)
+            return {FieldHeadNames.RGB: rgb.view(*outputs_shape, 3), FieldHeadNamesT.THERMAL: thermal.view(*outputs_shape, 1)}
         rgb = torch.empty((n, 3), dtype=torch.float32, device=dirs.device)
         thermal = torch.empty((n,), dtype=torch.float32, device=dirs.device)
         lib = _hip.load()

@@ -175,7 +175,8 @@ class ThermalNerfModel(ThermalNerfactoModel):
     def _fusable(self) -> bool:
         cfg = self.config
         # use_gradient_scaling only rescales gradients (backward); use_same_proposal_network hands one network to both levels
-        return cfg.fused and cfg.num_proposal_iterations == 2 and not cfg.predict_normals
+        # (field.staged: MLP widths other than the reference's 64 run one launch per module / layer, thermal_field.py)
+        return cfg.fused and cfg.num_proposal_iterations == 2 and not cfg.predict_normals and not self.field.staged
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:

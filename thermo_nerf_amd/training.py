@@ -683,7 +683,6 @@ class RenderTrain(torch.autograd.Function):
                                          _hip.ptr(None if g_acc is None else g_acc.contiguous()), _hip.ptr(g_wx),
                                          _hip.ptr(st_en[0]), _hip.ptr(st_en[1]), R, S, _hip.ptr(g_rgb_s), _hip.ptr(g_th_s),
                                          g_density.data_ptr(), _stream()), "tn_ray_render_bwd")
-        W = 64
         E = f.enc.shape[1]
         g_enc = _f32((N, E), dev)  # row-major [N,32] in both forms (what the table scatter reads)
         if ctx.tape_free:
@@ -743,47 +742,52 @@ class RenderTrain(torch.autograd.Function):
                 _hip.defer(dev, (), [arena.flat, f.enc, g_density, g_rgb_s, g_th_s])
             return RenderTrain._finish(ctx, model, grads, arena, ray_grads, chained, bucketed, exp_min, g_prop, prop_join)
         ldb = bo.shape[1]
+        # layer widths as built (config.hidden_dim / hidden_dim_color / hidden_dim_transient; 64 in the reference's configs)
+        Wb, Wc = h1.shape[1], c1.shape[1]
+        Wt1, Wt2 = t1.shape[1], t2.shape[1]
+        if model.field.staged:
+            chained = False  # (the chained launch tiles 64-wide layers)
         g_bo = _f32((N, ldb), dev)  # column 0 written, the geo columns cleared (the += target of both heads) in one pass
         _hip.check(lib.tn_density_act_bwd(bo.data_ptr(), ldb, f.sel.data_ptr(), fld.average_init_density, exp_min,
                                           g_density.data_ptr(), N, g_bo.data_ptr(), ldb, ldb, _stream()), "tn_density_act_bwd")
         if g_th_s is not None:  # thermal branch [REF thermal_field.py:170-179]
             into_geo = g_bo if model.field.pass_thermal_gradients else None  # REF :171-172 (.detach())
-            th = [(fld.thead, t2, 0, W, ACT_SIGMOID, zeros("field.field_head_thermal.net.weight"),
+            th = [(fld.thead, t2, 0, Wt2, ACT_SIGMOID, zeros("field.field_head_thermal.net.weight"),
                    zeros("field.field_head_thermal.net.bias")),
-                  (fld.th1, t1, 0, W, ACT_RELU, zeros("field.mlp_thermal.layers.1.weight"), zeros("field.mlp_thermal.layers.1.bias")),
+                  (fld.th1, t1, 0, Wt1, ACT_RELU, zeros("field.mlp_thermal.layers.1.weight"), zeros("field.mlp_thermal.layers.1.bias")),
                   (fld.th0, bo, 1, ldb, ACT_NONE, zeros("field.mlp_thermal.layers.0.weight"), zeros("field.mlp_thermal.layers.0.bias"))]
             if chained:
                 linear_chain_bwd(th, None, ACT_NONE, g_th_s, 1, N, into_geo, 1, ldb, True)
             else:
-                g_t2, g_t1 = _f32((N, W), dev), _f32((N, W), dev)
-                linear_bwd(t2, 0, W, None, g_th_s, 1, fld.thead, ACT_NONE, N, g_t2, 0, W, False, th[0][5], th[0][6])
-                linear_bwd(t1, 0, W, t2, g_t2, W, fld.th1, ACT_SIGMOID, N, g_t1, 0, W, False, th[1][5], th[1][6])
-                linear_bwd(bo, 1, ldb, t1, g_t1, W, fld.th0, ACT_RELU, N, into_geo, 1, ldb, True, th[2][5], th[2][6])
+                g_t2, g_t1 = _f32((N, Wt2), dev), _f32((N, Wt1), dev)
+                linear_bwd(t2, 0, Wt2, None, g_th_s, 1, fld.thead, ACT_NONE, N, g_t2, 0, Wt2, False, th[0][5], th[0][6])
+                linear_bwd(t1, 0, Wt1, t2, g_t2, Wt2, fld.th1, ACT_SIGMOID, N, g_t1, 0, Wt1, False, th[1][5], th[1][6])
+                linear_bwd(bo, 1, ldb, t1, g_t1, Wt1, fld.th0, ACT_RELU, N, into_geo, 1, ldb, True, th[2][5], th[2][6])
         if g_rgb_s is not None:  # colour branch [REF :160-168]
             g_cin = _f32((N, 64), dev)
-            hd = [(fld.head2, c2, 0, W, ACT_RELU, zeros("field.mlp_head.layers.2.weight"), zeros("field.mlp_head.layers.2.bias")),
-                  (fld.head1, c1, 0, W, ACT_RELU, zeros("field.mlp_head.layers.1.weight"), zeros("field.mlp_head.layers.1.bias")),
+            hd = [(fld.head2, c2, 0, Wc, ACT_RELU, zeros("field.mlp_head.layers.2.weight"), zeros("field.mlp_head.layers.2.bias")),
+                  (fld.head1, c1, 0, Wc, ACT_RELU, zeros("field.mlp_head.layers.1.weight"), zeros("field.mlp_head.layers.1.bias")),
                   (fld.head0, cin, 0, 64, ACT_NONE, zeros("field.mlp_head.layers.0.weight"), zeros("field.mlp_head.layers.0.bias"))]
             if chained:
                 linear_chain_bwd(hd, rgb_s, ACT_SIGMOID, g_rgb_s, 3, N, g_cin, 0, 64, False)
             else:
-                g_c2, g_c1 = _f32((N, W), dev), _f32((N, W), dev)
-                linear_bwd(c2, 0, W, rgb_s, g_rgb_s, 3, fld.head2, ACT_SIGMOID, N, g_c2, 0, W, False, hd[0][5], hd[0][6])
-                linear_bwd(c1, 0, W, c2, g_c2, W, fld.head1, ACT_RELU, N, g_c1, 0, W, False, hd[1][5], hd[1][6])
-                linear_bwd(cin, 0, 64, c1, g_c1, W, fld.head0, ACT_RELU, N, g_cin, 0, 64, False, hd[2][5], hd[2][6])
+                g_c2, g_c1 = _f32((N, Wc), dev), _f32((N, Wc), dev)
+                linear_bwd(c2, 0, Wc, rgb_s, g_rgb_s, 3, fld.head2, ACT_SIGMOID, N, g_c2, 0, Wc, False, hd[0][5], hd[0][6])
+                linear_bwd(c1, 0, Wc, c2, g_c2, Wc, fld.head1, ACT_RELU, N, g_c1, 0, Wc, False, hd[1][5], hd[1][6])
+                linear_bwd(cin, 0, 64, c1, g_c1, Wc, fld.head0, ACT_RELU, N, g_cin, 0, 64, False, hd[2][5], hd[2][6])
             _hip.check(lib.tn_color_input_bwd(fld, g_cin.data_ptr(), ctx.cam.data_ptr(), 1, R, S, g_bo.data_ptr() + 4, ldb,
                                               zeros("field.embedding_appearance.embedding.weight").data_ptr(),
                                               ctx.d.data_ptr() if sh_grads else None,
                                               ray_grads[1].data_ptr() if sh_grads else None, _stream()),
                        "tn_color_input_bwd")
-        bs = [(fld.base1, h1, 0, W, ACT_RELU, zeros("field.mlp_base.mlp.layers.1.weight"), zeros("field.mlp_base.mlp.layers.1.bias")),
+        bs = [(fld.base1, h1, 0, Wb, ACT_RELU, zeros("field.mlp_base.mlp.layers.1.weight"), zeros("field.mlp_base.mlp.layers.1.bias")),
               (fld.base0, f.enc, 0, E, ACT_NONE, zeros("field.mlp_base.mlp.layers.0.weight"), zeros("field.mlp_base.mlp.layers.0.bias"))]
         if chained:
             linear_chain_bwd(bs, None, ACT_NONE, g_bo, ldb, N, g_enc, 0, E, False)
         else:
-            g_h1 = _f32((N, W), dev)
-            linear_bwd(h1, 0, W, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, W, False, bs[0][5], bs[0][6])
-            linear_bwd(f.enc, 0, E, h1, g_h1, W, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
+            g_h1 = _f32((N, Wb), dev)
+            linear_bwd(h1, 0, Wb, None, g_bo, ldb, fld.base1, ACT_NONE, N, g_h1, 0, Wb, False, bs[0][5], bs[0][6])
+            linear_bwd(f.enc, 0, E, h1, g_h1, Wb, fld.base0, ACT_RELU, N, g_enc, 0, E, False, bs[1][5], bs[1][6])
         hash_encode_bwd(fld.grid, fld.space, f.pos, g_enc, zeros("field.mlp_base.encoder.hash_table"), bucketed, spread,
                         getattr(cfg, "overlap_table_scatter", True))
         if ray_grads:
@@ -829,7 +833,7 @@ def _step_call_applies(model, cfg) -> bool:
     """config.fused_step_calls (default on) on the default training configuration: tape-free final level, split backward; any
     other setting keeps the per-call path above (which is also the cross-check: same launches, same streams, same bits)."""
     return bool(getattr(cfg, "fused_step_calls", True)) and bool(getattr(cfg, "tape_free_training", True)) \
-        and bool(getattr(cfg, "fused_backward_split", True)) and cfg.num_proposal_iterations == 2
+        and bool(getattr(cfg, "fused_backward_split", True)) and cfg.num_proposal_iterations == 2 and not model.field.staged
 
 
 def _al(n: int) -> int:
