@@ -589,6 +589,13 @@ int tn_color_input_bwd(const tn_thermal_field *field, const float *d_cin, const 
  * scale_gradients_by_distance_squared [REF :228-231] to the three.  n <= 1024. */
 int tn_ray_render_fwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
                       int64_t num_rays, int32_t n, float *weights, float *rgb, float *thermal, float *accumulation, void *stream);
+/* tn_ray_render_fwd + tn_depth_fwd(median, expected) of the same level in one pass [REF thermal_nerf_model.py:233-243]: the weights
+ * are in registers when the depth renderers need them.  Bit-equal outputs to the two calls; the expected depth's call-global clip
+ * [NS DepthRenderer("expected")] reduces per-block bounds instead of two atomically updated words: bounds_scratch holds
+ * 2 * ceil(num_rays / 4) floats and needs no initialisation. */
+int tn_ray_render_depth_fwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
+                            const float *starts, const float *ends, int64_t num_rays, int32_t n, float *weights, float *rgb,
+                            float *thermal, float *accumulation, float *median, float *expected, float *bounds_scratch, void *stream);
 int tn_ray_render_bwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
                       const float *accumulation, const float *d_rgb, const float *d_thermal, const float *d_accumulation,
                       const float *d_weights, const float *starts, const float *ends, int64_t num_rays, int32_t n,
@@ -599,6 +606,12 @@ int tn_ray_render_bwd(const float *deltas, const float *densities, const float *
  * out[1] = thermal MSE, out[2] = 10 log10(1 / out[0]); d_rgb [R,3] (=) and d_thermal [R] (=) = the gradients of the two means. */
 int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal, const float *gt_thermal, int64_t num_rays,
                     float *out, float *d_rgb, float *d_thermal, void *stream);
+
+/* The step's total loss as nerfstudio's Trainer forms it — functools.reduce(torch.add, loss_dict.values()) [NS Trainer.train_iteration,
+ * driven by REF thermo_nerf/thermal_nerf/config_thermal_nerf.py:17-30] — in one launch: out[0] = ((t0 + t1) + t2) + ...;
+ * `terms` is a HOST array of `count` <= TN_SUM_MAX_TERMS device pointers to one float each. */
+#define TN_SUM_MAX_TERMS 16
+int tn_sum_scalars(const float *const *terms, int32_t count, float *out, void *stream);
 
 /* NS losses.distortion_loss on one level: spacing bins [R,n+1], weights [R,n] -> loss_sum[0] (+=) = scale * sum over rays
  * of lossfun_distortion (scale = 1/R for nerfstudio's mean), d_weights [R,n] (=) = scale * d(sum)/dw.  O(n) per ray. */
@@ -630,8 +643,8 @@ int tn_interlevel_loss_levels(const float *c, const float *w, int64_t num_rays, 
  *
  * tn_train_step_fwd:  tn_field_prepare(field_raw -> field->prepared) | tn_proposal_sample_fwd (train-mode, untaped) |
  *   tn_frustum_from_edges | tn_ray_head_fwd | [wait for `wait_events`: a deferred table update of the previous step] |
- *   tn_field_fwd_train | tn_ray_render_fwd | the two regularisers on `second` / `third` behind the level's weights (when their
- *   loss pointers are set: tn_distortion_loss_term, tn_interlevel_loss_levels) | tn_depth_fwd.
+ *   tn_field_fwd_train | tn_ray_render_depth_fwd | the two regularisers on `second` / `third` behind the level's weights (when their
+ *   loss pointers are set: tn_distortion_loss_term, tn_interlevel_loss_levels).
  * tn_train_step_bwd:  tn_ray_render_bwd | tn_field_bwd_fused | the table scatter — tn_hash_encode_bwd_sorted on `second` beside
  *   tn_hash_encode_bwd_spread / _levels for the levels below `first_sorted_level` on `stream` (defer == 0: `stream` waits for
  *   `second` at the end) or on `third` (defer != 0: nobody waits — the caller joins, thermo_nerf_amd/_hip.py) | the ray-level
@@ -652,9 +665,11 @@ typedef struct tn_train_step {
     float *starts, *ends, *deltas;       /* [R, S]                                                                      */
     float *ray_bias;                     /* [R, 64]                                                                     */
     float *enc, *selector, *density, *rgb_samples, *thermal_samples, *base_out, *jacobian; /* tn_field_fwd_train's      */
-    float *rgb, *thermal, *accumulation, *depth, *expected_depth, *depth_scratch;          /* [R,3] [R] [R] [R] [R] [2] */
+    float *rgb, *thermal, *accumulation, *depth, *expected_depth, *depth_scratch; /* [R,3] [R] [R] [R] [R] [2 ceil(R/4)] */
     void *workspace;                     /* tn_render_workspace_bytes(cfg, num_rays)                                    */
     size_t workspace_bytes;
+    void *zero_buffer;                   /* optional: cleared (hipMemsetAsync) on `second` at the start of the call — the  */
+    size_t zero_bytes;                   /* backward's gradient arena, off the calling stream (tn_train_step_bwd waits)    */
     /* regularisers (optional: loss pointers NULL = not launched); losses are += accumulators the caller zeroed         */
     float distortion_mult, interlevel_mult;
     float *distortion_loss_pair, *distortion_grad;   /* [2], [R,S]                                                      */
@@ -689,6 +704,7 @@ typedef struct tn_train_step_bwd_args {
     int32_t spread;                      /* config.spread_coarse_scatter                                                */
     void *spread_workspace; size_t spread_workspace_bytes;    /* of the stream the atomic levels run on                 */
     int32_t overlap, defer;              /* config.overlap_table_scatter / deferred_table_update                        */
+    int32_t wait_second_first;           /* the gradients were cleared on `second` by tn_train_step_fwd (zero_buffer)   */
     void *stream, *second, *third;
 } tn_train_step_bwd_args;
 int tn_train_step_bwd(const tn_train_step_bwd_args *a);

@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(_hip.tn_render_outputs) == 7 * 8 + 9 * 8
     assert ctypes.sizeof(_hip.tn_adam_tensor) == 4 * 8 + 8 + 7 * 4 + 4  # (+ tail padding to 8)
     # the step calls' argument blocks (round 6): sizes as gcc lays the header's structs out (g++ -I. on include/thermonerf_hip.h)
-    assert ctypes.sizeof(_hip.tn_train_step) == 400 and ctypes.sizeof(_hip.tn_train_step_bwd_args) == 400
+    assert ctypes.sizeof(_hip.tn_train_step) == 416 and ctypes.sizeof(_hip.tn_train_step_bwd_args) == 408
 
 
 def test_model_surface_and_state_dict_names():

@@ -167,7 +167,7 @@ class tn_train_step(C.Structure):
                 ("enc", _fp), ("selector", _fp), ("density", _fp), ("rgb_samples", _fp), ("thermal_samples", _fp), ("base_out", _fp),
                 ("jacobian", _fp),
                 ("rgb", _fp), ("thermal", _fp), ("accumulation", _fp), ("depth", _fp), ("expected_depth", _fp), ("depth_scratch", _fp),
-                ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+                ("workspace", _fp), ("workspace_bytes", C.c_size_t), ("zero_buffer", _fp), ("zero_bytes", C.c_size_t),
                 ("distortion_mult", C.c_float), ("interlevel_mult", C.c_float),
                 ("distortion_loss_pair", _fp), ("distortion_grad", _fp), ("interlevel_loss", _fp), ("interlevel_grad", _fp * 2),
                 ("stream", _fp), ("second", _fp), ("third", _fp), ("wait_events", C.POINTER(C.c_void_p)), ("num_wait_events", C.c_int32)]
@@ -184,8 +184,8 @@ class tn_train_step_bwd_args(C.Structure):
         ("grads", C.POINTER(tn_field_grads)), ("d_table", _fp), ("d_appearance", _fp), ("d_head0_bias", _fp), ("d_origins", _fp),
         ("d_directions", _fp), ("fused_workspace", _fp), ("fused_workspace_bytes", C.c_size_t), ("first_sorted_level", C.c_int32),
         ("sorted_workspace", _fp), ("sorted_workspace_bytes", C.c_size_t), ("spread", C.c_int32), ("spread_workspace", _fp),
-        ("spread_workspace_bytes", C.c_size_t), ("overlap", C.c_int32), ("defer", C.c_int32), ("stream", _fp), ("second", _fp),
-        ("third", _fp)]
+        ("spread_workspace_bytes", C.c_size_t), ("overlap", C.c_int32), ("defer", C.c_int32), ("wait_second_first", C.c_int32),
+        ("stream", _fp), ("second", _fp), ("third", _fp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/thermonerf_hip.h
@@ -277,7 +277,9 @@ SIGNATURES = {
     "tn_frustum_positions_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "tn_ray_render_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "tn_ray_render_bwd": (C.c_int, [_vp] * 11 + [_i64, _i32, _vp, _vp, _vp, _vp]),
+    "tn_ray_render_depth_fwd": (C.c_int, [_vp] * 6 + [_i64, _i32] + [_vp] * 8),
     "tn_image_losses": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tn_sum_scalars": (C.c_int, [C.POINTER(C.c_void_p), _i32, _vp, _vp]),
     "tn_distortion_loss": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, _vp, _vp, _vp]),
     "tn_distortion_loss_term": (C.c_int, [_vp, _vp, _i64, _i32, C.c_float, C.c_float, _vp, _vp, _vp]),
     "tn_interlevel_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp, _vp]),

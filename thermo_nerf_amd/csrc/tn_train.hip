@@ -1487,6 +1487,118 @@ ray_render_fwd_kernel(const float *__restrict__ deltas, const float *__restrict_
     }
 }
 
+// ray_render_fwd_kernel + the level's depth renderers in the same pass over the ray (round 6): the weights are in registers when the
+// median / expected depths need them, so tn_depth_fwd's three launches (bounds reset, depth_kernel, clip) shrink to the clip.
+// Same operations in the same order as depth_kernel on the stored weights (bit-equal outputs: tests/test_gpu_training.py compares
+// the step calls with the per-call path).  DepthRenderer("expected") clips to the call's [min, max] sample mid-point: every block
+// leaves its rays' bounds in block_bounds[blockIdx] (no atomics, nothing to reset) and ray_depth_clip_kernel reduces them.
+__global__ void __launch_bounds__(kBlock)
+ray_render_depth_fwd_kernel(const float *__restrict__ deltas, const float *__restrict__ dens, const float *__restrict__ rgb_s,
+                            const float *__restrict__ th_s, const float *__restrict__ starts, const float *__restrict__ ends, long long R,
+                            int n, float *__restrict__ weights, float *__restrict__ rgb, float *__restrict__ thermal,
+                            float *__restrict__ acc, float *__restrict__ median, float *__restrict__ expected,
+                            float2 *__restrict__ block_bounds) {
+    __shared__ float red[2][kBlock / 64];
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    float smin = INFINITY, smax = -INFINITY;
+    if (ray < R) {
+        const float *dl = deltas + ray * n, *dn = dens + ray * n, *st = starts + ray * n, *en = ends + ray * n;
+        float carry = 0.0f, sw = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, sth = 0.0f;
+        float wcarry = 0.0f, wsteps = 0.0f;
+        int med_idx = n;  // first index with cumsum(w) >= 0.5 (searchsorted side="left")
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const bool live = i < n;
+            const float a = live ? mul_rn(dl[i], dn[i]) : 0.0f;
+            const float incl = wave_incl_scan(a, lane);
+            const float excl = wave_excl_from_incl(incl, lane) + carry;
+            carry += lane_value<63>(incl);
+            const float w = live ? nan_to_num(mul_rn(sub_rn(1.0f, expf(-a)), expf(-excl))) : 0.0f;
+            const float step = live ? add_rn(st[i], en[i]) / 2.0f : 0.0f;
+            const float wincl = wave_incl_scan(w, lane) + wcarry;
+            const unsigned long long hit = __ballot(live && (wincl >= 0.5f));
+            if (hit && med_idx == n) med_idx = base + __ffsll((long long)hit) - 1;
+            wcarry = lane_value<63>(wincl);
+            wsteps += mul_rn(w, step);
+            if (live) {
+                const long long t = ray * n + i;
+                weights[t] = w;
+                sw += w;
+                s0 += mul_rn(w, rgb_s[t * 3]);
+                s1 += mul_rn(w, rgb_s[t * 3 + 1]);
+                s2 += mul_rn(w, rgb_s[t * 3 + 2]);
+                sth += mul_rn(w, th_s[t]);
+                smin = fminf(smin, step);
+                smax = fmaxf(smax, step);
+            }
+        }
+        sw = wave_sum(sw); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); sth = wave_sum(sth);
+        wsteps = wave_sum(wsteps);
+        if (lane == 0) {
+            const long long last = ray * n + n - 1;
+            const float bg = sub_rn(1.0f, sw);
+            rgb[ray * 3] = add_rn(s0, mul_rn(rgb_s[last * 3], bg));
+            rgb[ray * 3 + 1] = add_rn(s1, mul_rn(rgb_s[last * 3 + 1], bg));
+            rgb[ray * 3 + 2] = add_rn(s2, mul_rn(rgb_s[last * 3 + 2], bg));
+            thermal[ray] = add_rn(sth, mul_rn(th_s[last], bg));
+            acc[ray] = sw;
+            const int idx = min(med_idx, n - 1);
+            median[ray] = add_rn(st[idx], en[idx]) / 2.0f;
+            expected[ray] = wsteps / add_rn(sw, 1e-10f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        smin = fminf(smin, __shfl_xor(smin, o, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0) {
+        red[0][threadIdx.x >> 6] = smin;
+        red[1][threadIdx.x >> 6] = smax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int wv = 1; wv < kBlock / 64; ++wv) {
+            smin = fminf(smin, red[0][wv]);
+            smax = fmaxf(smax, red[1][wv]);
+        }
+        block_bounds[blockIdx.x] = make_float2(smin, smax);
+    }
+}
+
+// expected depth clipped to the call's [min, max] mid-point: every block reduces the (few thousand) per-block bounds itself
+__global__ void __launch_bounds__(kBlock)
+ray_depth_clip_kernel(float *__restrict__ expected, long long R, const float2 *__restrict__ block_bounds, int nblocks) {
+    __shared__ float red[2][kBlock / 64];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+        const float2 v = block_bounds[b];
+        lo = fminf(lo, v.x);
+        hi = fmaxf(hi, v.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = lo;
+        red[1][threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = red[0][0];
+    hi = red[1][0];
+#pragma unroll
+    for (int wv = 1; wv < kBlock / 64; ++wv) {
+        lo = fminf(lo, red[0][wv]);
+        hi = fmaxf(hi, red[1][wv]);
+    }
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r < R && lo <= hi) expected[r] = fminf(fmaxf(expected[r], lo), hi);
+}
+
 __global__ void __launch_bounds__(kBlock)
 ray_render_bwd_kernel(const float *__restrict__ deltas, const float *__restrict__ dens, const float *__restrict__ rgb_s,
                       const float *__restrict__ th_s, const float *__restrict__ acc, const float *__restrict__ g_rgb,
@@ -1905,6 +2017,17 @@ image_losses_kernel(const float *__restrict__ rgb, const float *__restrict__ gt_
         out[1] = b / (float)R;
         out[2] = 10.0f * log10f(1.0f / mse);
     }
+}
+
+// the step's total loss: NS Trainer.train_iteration reduces the loss dictionary with torch.add, left to right — one launch here
+struct ScalarList {
+    const float *p[TN_SUM_MAX_TERMS];
+    int count;
+};
+__global__ void sum_scalars_kernel(ScalarList L, float *__restrict__ out) {
+    float s = L.p[0][0];
+    for (int k = 1; k < L.count; ++k) s = add_rn(s, L.p[k][0]);
+    out[0] = s;
 }
 
 }  // namespace
@@ -2444,6 +2567,20 @@ int tn_interlevel_loss(const float *c, const float *w, const float *cp, const fl
     return tn_interlevel_loss_levels(c, w, num_rays, n, 1, &cp, &wp, &p, scale, loss_sum, &d_wp, stream);
 }
 
+int tn_sum_scalars(const float *const *terms, int32_t count, float *out, void *stream) {
+    if (!terms || !out) return TN_ERR_NULL;
+    if (count < 1 || count > TN_SUM_MAX_TERMS) return TN_ERR_SHAPE;
+    ScalarList L;
+    for (int k = 0; k < count; ++k) {
+        if (!terms[k]) return TN_ERR_NULL;
+        L.p[k] = terms[k];
+    }
+    L.count = count;
+    hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, L, out);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
 int tn_image_losses(const float *rgb, const float *gt_rgb, const float *thermal, const float *gt_thermal, int64_t num_rays,
                     float *out, float *d_rgb, float *d_thermal, void *stream) {
     if (!rgb || !gt_rgb || !out || !d_rgb) return TN_ERR_NULL;
@@ -2462,6 +2599,24 @@ int tn_ray_render_fwd(const float *deltas, const float *densities, const float *
     if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
     hipLaunchKernelGGL(ray_render_fwd_kernel, dim3((unsigned)((num_rays + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, deltas,
                        densities, rgb_samples, thermal_samples, (long long)num_rays, n, weights, rgb, thermal, accumulation);
+    TN_LAUNCH_CHECK();
+    return TN_OK;
+}
+
+int tn_ray_render_depth_fwd(const float *deltas, const float *densities, const float *rgb_samples, const float *thermal_samples,
+                            const float *starts, const float *ends, int64_t num_rays, int32_t n, float *weights, float *rgb,
+                            float *thermal, float *accumulation, float *median, float *expected, float *bounds_scratch, void *stream) {
+    if (num_rays == 0) return TN_OK;
+    if (!deltas || !densities || !rgb_samples || !thermal_samples || !starts || !ends || !weights || !rgb || !thermal || !accumulation ||
+        !median || !expected || !bounds_scratch)
+        return TN_ERR_NULL;
+    if (num_rays < 0 || n < 1) return TN_ERR_SHAPE;
+    const unsigned blocks = (unsigned)((num_rays + 3) / 4);
+    float2 *bounds = reinterpret_cast<float2 *>(bounds_scratch);
+    hipLaunchKernelGGL(ray_render_depth_fwd_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, deltas, densities, rgb_samples,
+                       thermal_samples, starts, ends, (long long)num_rays, n, weights, rgb, thermal, accumulation, median, expected, bounds);
+    hipLaunchKernelGGL(ray_depth_clip_kernel, dim3((unsigned)((num_rays + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       expected, (long long)num_rays, bounds, (int)blocks);
     TN_LAUNCH_CHECK();
     return TN_OK;
 }

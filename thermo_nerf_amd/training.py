@@ -300,7 +300,9 @@ class _GradArena:
     parameter was ~50 fill launches per step).  A fresh arena per backward: the views become the parameters' .grad and must
     not alias the next step's."""
 
-    def __init__(self, like: Dict[str, Tensor], dev, extra: int = 0) -> None:
+    def __init__(self, like: Dict[str, Tensor], dev, extra: int = 0, zero: bool = True) -> None:
+        """``zero=False``: the flat buffer is allocated but not cleared — tn_train_step_fwd clears it on the step's second stream
+        beside the forward (the 75 MB fill leaves the calling stream's critical path)"""
         self.like, self.dev = like, dev
         self.offsets: Dict[str, int] = {}
         total = 0
@@ -308,7 +310,7 @@ class _GradArena:
             self.offsets[name] = total
             total += (p.numel() + 63) // 64 * 64  # 256-byte aligned views
         self._extra = total  # `extra` more zero floats for the step's other zero-initialised buffers (ray gradients, per-ray sums)
-        self.flat = torch.zeros((total + extra,), dtype=torch.float32, device=dev)
+        self.flat = (torch.zeros if zero else torch.empty)((total + extra,), dtype=torch.float32, device=dev)
 
     def zeros(self, shape) -> Tensor:
         """a zero tensor carved from the arena's tail (falls back to a fresh allocation when the tail is used up)"""
@@ -890,7 +892,7 @@ class _StepCall:
         need_ws = lib.tn_render_workspace_bytes(rc, R)
         sizes = [("pos", N * 3), ("starts", N), ("ends", N), ("deltas", N), ("ray_bias", R * 64), ("enc", NP * 32), ("sel", N),
                  ("density", N), ("rgb_s", N * 3), ("th_s", N), ("base_out", N * 16 if keep_base else 0),
-                 ("jac", NP * 96 if keep_jac else 0), ("scratch", 2), ("ws", (need_ws + 3) // 4)]
+                 ("jac", NP * 96 if keep_jac else 0), ("scratch", 2 * ((R + 3) // 4)), ("ws", (need_ws + 3) // 4)]
         so, stotal = {}, 0
         for name, n in sizes:
             so[name] = stotal
@@ -921,6 +923,9 @@ class _StepCall:
         st.rgb, st.thermal, st.accumulation = t["rgb"].data_ptr(), t["thermal"].data_ptr(), t["acc"].data_ptr()
         st.depth, st.expected_depth, st.depth_scratch = t["depth"].data_ptr(), t["expected"].data_ptr(), ptr("scratch")
         st.workspace, st.workspace_bytes = ptr("ws"), need_ws
+        # the backward's gradient arena: allocated now, cleared by the call on the second stream
+        arena = _GradArena(dict(zip(model.named_parameter_lists()[0], params)), dev, extra=R * (64 + 2 * 64 + S) + 1024, zero=False)
+        st.zero_buffer, st.zero_bytes = arena.flat.data_ptr(), arena.flat.numel() * 4
         slot = (dev, _hip.current_stream())
         _drop_precomputed(slot)
         entry = None
@@ -960,7 +965,7 @@ class _StepCall:
 
         ctx.set_materialize_grads(False)
         ctx.model, ctx.o, ctx.d, ctx.cam = model, o, d, cam
-        ctx.step_call = (slab, so, ray_slab, off, R, S, keep_base, keep_jac)
+        ctx.step_call = (slab, so, ray_slab, off, R, S, keep_base, keep_jac, arena)
         ctx.updated, ctx.tape_free = False, True
         ctx.tapes = ctx.field_tape = ctx.acts = ctx.acc = None
         ctx.param_names = model.named_parameter_lists()[0]
@@ -976,13 +981,11 @@ class _StepCall:
         lib = _hip.load()
         model = ctx.model
         cfg = model.config
-        slab, so, ray_slab, off, R, S, keep_base, keep_jac = ctx.step_call
+        slab, so, ray_slab, off, R, S, keep_base, keep_jac, arena = ctx.step_call
         dev = slab.device
         N = R * S
         _drop_precomputed((dev, _hip.current_stream()))
         fld = model.field.train_struct()
-        like = ctx.params
-        arena = _GradArena(like, dev, extra=R * (64 + 2 * 64 + S) + 1024)
         ray_grads = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             ray_grads = (arena.zeros(tuple(ctx.o.shape)), arena.zeros(tuple(ctx.d.shape)))
@@ -1078,6 +1081,7 @@ class _StepCall:
                     sws = _SPREAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
                 a.spread_workspace, a.spread_workspace_bytes = sws.data_ptr(), need
         a.overlap, a.defer = (1 if overlap else 0), (1 if defer else 0)
+        a.wait_second_first = 1  # the arena was cleared on the second stream (tn_train_step_fwd)
         a.stream, a.second, a.third = main.cuda_stream, second.cuda_stream, third.cuda_stream
         _hip.check(lib.tn_train_step_bwd(C.byref(a)), "tn_train_step_bwd")
         if defer:  # both halves of the scatter are still out: whoever reads the table (or its gradient) joins (_hip.join_pending)
@@ -1226,6 +1230,12 @@ class _TotalLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *terms: Tensor):
         ctx.n = len(terms)
+        if len(terms) <= 16 and all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms):
+            # ((t0 + t1) + t2) + ... as torch.add would form it, in one launch (tn_sum_scalars) instead of a stack and a reduction
+            out = _f32((), terms[0].device)
+            ptrs = (C.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+            _hip.check(_hip.load().tn_sum_scalars(ptrs, len(terms), out.data_ptr(), _stream()), "tn_sum_scalars")
+            return out
         return torch.stack([t.reshape(()) for t in terms]).sum()
 
     @staticmethod
