@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_PATHS = ["thermo_nerf_amd/csrc", "include"]
-ROUND = "round5"
+ROUND = "round6"
 
 
 def _git(*args):

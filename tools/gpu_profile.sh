@@ -2,8 +2,9 @@
 # Kernel trace + three separate PMC passes of the bench frame, summarised ON the GPU box (the raw rocprofv3 databases exceed what
 # gpurun copies back).  From the build container, on a COMMITTED tree:
 #   git rev-parse HEAD > tools/.head_stamp && gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh round2 192 f32'
-# Writes gpurun_out/<tag>_kernel_trace_S<S>_<prec>.txt and gpurun_out/<tag>_pmc_S<S>_<prec>.txt (+ updates profiles/pmc_traffic.json
-# in the box's copy, echoed at the end: paste it back).  Every rocprofv3 call is wrapped in `timeout`, and --pmc is only ever
+# Writes gpurun_out/<tag>_kernel_trace_S<S>_<prec>.txt, gpurun_out/<tag>_pmc_S<S>_<prec>.txt and gpurun_out/pmc_traffic.json (pmc_summary.py
+# writes the traffic entries NEXT TO the summary; tools/install_profiles.sh merges them into profiles/pmc_traffic.json — do not copy
+# profiles/pmc_traffic.json over it).  Every rocprofv3 call is wrapped in `timeout`, and --pmc is only ever
 # combined with --kernel-trace.
 tag=${1:-prof}
 S=${2:-192}

@@ -22,11 +22,14 @@ from collections import defaultdict
 
 # phase -> kernel-name patterns, in priority order (an instant covered by kernels of two phases goes to the earlier one)
 PHASES = [
+    # (round 6: with the table update deferred, the NEXT step's preparation — field_prepare, ray_head_fwd, level geometry, the
+    # proposal pass — runs on the calling stream beside this step's scatter; those kernels rank below the scatter so that the
+    # scatter's critical path is the time until its last kernel ends, whatever runs beside it)
     ("field_backward", r"field_bwd_fused_kernel|field_bwd_reduce_kernel|ray_render_bwd_kernel|linear_chain_bwd|linear_bwd_reduce|density_act_bwd"),
-    ("field_forward", r"field_fwd_taped_kernel|ray_head_fwd_kernel|frustum_from_edges_kernel|field_prepare_kernel"),
+    ("field_forward", r"field_fwd_taped_kernel"),
     ("table_scatter", r"hash_encode_bwd_kernel|spread_reduce_kernel|sort_emit_kernel|sort_owner_kernel|sort_count|fillBufferAligned"),
-    ("proposal_pass", r"proposal_kernel|prop_weights_kmajor_kernel|density_fwd_train|density_bwd_train|weights_bwd|sample_pdf|sample_initial|weights_fwd_kernel"),
-    ("optimizer_and_pose", r"multi_tensor_apply_kernel|camera_opt_"),
+    ("optimizer_and_pose", r"adam_kernel|multi_tensor_apply_kernel|camera_opt_"),
+    ("proposal_pass", r"proposal_kernel|prop_weights_kmajor_kernel|density_fwd_train|density_bwd_train|weights_bwd|sample_pdf|sample_initial|weights_fwd_kernel|ray_head_fwd_kernel|frustum_from_edges_kernel|field_prepare_kernel"),
     ("ray_level_adjoints", r"ray_head_bwd_kernel|frustum_positions_bwd_kernel|color_input_bwd"),
     ("renderers_losses_glue", r".*"),
 ]
