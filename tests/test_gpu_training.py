@@ -432,6 +432,31 @@ def test_training_step_matches_autograd_oracle(kind, S, variant):
     assert checked >= (13 if variant == "same_proposal_network" else 18)
 
 
+def test_transient_embedding_flag_leaves_the_step_unchanged():
+    """use_transient_embedding=True [REF thermal_nerf_model.py:111]: the reference's model never reads the transient heads (G10,
+    tests/golden/transient_embedding.json) — eval outputs, training outputs, losses and every gradient equal the flag-off model's on
+    the same weights; the transient parameters receive no gradient (as in the reference)."""
+    res = {}
+    for flag in (False, True):
+        gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("scene", 48, use_transient_embedding=flag)
+        out, loss_dict = _gpu_step(gm, o, d, jit, cam, batch)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in gm.named_parameters() if p.grad is not None}
+        assert not any("transient" in n for n in grads)
+        gm.eval()
+        with torch.no_grad():
+            ev = gm(RayBundle(origins=o.to(DEV), directions=d.to(DEV), camera_indices=cam.to(DEV)))
+        res[flag] = (out, loss_dict, grads, ev)
+    (o0, l0, g0, e0), (o1, l1, g1, e1) = res[False], res[True]
+    for k in ("rgb", "thermal", "accumulation", "depth", "expected_depth"):
+        assert torch.equal(o0[k], o1[k]) and torch.equal(e0[k], e1[k]), k
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert rel(g1[n], g0[n]) <= 2e-5, n
+    for k in l0:
+        assert abs(float(l0[k]) - float(l1[k])) <= 1e-6 * abs(float(l0[k])), k
+
+
 @pytest.mark.parametrize("widths", [(32, 16, 48), (16, 64, 8)])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 def test_training_step_with_other_mlp_widths(kind, widths):

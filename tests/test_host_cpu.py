@@ -109,6 +109,29 @@ def test_predict_normals_ends_where_the_reference_ends(golden_dir):
     model.eval()
 
 
+def test_transient_embedding_flag_builds_the_references_modules_and_changes_nothing(golden_dir):
+    """G10 (tests/golden/transient_embedding.json, tools/make_golden_g9.py: the reference executed with use_transient_embedding on
+    and off on the same weights): its field returns two more entries in training, its model reads neither — model outputs are
+    identical.  The product builds nerfstudio's transient modules (state-dict names) and leaves the hot path as it is."""
+    import json
+
+    gold = json.load(open(os.path.join(golden_dir, "transient_embedding.json")))
+    assert gold["model_outputs_identical_with_and_without_the_flag"] is True
+    assert gold["field_output_keys"]["flag_1_train"][:2] == ["TRANSIENT_RGB", "TRANSIENT_DENSITY"]
+    assert gold["field_output_keys"]["flag_1_eval"] == gold["field_output_keys"]["flag_0_eval"] == ["RGB", "THERMAL", "DENSITY"]
+    assert "transient_rgb" not in gold["model_output_keys"]
+    on, sd_on, _ = helpers.build("init", 8, use_transient_embedding=True)
+    off, sd_off, _ = helpers.build("init", 8)
+    extra = sorted(set(sd_on) - set(sd_off))
+    assert extra == ["field.embedding_transient.embedding.weight", "field.field_head_transient_density.net.bias",
+                     "field.field_head_transient_density.net.weight", "field.field_head_transient_rgb.net.bias",
+                     "field.field_head_transient_rgb.net.weight", "field.field_head_transient_uncertainty.net.bias",
+                     "field.field_head_transient_uncertainty.net.weight", "field.mlp_transient.layers.0.bias",
+                     "field.mlp_transient.layers.0.weight", "field.mlp_transient.layers.1.bias", "field.mlp_transient.layers.1.weight"]
+    assert sd_on["field.embedding_transient.embedding.weight"].shape == (8, 16) and sd_on["field.mlp_transient.layers.0.weight"].shape == (64, 31)
+    assert not on.field.staged and on._fusable()  # the fused hot path is untouched
+
+
 def test_packed_samples_rejected_like_reference():
     r = tna.ThermalRenderer()
     with pytest.raises(NotImplementedError):

@@ -50,9 +50,9 @@ class ThermalNerfactoTField(nn.Module):
         sh_input: Literal["shifted", "unit"] = "shifted",
     ) -> None:
         super().__init__()
-        if use_transient_embedding or use_semantics:
-            # REF thermal_nerf_model.py:50-56,106-112 never enables these on the thermal-nerf path
-            raise NotImplementedError("transient / semantics heads are off on the ThermoNeRF path")
+        if use_semantics:
+            # REF thermal_nerf_model.py:96-114 never passes it (NerfactoField's default False)
+            raise NotImplementedError("the semantics head is off on the ThermoNeRF path")
         if (num_layers, num_layers_color, num_layers_transient) != (2, 3, 2):
             raise NotImplementedError("kernels implement mlp_base 2, mlp_head 3, mlp_thermal 2 layers (the defaults)")
         widths = (int(hidden_dim), int(hidden_dim_color), int(hidden_dim_transient))
@@ -88,6 +88,22 @@ class ThermalNerfactoTField(nn.Module):
         # REF thermal_field.py:90-98: 15 -> 64 -> 64, ReLU, Sigmoid
         self.mlp_thermal = MLP(self.geo_feat_dim, 2, 64, hidden_dim_transient)
         self.field_head_thermal = ThermalFieldHead(in_dim=self.mlp_thermal.get_out_dim())  # REF :100-102
+        self.transient_embedding_dim = transient_embedding_dim
+        if use_transient_embedding:
+            # config.use_transient_embedding=True [REF thermal_nerf_model.py:111]: NS NerfactoField builds the transient branch —
+            # Embedding(num_images, 16), MLP(15 + 16 -> hidden_dim_transient, 2 layers), uncertainty / rgb / density heads
+            # [NS-recall] — and the reference's field evaluates it in training [REF thermal_field.py:139-158], but the reference's
+            # MODEL reads neither TRANSIENT_RGB nor TRANSIENT_DENSITY [REF thermal_nerf_model.py:210-275]: recorded by executing it
+            # (G10, tests/golden/transient_embedding.json: model outputs identical with the flag on and off).  So the parameters
+            # exist (module tree / state-dict names are the reference's; they never receive a gradient there either) and the
+            # branch's two unread dictionary entries are not evaluated.
+            self.embedding_transient = Embedding(self.num_images, transient_embedding_dim)
+            self.mlp_transient = MLP(self.geo_feat_dim + transient_embedding_dim, num_layers_transient, hidden_dim_transient,
+                                     hidden_dim_transient)
+            for name, width in (("uncertainty", 1), ("rgb", 3), ("density", 1)):
+                head = nn.Module()
+                head.net = nn.Linear(self.mlp_transient.get_out_dim(), width)
+                setattr(self, "field_head_transient_" + name, head)
         if use_pred_normals:
             # config.predict_normals=True [REF thermal_nerf_model.py:108]: NS NerfactoField builds the predicted-normals head —
             # NeRFEncoding(3, 2 frequencies) -> MLP(15 + 12, 3 layers of 64, out hidden_dim_transient) -> PredNormalsFieldHead

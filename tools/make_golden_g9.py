@@ -180,6 +180,64 @@ def main() -> None:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc, indent=1))
 
+    # ---- G10: use_transient_embedding=True [REF thermal_nerf_model.py:111; thermal_field.py:139-158] ----------------------------------
+    # The reference's field evaluates nerfstudio's transient branch in TRAINING (embedding_transient[camera] ++ geo -> mlp_transient ->
+    # two heads) and returns TRANSIENT_RGB / TRANSIENT_DENSITY; the reference's MODEL never reads either key.  Executed here: the real
+    # field's output keys with the flag on (train / eval), and the real model's get_outputs on the SAME weights with the flag on and
+    # off — identical keys, identical values: the flag adds parameters and wasted work, nothing else.
+    MLP = sys.modules["nerfstudio.field_components.mlp"].MLP
+    host.train()
+    host.config.predict_normals = False
+    host.camera_optimizer = types.SimpleNamespace(apply_to_raybundle=lambda rb: None)
+    runs = {}
+    keys = {}
+    for flag in (False, True):
+        torch.manual_seed(3)
+        fld = tf.ThermalNerfactoTField(aabb, hidden_dim=64, num_levels=4, max_res=64, base_res=16, features_per_level=2,
+                                       log2_hashmap_size=8, hidden_dim_color=64, hidden_dim_transient=64,
+                                       spatial_distortion=torch.nn.Identity(), num_images=3, use_pred_normals=False,
+                                       use_average_appearance_embedding=True, appearance_embedding_dim=32, implementation="torch",
+                                       use_transient_embedding=flag, pass_thermal_gradients=True)
+        if flag:  # what NS NerfactoField builds for the flag [NS-recall]; the G6 stand-in base does not
+            torch.manual_seed(4)
+            fld.transient_embedding_dim = 16
+            fld.embedding_transient = torch.nn.Embedding(3, 16)
+            fld.mlp_transient = MLP(15 + 16, 2, 64, 64, activation=torch.nn.ReLU())
+            fld.field_head_transient_rgb = torch.nn.Sequential(torch.nn.Linear(64, 3), torch.nn.Sigmoid())
+            fld.field_head_transient_density = torch.nn.Sequential(torch.nn.Linear(64, 1), torch.nn.Softplus())
+        fld._g9_shape = (R, S)
+        for mode in ("train", "eval"):
+            fld.train(mode == "train")
+            with torch.no_grad():
+                o = fld.forward(RS, compute_normals=False)
+            keys["flag_%s_%s" % (int(flag), mode)] = [getattr(k, "name", str(k)) for k in o.keys()]
+        fld.train(True)
+        host.field = fld
+        calls = {}
+
+        def rend(name):
+            def call(*a, **k):
+                t = [x for x in list(a) + list(k.values()) if isinstance(x, torch.Tensor)]
+                calls[name] = float(sum(x.double().sum() for x in t))
+                return torch.full((R, 3 if name == "renderer_rgb" else 1), calls[name] % 1.0)
+            return call
+
+        for name in ("renderer_rgb", "renderer_depth", "renderer_expected_depth", "renderer_accumulation"):
+            setattr(host, name, rend(name))
+        host.thermal_renderer.train(True)
+        with torch.no_grad():
+            out_m = ref.ThermalNerfModel.get_outputs(host, types.SimpleNamespace())
+        runs[flag] = (list(out_m.keys()), {k: v.double().sum().item() for k, v in out_m.items() if isinstance(v, torch.Tensor)}, dict(calls))
+    same_keys = runs[False][0] == runs[True][0]
+    same_vals = all(abs(runs[False][1][k] - runs[True][1][k]) <= 1e-12 for k in runs[False][1]) and runs[False][2] == runs[True][2]
+    doc2 = {"what": "use_transient_embedding=True in the reference, executed from /root/reference (G10)",
+            "field_output_keys": keys, "model_output_keys": runs[True][0], "model_outputs_identical_with_and_without_the_flag": bool(same_keys and same_vals),
+            "reference_lines": "thermal_field.py:139-158 (transient branch, training only); thermal_nerf_model.py:210-275 reads neither "
+                               "TRANSIENT_RGB nor TRANSIENT_DENSITY"}
+    with open(os.path.join(G.OUT, "transient_embedding.json"), "w") as f:
+        json.dump(doc2, f, indent=1)
+    print(json.dumps(doc2, indent=1))
+
 
 if __name__ == "__main__":
     main()
