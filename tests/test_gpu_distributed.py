@@ -122,6 +122,12 @@ def test_sharded_frame_world_size_1_on_rccl():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         model, _, _ = _model()
+        # the load-time weight broadcast on the real backend (RCCL takes device tensors of every dtype the model holds: fp32
+        # parameters, the int64 / fp32 buffers): 78 MB, parameters unchanged at world size 1
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        moved = D.broadcast_model_(model, src=0)
+        torch.cuda.synchronize()
+        assert 70e6 < moved < 90e6 and all(torch.equal(v, before[k]) for k, v in model.state_dict().items())
         o3, d3 = _frame_rays(3)
         eng = RayRenderEngine(model, chunk=CHUNK)
         want = eng.render(o3.reshape(-1, 3).contiguous(), d3.reshape(-1, 3).contiguous())
