@@ -19,6 +19,7 @@ No CPU path: parameters must live on a ROCm device.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Iterable, List, Optional
 
@@ -34,8 +35,18 @@ class HipAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._deferred = {id(p) for p in (deferred or ())}
+        self._lists: dict = {}  # cached ctypes descriptor arrays
+        self._fixed: dict = {}  # (array id, position) -> the step-invariant fields written there
 
-    def _descriptor(self, group, p: torch.nn.Parameter) -> _hip.tn_adam_tensor:
+    def __setstate__(self, state) -> None:  # (torch's Optimizer pickles defaults / state / param_groups only)
+        super().__setstate__(state)
+        self.__dict__.setdefault("_deferred", set())
+        self._lists, self._fixed = {}, {}
+
+    def _slot(self, group, p: torch.nn.Parameter, arr, k: int) -> None:
+        """fill descriptor ``k`` of the launch list ``arr`` for this step.  The fields that do not change from step to step (parameter
+        and moment addresses, size, betas, eps, weight decay) are written once per (list, position): the arrays are cached per
+        optimizer and reused while the same parameters receive gradients — a step then sets three fields per tensor"""
         g = p.grad
         if g.is_sparse:
             raise RuntimeError("HipAdam does not support sparse gradients")
@@ -53,23 +64,33 @@ class HipAdam(torch.optim.Optimizer):
         st["step"] += 1.0
         t = st["step"]
         b1, b2 = group["betas"]
-        d = _hip.tn_adam_tensor()
-        d.param, d.grad = p.data_ptr(), g.data_ptr()
-        d.exp_avg, d.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-        d.n = p.numel()
+        d = arr[k]
+        key = (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), b1, b2, group["eps"], group["weight_decay"])
+        fixed = self._fixed.get((id(arr), k))
+        if fixed != key:
+            d.param, d.exp_avg, d.exp_avg_sq = key[0], key[1], key[2]
+            d.n = p.numel()
+            d.one_minus_beta1, d.beta2, d.one_minus_beta2 = 1.0 - b1, b2, 1.0 - b2
+            d.eps, d.weight_decay = group["eps"], group["weight_decay"]
+            self._fixed[(id(arr), k)] = key
+        d.grad = g.data_ptr()
         d.step_size = group["lr"] / (1.0 - b1 ** t)
         d.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** t)
-        d.one_minus_beta1, d.beta2, d.one_minus_beta2 = 1.0 - b1, b2, 1.0 - b2
-        d.eps, d.weight_decay = group["eps"], group["weight_decay"]
-        return d
+
+    def _list(self, n: int, tag):
+        """a cached descriptor array of n entries (one per distinct (tag, n): the small tensors of a step, each deferred tensor)"""
+        hit = self._lists.get((tag, n))
+        if hit is None:
+            hit = self._lists[(tag, n)] = (_hip.tn_adam_tensor * n)()
+        return hit
 
     @staticmethod
-    def _launch(descs: List[_hip.tn_adam_tensor], stream: int) -> None:
+    def _launch(arr, count: int, stream: int) -> None:
         lib = _hip.load()
-        for k in range(0, len(descs), _hip.ADAM_MAX_TENSORS):
-            part = descs[k:k + _hip.ADAM_MAX_TENSORS]
-            arr = (_hip.tn_adam_tensor * len(part))(*part)
-            _hip.check(lib.tn_adam_step(arr, len(part), stream), "tn_adam_step")
+        for k in range(0, count, _hip.ADAM_MAX_TENSORS):
+            n = min(_hip.ADAM_MAX_TENSORS, count - k)
+            part = C.cast(C.byref(arr, k * C.sizeof(_hip.tn_adam_tensor)), C.POINTER(_hip.tn_adam_tensor))
+            _hip.check(lib.tn_adam_step(part, n, stream), "tn_adam_step")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -77,21 +98,22 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        small: List[_hip.tn_adam_tensor] = []
+        small = [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None and id(p) not in self._deferred]
+        if small:
+            # (the list is keyed by WHICH parameters have gradients this step: frozen-proposal and update steps alternate)
+            arr = self._list(len(small), tuple(id(p) for _, p in small))
+            for k, (group, p) in enumerate(small):
+                self._slot(group, p, arr, k)
+            self._launch(arr, len(small), _hip.current_stream())
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None:
-                    continue
-                d = self._descriptor(group, p)
-                if id(p) in self._deferred:
-                    self._step_deferred(p, d)
-                else:
-                    small.append(d)
-        if small:
-            self._launch(small, _hip.current_stream())
+                if p.grad is not None and id(p) in self._deferred:
+                    arr = self._list(1, ("deferred", id(p)))
+                    self._slot(group, p, arr, 0)
+                    self._step_deferred(p, arr)
         return loss
 
-    def _step_deferred(self, p: torch.nn.Parameter, d: _hip.tn_adam_tensor) -> None:
+    def _step_deferred(self, p: torch.nn.Parameter, arr) -> None:
         """the table's launch on the step's second stream: behind the bucketed half of its gradient's scatter (queued there) and the
         atomic half (third stream: waited for), or — scatter already joined — behind the calling stream's work so far"""
         from .training import _step_streams
@@ -104,7 +126,7 @@ class HipAdam(torch.optim.Optimizer):
             for s in pend["streams"]:
                 if s.cuda_stream != second.cuda_stream:
                     second.wait_stream(s)
-        self._launch([d], second.cuda_stream)
+        self._launch(arr, 1, second.cuda_stream)
         st = self.state[p]
         _hip.defer(p.device, [second], [p.grad, st["exp_avg"], st["exp_avg_sq"]])
 
