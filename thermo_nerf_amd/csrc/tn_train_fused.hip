@@ -621,9 +621,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
 
         // =================================== mlp_base ===================================================================
         float2 jv[12];  // (BASE, pose gradient from the forward's Jacobian) levels 2 sl, 2 sl + 1, 8 + 2 sl, 9 + 2 sl x 3 axes of sample n
+        float pos_x = 0.0f, pos_y = 0.0f, pos_z = 0.0f;
         if (BASE) {
             // the next tile's inputs: in flight during this section
             if (tile + stride < tiles) tile_load<MODE>(nxt, a, tile + stride, n, sl);
+            if (a.d_pos) {  // the sample's position: requested here, a hundred MFMAs before position_grad_finish reads it
+                const long long ic = live ? i0 + n : a.N - 1;
+                pos_x = a.positions[ic * 3]; pos_y = a.positions[ic * 3 + 1]; pos_z = a.positions[ic * 3 + 2];
+            }
             if (a.d_pos && a.jac) {
                 const long long ic = live ? i0 + n : a.N - 1;
                 const float2 *jt = reinterpret_cast<const float2 *>(a.jac) + (ic >> 6) * (16 * 3 * 64) + (ic & 63);
@@ -667,8 +672,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) field_bwd_fused_kernel(
                 // weight-gradient MFMAs below, summed over the sample's four lanes.  (As a kernel of its own — one lane per
                 // (sample, level), tn_hash_encode_bwd_input — this was 310 us of pure gather time per step at S=192.)
                 const Space sp = make_space(a.space);
-                const long long ic = live ? i0 + n : a.N - 1;
-                const float x = a.positions[ic * 3], y = a.positions[ic * 3 + 1], z = a.positions[ic * 3 + 2];
+                const float x = pos_x, y = pos_y, z = pos_z;
                 float px, py, pz;
                 const float selp = normalize_position(sp, x, y, z, px, py, pz);
                 float gx = 0.0f, gy = 0.0f, gz = 0.0f;
