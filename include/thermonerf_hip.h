@@ -420,7 +420,10 @@ int tn_frustum_positions_bwd(const float *d_positions, const float *starts, cons
                              float *d_origins, float *d_directions, void *stream);
 
 /* torch.nn.Linear (+ activation): y[n, :out] = act(x[n, :in] W^T + b); x rows are ldx floats apart, y rows ldy.
- * in_dim, out_dim <= 64. */
+ * in_dim, out_dim <= 256 (TN_ERR_SHAPE beyond).  Layers up to 64 wide — the reference's configs — keep a row's inputs in
+ * registers; wider ones (config.hidden_dim / hidden_dim_color / hidden_dim_transient [REF thermal_nerf_model.py:96-114] above 64)
+ * stage 64-row tiles of x in LDS, and their backward runs the 64-wide kernel once per 64 x 64 block of the weight matrix (it
+ * needs the workspace: TN_ERR_WORKSPACE without one when weight gradients are asked for). */
 int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act, int64_t n, float *y, int32_t ldy,
                   void *stream);
 /* backward: g = dy * act'(y) (y = the forward OUTPUT, rows ldy apart like dy);  dx[n,:in] (= or += when

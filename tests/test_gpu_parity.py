@@ -452,12 +452,13 @@ def test_get_outputs_eval(kind, S, impl):
     check_outputs(got, want, f"{kind}/S{S}/fused={fused}")
 
 
-@pytest.mark.parametrize("widths", [(32, 16, 48), (16, 64, 8), (64, 64, 24), (48, 32, 64)])
+@pytest.mark.parametrize("widths", [(32, 16, 48), (16, 64, 8), (64, 64, 24), (48, 32, 64), (128, 128, 128), (100, 130, 66), (256, 72, 200)])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 def test_other_mlp_widths_run_stage_by_stage(kind, widths):
     """hidden_dim / hidden_dim_color / hidden_dim_transient [REF thermal_nerf_model.py:96-114 forwards them to the field; 64 in every
     reference config] other than 64 (VERDICT r5 missing #4): the fused kernels are laid out for 64-wide layers, so such a field
-    runs the same arithmetic one launch per nerfstudio module / layer (field.staged; up to 64 — wider raises).  Eval outputs, the
+    runs the same arithmetic one launch per nerfstudio module / layer (field.staged; up to 256 — wider raises; layers above 64 take
+    tn_linear_fwd's LDS-tiled form, widths that are no multiple of 4 its scalar stores).  Eval outputs, the
     field's plugin surface (get_density / get_outputs) and the chunked camera render against the oracle, same tolerances."""
     from thermo_nerf_amd.engine import RayRenderEngine
 
@@ -477,8 +478,8 @@ def test_other_mlp_widths_run_stage_by_stage(kind, widths):
     assert (whole["rgb"].reshape(-1, 3) - got["rgb"]).abs().max().item() <= 1e-6
     with pytest.raises(RuntimeError, match="staged"):
         RayRenderEngine(gm)
-    with pytest.raises(NotImplementedError, match="up to 64"):
-        helpers.build(kind, 48, hidden_dim=128)
+    with pytest.raises(NotImplementedError, match="up to 256"):
+        helpers.build(kind, 48, hidden_dim=512)
 
 
 @pytest.mark.parametrize("kind", ["stress", "scene"])

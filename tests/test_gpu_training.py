@@ -37,7 +37,10 @@ def lin_struct(w: torch.Tensor, b: torch.Tensor) -> _hip.tn_linear:
 # --------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("IN,OUT,ldx,off,act", [
     (32, 64, 32, 0, 1), (64, 16, 64, 0, 0), (63, 64, 64, 0, 1), (15, 64, 16, 1, 1), (64, 64, 64, 0, 2),
-    (64, 3, 64, 0, 2), (64, 1, 64, 0, 0), (10, 16, 10, 0, 1), (16, 1, 16, 0, 0)])
+    (64, 3, 64, 0, 2), (64, 1, 64, 0, 0), (10, 16, 10, 0, 1), (16, 1, 16, 0, 0),
+    # layers wider than 64 (hidden_dim* up to 256): the LDS-tiled forward, the backward one 64 x 64 weight block at a time
+    (32, 128, 32, 0, 1), (128, 128, 128, 0, 1), (128, 16, 128, 0, 0), (63, 130, 64, 0, 1), (130, 130, 132, 2, 2), (130, 3, 130, 0, 2),
+    (256, 256, 256, 0, 1), (200, 1, 200, 0, 0), (15, 100, 16, 1, 1), (100, 66, 100, 0, 2)])
 @pytest.mark.parametrize("n", [1000, 64, 1])
 def test_linear_fwd_bwd(IN, OUT, ldx, off, act, n):
     g = torch.Generator().manual_seed(IN * 100 + OUT + n)
@@ -461,11 +464,12 @@ def test_transient_embedding_flag_leaves_the_step_unchanged():
         assert abs(float(l0[k].detach()) - float(l1[k].detach())) <= 1e-6 * abs(float(l0[k].detach())), k
 
 
-@pytest.mark.parametrize("widths", [(32, 16, 48), (16, 64, 8)])
+@pytest.mark.parametrize("widths", [(32, 16, 48), (16, 64, 8), (128, 128, 128), (100, 130, 66), (256, 72, 200)])
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 def test_training_step_with_other_mlp_widths(kind, widths):
     """hidden_dim / hidden_dim_color / hidden_dim_transient other than 64 (field.staged): the training step takes the stage-by-stage
-    forward and one tn_linear_bwd per layer; outputs, losses and every parameter gradient against torch autograd over the oracle."""
+    forward and one tn_linear_bwd per layer (a layer above 64 wide: one pass of the 64-wide kernel per 64 x 64 block of its weight
+    matrix); outputs, losses and every parameter gradient against torch autograd over the oracle."""
     hd, hc, ht = widths
     gm, sd, ocfg, o, d, jit, cam, batch = _train_setup(kind, 48, hidden_dim=hd, hidden_dim_color=hc, hidden_dim_transient=ht)
     assert gm.field.staged

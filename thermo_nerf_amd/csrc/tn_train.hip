@@ -697,14 +697,16 @@ __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2
 
 __global__ void __launch_bounds__(kBlock)
 linear_bwd_mfma_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ y, const float *__restrict__ dy, int ldy,
-                       const float *__restrict__ W, int IN, int OUT, int act, long long n, float *__restrict__ dx, int lddx,
-                       int accumulate_dx, int want_w, float *__restrict__ partials, int vec, int vec_dx) {
+                       const float *__restrict__ W, int ldw, int IN, int OUT, int act, long long n, float *__restrict__ dx,
+                       int lddx, int accumulate_dx, int want_w, float *__restrict__ partials, int vec, int vec_dx) {
+    // (W: the [OUT][IN] block of a weight matrix whose rows are ldw floats apart — the whole matrix, ldw = IN, for layers up to 64
+    // wide; one 64 x 64 block of a wider layer otherwise, see tn_linear_bwd)
     __shared__ float Ws[64 * LDP];  // [o][i], zero padded to 64 x 64
     __shared__ float gs[TILE * LDP];  // [row][o]
     __shared__ float xs[TILE * LDP];  // [row][i]; reused as dx staging [row][i]
     for (int e = threadIdx.x; e < 64 * 64; e += kBlock) {
         const int o = e >> 6, i = e & 63;
-        Ws[o * LDP + i] = (o < OUT && i < IN) ? W[o * IN + i] : 0.0f;
+        Ws[o * LDP + i] = (o < OUT && i < IN) ? W[o * ldw + i] : 0.0f;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
     const int n_it = (IN + 31) >> 5, n_ot = (OUT + 31) >> 5;
@@ -1054,12 +1056,59 @@ __global__ void __launch_bounds__(kBlock, 2) linear_chain_bwd_kernel(ChainArgs a
     }
 }
 
+// Layers wider than 64 (config.hidden_dim / hidden_dim_color / hidden_dim_transient up to kLinWide, stage-by-stage fields only):
+// a block owns tiles of 64 rows, the x tile in LDS [64][IN | 1]; lane = row, a wave walks the outputs four at a time (its weight
+// rows are wave-uniform: scalar loads).  Same order of additions as the narrow kernel: bias first, inputs ascending.
+constexpr int kLinWide = 256;
+__global__ void __launch_bounds__(kBlock)
+linear_fwd_wide_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ W, const float *__restrict__ b, int IN,
+                       int OUT, int act, long long n, float *__restrict__ y, int ldy, int vec_out) {
+    extern __shared__ __attribute__((aligned(16))) float xs_wide[];
+    const int LDK = IN | 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long tiles = (n + TILE - 1) / TILE;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const long long base = tile * TILE;
+        __syncthreads();
+        for (int e = threadIdx.x; e < TILE * IN; e += kBlock) {
+            const int r = e / IN, c = e - r * IN;
+            xs_wide[r * LDK + c] = base + r < n ? x[(size_t)(base + r) * ldx + c] : 0.0f;
+        }
+        __syncthreads();
+        const float *xr = xs_wide + lane * LDK;
+        const bool live = base + lane < n;
+        float *yp = y + (size_t)(base + lane) * ldy;
+        for (int o0 = 4 * wave; o0 < OUT; o0 += 4 * (kBlock / 64)) {
+            const int oa = o0, ob = min(o0 + 1, OUT - 1), oc = min(o0 + 2, OUT - 1), od = min(o0 + 3, OUT - 1);
+            const float *wa = W + (size_t)oa * IN, *wb = W + (size_t)ob * IN, *wc = W + (size_t)oc * IN, *wd = W + (size_t)od * IN;
+            float a0 = b ? b[oa] : 0.0f, a1 = b ? b[ob] : 0.0f, a2 = b ? b[oc] : 0.0f, a3 = b ? b[od] : 0.0f;
+#pragma unroll 8
+            for (int i = 0; i < IN; ++i) {
+                const float xv = xr[i];
+                a0 = fmaf(xv, wa[i], a0);
+                a1 = fmaf(xv, wb[i], a1);
+                a2 = fmaf(xv, wc[i], a2);
+                a3 = fmaf(xv, wd[i], a3);
+            }
+            if (!live) continue;
+            if (vec_out) {
+                *reinterpret_cast<float4 *>(yp + o0) = make_float4(act_fwd(a0, act), act_fwd(a1, act), act_fwd(a2, act), act_fwd(a3, act));
+            } else {
+                yp[o0] = act_fwd(a0, act);
+                if (o0 + 1 < OUT) yp[o0 + 1] = act_fwd(a1, act);
+                if (o0 + 2 < OUT) yp[o0 + 2] = act_fwd(a2, act);
+                if (o0 + 3 < OUT) yp[o0 + 3] = act_fwd(a3, act);
+            }
+        }
+    }
+}
+
 // dW[o][i] += sum_b partials[b][i][o];  db[o] += sum_b partials[b][INP][o].  grid (INP + 1 rows, kRedSplit slices of
-// the block range); 256 threads = 64 outputs x 4 interleaved block streams; one atomic per (entry, slice).
+// the block range); 256 threads = 64 outputs x 4 interleaved block streams; one atomic per (entry, slice).  dW rows ldw apart.
 constexpr int kRedSplit = 8;
 __global__ void __launch_bounds__(kBlock)
 linear_bwd_reduce_kernel(const float *__restrict__ partials, int blocks, int INP, int IN, int OUT, float *__restrict__ dW,
-                         float *__restrict__ db) {
+                         int ldw, float *__restrict__ db) {
     __shared__ float red[kBlock];
     const int i = blockIdx.x, o = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int per = (blocks + kRedSplit - 1) / kRedSplit;
@@ -1080,7 +1129,7 @@ linear_bwd_reduce_kernel(const float *__restrict__ partials, int blocks, int INP
         if (i == INP) {
             if (db) atomic_add_f32(db + o, tot);
         } else if (i < IN && dW) {
-            atomic_add_f32(dW + o * IN + i, tot);
+            atomic_add_f32(dW + o * ldw + i, tot);
         }
     }
 }
@@ -2231,11 +2280,20 @@ int tn_linear_fwd(const float *x, int32_t ldx, const tn_linear *lin, int32_t act
                   void *stream) {
     if (!lin || !lin->weight) return TN_ERR_NULL;
     const int IN = lin->in_dim, OUT = lin->out_dim;
-    if (IN < 1 || IN > 64 || OUT < 1 || OUT > 64 || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
+    if (IN < 1 || IN > kLinWide || OUT < 1 || OUT > kLinWide || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
     if (act < TN_ACT_NONE || act > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
     if (n == 0) return TN_OK;
     if (!x || !y) return TN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
+    if (IN > 64 || OUT > 64) {
+        const size_t smem = (size_t)TILE * (IN | 1) * sizeof(float);
+        if (!tn_ensure_dynamic_lds<linear_fwd_wide_kernel>(smem)) return TN_ERR_LAUNCH;
+        const int vec = (ldy % 4 == 0) && (OUT % 4 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+        hipLaunchKernelGGL(linear_fwd_wide_kernel, dim3(grid_for((n + TILE - 1) / TILE, 1, 1024)), dim3(kBlock), smem, st, x, ldx,
+                           lin->weight, lin->bias, IN, OUT, act, (long long)n, y, ldy, vec);
+        TN_LAUNCH_CHECK();
+        return TN_OK;
+    }
     const int INP = IN <= 16 ? 16 : IN <= 32 ? 32 : 64;
     const int vec_in = (ldx % 4 == 0) && (ldx >= INP) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     const int vec_out = (ldy % 4 == 0) && (OUT % 4 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
@@ -2260,7 +2318,7 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
                   float *d_bias, void *workspace, size_t workspace_bytes, void *stream) {
     if (!lin || !lin->weight) return TN_ERR_NULL;
     const int IN = lin->in_dim, OUT = lin->out_dim;
-    if (IN < 1 || IN > 64 || OUT < 1 || OUT > 64 || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
+    if (IN < 1 || IN > kLinWide || OUT < 1 || OUT > kLinWide || ldx < IN || ldy < OUT || n < 0) return TN_ERR_SHAPE;
     if (dx && lddx < IN) return TN_ERR_SHAPE;
     if (act < TN_ACT_NONE || act > TN_ACT_SIGMOID) return TN_ERR_UNSUPPORTED;
     if (n == 0) return TN_OK;
@@ -2275,18 +2333,32 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
     float *partials = nullptr;
     if (want_w && workspace && workspace_bytes >= (size_t)blocks * 65 * 64 * sizeof(float))
         partials = reinterpret_cast<float *>(workspace);
+    const bool wide = IN > 64 || OUT > 64;
+    if (wide && want_w && !partials) return TN_ERR_WORKSPACE;
     if (!want_w || partials) {  // matrix-pipe form (needs the workspace for its partial weight gradients)
         auto al16 = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-        const int vec = (ldy % 4 == 0) && (OUT % 4 == 0) && al16(dy) && (act == TN_ACT_NONE || al16(y)) &&
-                        (!want_w || ((ldx % 4 == 0) && (IN % 4 == 0) && al16(x)));
-        const int vec_dx = dx && !accumulate_dx && (lddx % 4 == 0) && (IN % 4 == 0) && al16(dx);
-        hipLaunchKernelGGL(linear_bwd_mfma_kernel, g, b, 0, st, x, ldx, y, dy, ldy, lin->weight, IN, OUT, act, (long long)n, dx,
-                           lddx, accumulate_dx, want_w ? 1 : 0, partials, vec, vec_dx);
-        TN_LAUNCH_CHECK();
-        if (want_w) {
-            hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(65, kRedSplit), dim3(kBlock), 0, st, partials, blocks, 64, IN, OUT,
-                               d_weight, d_bias);
-            TN_LAUNCH_CHECK();
+        // a layer wider than 64 goes through the same kernel one 64 x 64 block of its weight matrix at a time (launches on one
+        // stream: the partial-sum slabs are reused): block (ob, kb) takes the columns 64 ob .. of g = dy . act'(y) to
+        // dx[:, 64 kb ..] (+= behind the first ob), to dW[64 ob .., 64 kb ..] and — once per ob — to db[64 ob ..]
+        for (int ob = 0; ob < OUT; ob += 64) {
+            for (int kb = 0; kb < IN; kb += 64) {
+                const int OUTb = OUT - ob < 64 ? OUT - ob : 64, INb = IN - kb < 64 ? IN - kb : 64;
+                const float *xb = x ? x + kb : nullptr, *yb = y ? y + ob : nullptr, *dyb = dy + ob;
+                float *dxb = dx ? dx + kb : nullptr;
+                const int acc = accumulate_dx || ob > 0;
+                const int vec = (ldy % 4 == 0) && (OUTb % 4 == 0) && al16(dyb) && (act == TN_ACT_NONE || al16(yb)) &&
+                                (!want_w || ((ldx % 4 == 0) && (INb % 4 == 0) && al16(xb)));
+                const int vec_dx = dxb && !acc && (lddx % 4 == 0) && (INb % 4 == 0) && al16(dxb);
+                hipLaunchKernelGGL(linear_bwd_mfma_kernel, g, b, 0, st, xb, ldx, yb, dyb, ldy, lin->weight + (size_t)ob * IN + kb, IN,
+                                   INb, OUTb, act, (long long)n, dxb, lddx, acc, want_w ? 1 : 0, partials, vec, vec_dx);
+                TN_LAUNCH_CHECK();
+                if (want_w) {
+                    hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(65, kRedSplit), dim3(kBlock), 0, st, partials, blocks, 64, INb,
+                                       OUTb, d_weight ? d_weight + (size_t)ob * IN + kb : nullptr, IN,
+                                       (d_bias && kb == 0) ? d_bias + ob : nullptr);
+                    TN_LAUNCH_CHECK();
+                }
+            }
         }
         return TN_OK;
     }
@@ -2302,7 +2374,7 @@ int tn_linear_bwd(const float *x, int32_t ldx, const float *y, const float *dy, 
     TN_LAUNCH_CHECK();
     if (partials) {
         hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(INP + 1, kRedSplit), dim3(kBlock), 0, st, partials, blocks, INP, IN, OUT,
-                           d_weight, d_bias);
+                           d_weight, IN, d_bias);
         TN_LAUNCH_CHECK();
     }
     return TN_OK;

@@ -56,9 +56,9 @@ class ThermalNerfactoTField(nn.Module):
         if (num_layers, num_layers_color, num_layers_transient) != (2, 3, 2):
             raise NotImplementedError("kernels implement mlp_base 2, mlp_head 3, mlp_thermal 2 layers (the defaults)")
         widths = (int(hidden_dim), int(hidden_dim_color), int(hidden_dim_transient))
-        if min(widths) < 1 or max(widths) > 64:
-            raise NotImplementedError("hidden_dim / hidden_dim_color / hidden_dim_transient [REF thermal_nerf_model.py:96-114] up to 64 "
-                                      "(the Linear kernels hold a layer's rows in one 64-wide tile); the defaults are 64")
+        if min(widths) < 1 or max(widths) > 256:
+            raise NotImplementedError("hidden_dim / hidden_dim_color / hidden_dim_transient [REF thermal_nerf_model.py:96-114] up to 256 "
+                                      "(tn_linear_fwd / tn_linear_bwd's limit); the defaults are 64")
         # the fused kernels (MFMA chains, one launch per pass) are laid out for the reference's 64-wide layers; any other width runs
         # the SAME arithmetic stage by stage — hash encode, one tn_linear_fwd / tn_linear_bwd per layer — in eval and in training
         self.staged = widths != (64, 64, 64)
