@@ -1017,8 +1017,11 @@ class _StepCall:
         a.trunc_exp_min = float(getattr(cfg, "trunc_exp_clamp_min", -15.0))
         # scratch of the backward: one slab (addresses only)
         first = -1
-        if getattr(cfg, "bucketed_table_scatter", True):
+        bucketed = getattr(cfg, "bucketed_table_scatter", True)
+        if bucketed is True:
             first = lib.tn_hash_encode_bwd_sorted_first_level(fld.grid, N)
+        elif bucketed is not False and bucketed is not None:
+            first = int(bucketed)  # (tests, tools/train_bench.py --first-sorted-level: bucketed from that level on)
         need_sorted = lib.tn_hash_encode_bwd_sorted_workspace_bytes(fld.grid, N, first) if first >= 0 else 0
         sizes = [("g_rgb_s", N * 3 if g_rgb is not None else 0), ("g_th_s", N if g_th is not None else 0), ("g_density", N), ("g_enc", N * 32),
                  ("g_pos", N * 3 if ray_grads else 0), ("g_cin", R * 64 if (sh_grads and g_rgb is not None) else 0),

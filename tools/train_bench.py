@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--no-reg-overlap", action="store_true", help="config.overlap_regularisers = False")
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
+    ap.add_argument("--first-sorted-level", type=int, default=-1, help="config.bucketed_table_scatter = this level (records from it on, "
+                    "atomics below) instead of the library's choice")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
     ap.add_argument("--ray-batch", default="patch", choices=["patch", "random"],
                     help="patch: the sqrt(rays)^2 image of one orbit view (rounds 1-3); random: pixels drawn uniformly over all 8 "
@@ -56,7 +58,7 @@ def main():
 
     _H.SIDE_STREAM_PRIORITY = a.side_priority
     cfg = ThermalNerfModelConfig(num_nerf_samples_per_ray=a.samples, camera_optimizer_mode=a.camera_opt,
-                                 bucketed_table_scatter=not a.atomic_scatter, tape_free_training=not a.taped,
+                                 bucketed_table_scatter=(a.first_sorted_level if a.first_sorted_level >= 0 else not a.atomic_scatter), tape_free_training=not a.taped,
                                  fused_backward_split=not a.one_launch, spread_coarse_scatter=not a.no_spread,
                                  overlap_table_scatter=not a.no_overlap, overlap_regularisers=(False if a.no_reg_overlap else "auto"),
                                  store_base_output=not a.no_store_base, backward_bf16_pieces=not a.f32_backward,
