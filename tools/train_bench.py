@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--atomic-scatter", action="store_true", help="config.bucketed_table_scatter = False (global atomics on every level)")
     ap.add_argument("--first-sorted-level", type=int, default=-1, help="config.bucketed_table_scatter = this level (records from it on, "
                     "atomics below) instead of the library's choice")
+    ap.add_argument("--sort-rays", action="store_true", help="order the batch's rays by (camera, Morton code of the direction)")
     ap.add_argument("--camera-opt", default="SO3xR3", choices=["off", "SO3xR3"], help="reference default: SO3xR3")
     ap.add_argument("--ray-batch", default="patch", choices=["patch", "random"],
                     help="patch: the sqrt(rays)^2 image of one orbit view (rounds 1-3); random: pixels drawn uniformly over all 8 "
@@ -88,6 +89,21 @@ def main():
         o, d, cam = (t.to(dev) for t in synthetic.random_pixel_rays(a.rays))
         R = o.shape[0]
     batch = {"image": torch.rand(R, 3, generator=g).to(dev), "thermal": torch.rand(R, 1, generator=g).to(dev)}
+    if a.sort_rays:
+        # the same batch with its rays ordered by (camera, Morton code of the direction): neighbours in the launch are neighbours in
+        # the image (the order of a batch's rays carries no meaning: every loss is a mean over them)
+        q = ((d * 0.5 + 0.5).clamp(0, 1) * 1023).long()
+
+        def spread(x):
+            x = (x | (x << 16)) & 0x30000FF
+            x = (x | (x << 8)) & 0x300F00F
+            x = (x | (x << 4)) & 0x30C30C3
+            return (x | (x << 2)) & 0x9249249
+
+        key = (cam.view(-1).long() << 30) | spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        order = torch.argsort(key)
+        o, d, cam = o[order].contiguous(), d[order].contiguous(), cam[order].contiguous()
+        batch = {k: v[order].contiguous() for k, v in batch.items()}
 
     phase = [0.0] * 5
 
