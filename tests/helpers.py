@@ -106,11 +106,12 @@ def proposal_updates(steps: int):
     return flags
 
 
-def config1_oracle_run(prob, steps=None, log=None, threads: int = 1, batch_order=None):
+def config1_oracle_run(prob, steps=None, log=None, threads: int = 1, batch_order=None, dtype=torch.float32):
     """Adam (lr 1e-2, eps 1e-15 [REF config_thermal_nerf.py:32-45], no decay over this horizon) over torch autograd on the CPU
     oracle.  Returns (loss per step, final state dict).  ``threads`` / ``batch_order`` (a permutation of the batch positions):
     the SAME optimisation in another floating-point summation order — what separates two valid fp32 runs of the reference path
-    (tools/make_config1_golden.py records several; the HIP run is held inside their envelope)."""
+    (tools/make_config1_golden.py records several; the HIP run is held inside their envelope).  ``dtype=torch.float64``: the same
+    optimisation in double precision — the yardstick that says which way an fp32 run leans while the trajectories still agree."""
     from oracle import training as T
 
     sd, ocfg = prob["sd"], prob["ocfg"]
@@ -118,12 +119,18 @@ def config1_oracle_run(prob, steps=None, log=None, threads: int = 1, batch_order
     # ONE thread + deterministic algorithms: two runs on one host are bit-identical (the intra-op pool's reduction order moved the
     # late loss windows by 5x and made the CPU test a coin toss); as fast as 8 threads on these op sizes (74 s / 1000 steps)
     threads_before, det = torch.get_num_threads(), torch.are_deterministic_algorithms_enabled()
+    dtype_before = torch.get_default_dtype()
     torch.set_num_threads(threads)
     torch.use_deterministic_algorithms(True)
+    torch.set_default_dtype(dtype)  # (the oracle creates temporaries in the default dtype)
+
+    def cast(t):
+        return t.to(dtype) if t.is_floating_point() else t
+
     try:  # (an exception must not leave deterministic mode / a one-thread pool on for the rest of the pytest process)
-        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+        leaves = {k: cast(v).clone().requires_grad_(True) for k, v in sd.items()
                   if v.is_floating_point() and not k.endswith((".aabb", ".scalings")) and not k.startswith("camera_optimizer")}
-        frozen = {k: v for k, v in sd.items() if k not in leaves}
+        frozen = {k: cast(v) for k, v in sd.items() if k not in leaves}
         opt = torch.optim.Adam(list(leaves.values()), lr=1e-2, eps=1e-15)
         upd = proposal_updates(steps)
         losses = []
@@ -131,9 +138,9 @@ def config1_oracle_run(prob, steps=None, log=None, threads: int = 1, batch_order
             ix = prob["idx"][i]
             if batch_order is not None:  # the same batch, its rays in another order: every batch reduction sums in another order
                 ix = ix[batch_order]
-            jitter = [j if batch_order is None else j[batch_order] for j in prob["jitter"][i]]
-            batch = {"image": prob["image"][ix], "thermal": prob["thermal"][ix]}
-            out = H.get_outputs({**frozen, **leaves}, prob["o"][ix], prob["d"][ix], prob["cam"][ix], ocfg, training=True,
+            jitter = [cast(j if batch_order is None else j[batch_order]) for j in prob["jitter"][i]]
+            batch = {"image": cast(prob["image"][ix]), "thermal": cast(prob["thermal"][ix])}
+            out = H.get_outputs({**frozen, **leaves}, cast(prob["o"][ix]), cast(prob["d"][ix]), prob["cam"][ix], ocfg, training=True,
                                 jitter=jitter, anneal=T.proposal_anneal(i), proposal_requires_grad=upd[i])
             loss = sum(T.get_loss_dict(out, batch, T.get_metrics_dict(out, batch, True), True).values())
             opt.zero_grad(set_to_none=True)
@@ -145,6 +152,7 @@ def config1_oracle_run(prob, steps=None, log=None, threads: int = 1, batch_order
     finally:
         torch.set_num_threads(threads_before)
         torch.use_deterministic_algorithms(det)
+        torch.set_default_dtype(dtype_before)
     return losses, {**frozen, **{k: v.detach() for k, v in leaves.items()}}
 
 

@@ -30,13 +30,18 @@ def test_config1_one_thousand_cpu_iterations_fit_the_scene(golden_dir):
 
     gold = np.load(os.path.join(golden_dir, "config1_oracle.npz"))
     assert np.abs(loss[:20] - gold["losses"][:20]).max() <= 2e-3 * np.abs(gold["losses"][:20]).max()
-    # round 6: the fixture's SET of valid fp32 runs (thread counts 1 / 2 / 4 / 8, a permuted batch order) — entry 0 is this very run,
-    # and the set's own spread over the descent is what the GPU test's envelope rests on
-    assert [str(x) for x in gold["run_labels"]][0] == "threads1" and gold["losses_set"].shape == (5, 1000)
+    # round 6: the fixture's SET of valid fp32 runs (thread counts 1 / 2 / 4 / 8, five orders of the batches' rays) — entry 0 is this
+    # very run, and the set's own spread over the descent is what the GPU test's envelopes rest on; `losses_fp64` is the same
+    # optimisation in float64: it shares the first steps with every fp32 run and sits at the set's upper edge in windows 2-3
+    assert [str(x) for x in gold["run_labels"]][0] == "threads1" and gold["losses_set"].shape == (9, 1000)
     assert np.array_equal(gold["losses_set"][0], gold["losses"])
-    ws = gold["losses_set"].reshape(5, 10, 100).mean(axis=2)
+    ws = gold["losses_set"].reshape(9, 10, 100).mean(axis=2)
     spread = ws.max(axis=0) / ws.min(axis=0)
     assert (spread[:3] < 1.15).all() and (spread[3:6] > 1.15).all() and (spread[3:6] < 1.6).all(), spread
+    l64 = gold["losses_fp64"]
+    assert l64.shape == (1000,) and np.abs(l64[:20] - gold["losses"][:20]).max() <= 2e-3 * np.abs(l64[:20]).max()
+    w64 = l64.reshape(10, 100).mean(axis=1)
+    assert (np.abs(ws[:, :3] - w64[:3]) <= 0.08 * w64[:3]).all(), (ws[:, :3], w64[:3])
     gw = gold["losses"].reshape(10, 100).mean(axis=1)
     assert (np.abs(windows[:6] - gw[:6]) <= 0.5 * gw[:6]).all(), (windows, gw)
     assert (gw[6:] < gw[1]).all()

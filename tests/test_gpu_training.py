@@ -1063,11 +1063,22 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     """BASELINE config 1 / SURVEY §8f row 2 "loss-curve parity over 1 k its on the analytic scene": the 1000 Adam steps of the
     CPU reference path (torch autograd over the oracle; tests/test_config1_cpu.py runs them live, tools/make_config1_golden.py
     recorded them in tests/golden/config1_oracle.npz — the GPU box's shared host cores can be 40x slower under load) and the
-    same 1000 steps on the HIP path: same batches, jitter draws, anneal and proposal-update schedule.  Trajectories of a
-    1000-step Adam run separate chaotically at the fp32 rounding level (two CPU runs do), so the claim is: step for step over
-    the first 20 steps (2e-3 relative), the 100-step means of the HIP loss curve inside the envelope x 1.25 of FIVE recorded CPU runs
-    (thread counts 1 / 2 / 4 / 8 and a permuted batch order) over the descent (600 steps), both staying converged after it, and the same final quality on held-out pixels (1.5 dB, 0.02 of the normalised
-    thermal range, both improving on the initial thermal MAE by 2.5x)."""
+    same 1000 steps on the HIP path: same batches, jitter draws, anneal and proposal-update schedule.
+
+    A 1000-step Adam run at eps = 1e-15 on 64-ray batches is a chaotic system: two valid fp32 runs of the CPU path agree step for
+    step over the first tens of steps, to 2-9 % in the 100-step means of windows 2-3, and then wander — the fixture's NINE CPU runs
+    (1 / 2 / 4 / 8 intra-op threads, five orders of the batches' rays) spread by 1.4x in windows 4-6 and by up to 5x in the plateau
+    behind them, with bumps at other steps in every run; a float64 run of the same optimisation is recorded beside them.  One HIP
+    run cannot be told from a biased step in that noise, so the test runs the HIP path SEVEN times (1.6 s each) and asks:
+      * every run: step for step over the first 20 steps (2e-3 relative); windows 1-4 inside the CPU set's [min, max] x 1.25; a
+        monotone descent over windows 1-5; windows 5-10 inside the band the CPU set's plateau covers (x 1.5) and below window 2;
+      * the MEDIAN over the seven runs of each window 1-6 inside the CPU set's [min, max] x 1.10 — a systematic bias of the step moves
+        the median, a bump moves one run;
+      * while the trajectories still agree (windows 1-3) the HIP median is no further from the float64 run than the furthest CPU run
+        x 1.5 (measured: fp32 runs of either path descend 0.3-2 % faster than float64 in window 2 — 0.01163 against 0.01136-0.01160
+        CPU and 0.01133-0.01156 HIP);
+      * the same final quality on held-out pixels (1.5 dB, 0.03 of the normalised thermal range, both improving on the initial
+        thermal MAE by 2.5x) and the HIP eval render of the HIP-trained weights against the oracle on those weights."""
     import os
 
     import numpy as np
@@ -1077,57 +1088,60 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
     gold = np.load(os.path.join(golden_dir, "config1_oracle.npz"))
     want, p_cpu, m_cpu = gold["losses"], float(gold["psnr"]), float(gold["mae"])
     assert want.shape == (steps,)
-    gm = copy.deepcopy(prob["model"]).to(DEV)
-    gm.train()
-    params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
-    opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, fused=True)
+    ws = gold["losses_set"].reshape(-1, 10, 100).mean(axis=2)
+    assert ws.shape[0] >= 9
+    lo, hi = ws.min(axis=0), ws.max(axis=0)
+    w64 = gold["losses_fp64"].reshape(10, 100).mean(axis=1)
+    plateau_lo, plateau_hi = ws[:, 4:].min() / 1.5, ws[:, 4:].max() * 1.5
     o, d, cam = prob["o"].to(DEV), prob["d"].to(DEV), prob["cam"].to(DEV)
     img, th, idx = prob["image"].to(DEV), prob["thermal"].to(DEV), prob["idx"].to(DEV)
     jitter = prob["jitter"].squeeze(-1).to(DEV)
     upd = helpers.proposal_updates(steps)
-    got = []
-    for i in range(steps):
-        gm.set_step(i)
-        ix = idx[i]
-        rb = gm.collider(RayBundle(origins=o[ix], directions=d[ix], camera_indices=cam[ix]))
-        out = TR.get_outputs_train(gm, rb, jitter=jitter[i].contiguous())
-        assert (gm.proposal_sampler._steps_since_update == 0) == upd[i], i  # same update steps as the CPU run
-        b = {"image": img[ix], "thermal": th[ix]}
-        loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        got.append(loss.detach())
-    got = torch.stack(got).cpu().numpy()
-    assert np.isfinite(got).all()
-    for i in range(20):
-        assert abs(got[i] - want[i]) <= 2e-3 * abs(want[i]), (i, got[i], want[i])
-    gw, ww = got.reshape(10, 100).mean(axis=1), want.reshape(10, 100).mean(axis=1)
-    # Round 6: the fixture holds FIVE valid fp32 runs of the reference path — 1 / 2 / 4 / 8 intra-op threads and the
-    # batches' rays in another order (tools/make_config1_golden.py).  Their 100-step means spread by 1.00 / 1.01 / 1.08 / 1.39 / 1.24 /
-    # 1.32 (max / min) over windows 1-6 and by up to 2.9x afterwards, and the one-thread run the earlier rounds compared with is the
-    # set's MINIMUM in windows 4-6 (0.00367 / 0.00231 / 0.00183 against 0.0037-0.0051 / 0.0025-0.0029 / 0.0022-0.0024): the fourteen
-    # HIP runs at 0.98 ... 1.51 x that one trajectory (round 5's "one-sided" band) sit inside the CPU set's own spread.  Each HIP window
-    # of the descent is held inside the set's [min, max] x 1.25 — a systematic bias of the step beyond a quarter of the envelope fails.
-    ws = gold["losses_set"].reshape(-1, 10, 100).mean(axis=2)
-    assert ws.shape[0] >= 5
-    lo, hi = ws.min(axis=0), ws.max(axis=0)
-    assert (gw[:6] <= 1.25 * hi[:6]).all() and (gw[:6] >= lo[:6] / 1.25).all(), (gw, lo, hi)
-    # (the descent flattens by window 6: two runs in twenty-six had window 6 at 1.00-1.02 x window 5)
-    assert (np.diff(gw[:5]) < 0).all() and gw[5] < 1.15 * gw[4] and gw[5] < 0.06 * gw[0], gw
-    assert (gw[6:] < gw[1]).all() and (ww[6:] < ww[1]).all(), (gw, ww)
-    # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
+    windows, gm = [], None
+    for run in range(7):
+        gm = copy.deepcopy(prob["model"]).to(DEV)
+        gm.train()
+        params = [p for n, p in gm.named_parameters() if not n.startswith("camera_optimizer")]
+        opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15, fused=True)
+        got = []
+        for i in range(steps):
+            gm.set_step(i)
+            ix = idx[i]
+            rb = gm.collider(RayBundle(origins=o[ix], directions=d[ix], camera_indices=cam[ix]))
+            out = TR.get_outputs_train(gm, rb, jitter=jitter[i].contiguous())
+            assert (gm.proposal_sampler._steps_since_update == 0) == upd[i], i  # same update steps as the CPU run
+            b = {"image": img[ix], "thermal": th[ix]}
+            loss = sum(gm.get_loss_dict(out, b, gm.get_metrics_dict(out, b)).values())
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            got.append(loss.detach())
+        got = torch.stack(got).cpu().numpy()
+        assert np.isfinite(got).all()
+        for i in range(20):
+            assert abs(got[i] - want[i]) <= 2e-3 * abs(want[i]), (run, i, got[i], want[i])
+        gw = got.reshape(10, 100).mean(axis=1)
+        assert (gw[:4] <= 1.25 * hi[:4]).all() and (gw[:4] >= lo[:4] / 1.25).all(), (run, gw, lo, hi)
+        assert (np.diff(gw[:5]) < 0).all(), (run, gw)
+        assert (gw[4:] <= plateau_hi).all() and (gw[4:] >= plateau_lo).all() and (gw[4:] < gw[1]).all(), (run, gw, plateau_lo, plateau_hi)
+        windows.append(gw)
+        if run >= 2:
+            continue
+        # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
+        sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
+        p_hip, m_hip, hit_hip = helpers.held_out_quality(prob, sd_hip)
+        # held-out pixels of a training view (helpers.config1_problem): the CPU runs end at 15.7 ... 16.8 dB, thermal MAE 0.018 ... 0.044
+        # from 12.8 dB / 0.255 / 0.227 (quality_set in the fixture); the late stage of a 64-ray-batch run wanders, hence bands
+        # (twelve HIP runs, tools/config1_spread.py: psnr 15.7 ... 17.0 dB, thermal MAE 0.017 ... 0.054, on the sphere's rays 0.015 ... 0.070)
+        assert p_hip >= p_cpu - 1.5, (p_cpu, p_hip)
+        assert m_hip <= m_cpu + 0.03 and hit_hip <= float(gold["mae_hit"]) + 0.04, (m_cpu, m_hip, hit_hip)
+        assert m_hip < 0.4 * float(gold["mae_initial"]) and hit_hip < 0.4 * float(gold["mae_hit_initial"])
+    med = np.median(np.stack(windows), axis=0)
+    assert (med[:6] <= 1.10 * hi[:6]).all() and (med[:6] >= lo[:6] / 1.10).all(), (med, lo, hi)
+    far = np.abs(ws[:, :3] - w64[:3]).max(axis=0)
+    assert (np.abs(med[:3] - w64[:3]) <= 1.5 * far + 1e-6).all(), (med[:3], w64[:3], far)
+    # and the HIP eval render of the (last) HIP-trained model agrees with the oracle on the same weights (eval after 1000 fused steps)
     sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
-    p_hip, m_hip, hit_hip = helpers.held_out_quality(prob, sd_hip)
-    # held-out pixels of a training view (helpers.config1_problem): the CPU run ends at 16.6 dB, thermal MAE 0.044 (0.047 on the
-    # sphere's rays) from 12.8 dB / 0.255 / 0.227; the late stage of a 64-ray-batch run wanders, hence bands not equalities
-    # (one-sided: the atomics' summation order makes the HIP run non-reproducible, and its wandering late stage has ended at a
-    # thermal MAE of 0.017 as well as 0.045 — better than the recorded CPU run is not a failure)
-    assert p_hip >= p_cpu - 1.5, (p_cpu, p_hip)
-    # (twelve runs, tools/config1_spread.py: psnr 15.7 … 17.0 dB, thermal MAE 0.017 … 0.054, on the sphere's rays 0.015 … 0.070)
-    assert m_hip <= m_cpu + 0.03 and hit_hip <= float(gold["mae_hit"]) + 0.04, (m_cpu, m_hip, hit_hip)
-    assert m_hip < 0.4 * float(gold["mae_initial"]) and hit_hip < 0.4 * float(gold["mae_hit_initial"])
-    # and the HIP eval render of the HIP-trained model agrees with the oracle on the same weights (eval after 1000 fused steps)
     gm.eval()
     h = prob["held_out"]
     with torch.no_grad():
