@@ -1127,7 +1127,9 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
         windows.append(gw)
         if run >= 2:
             continue
-        # final quality on the unseen view, both through the oracle's eval render: the HIP-trained weights go back to the CPU
+        # final quality on the held-out pixels of a training view (helpers.config1_problem says why a held-out VIEW checks nothing at this
+        # size; novel-view quality is config 3's held-out PSNR / MAE in bench.py), both through the oracle's eval render: the HIP-trained weights
+        # go back to the CPU
         sd_hip = {**prob["sd"], **{k: v.detach().cpu() for k, v in gm.state_dict().items() if k in prob["sd"]}}
         p_hip, m_hip, hit_hip = helpers.held_out_quality(prob, sd_hip)
         # held-out pixels of a training view (helpers.config1_problem): the CPU runs end at 15.7 ... 16.8 dB, thermal MAE 0.018 ... 0.044
