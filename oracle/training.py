@@ -16,7 +16,7 @@ Gradients come from torch autograd over these functions; the HIP backward kernel
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch

@@ -16,7 +16,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _hip
-from .rays import Frustums, RaySamples
+from .rays import RaySamples
 from .scene import SceneContraction
 
 

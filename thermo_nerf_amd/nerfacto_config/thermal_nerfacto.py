@@ -7,7 +7,7 @@ Mirror of [REF thermo_nerf/nerfacto_config/thermal_nerfacto.py:13-45] on top of 
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Any, Dict, List, Literal, Optional, Tuple, Type, Union
+from typing import Any, Dict, List, Literal, Tuple, Type, Union
 
 import torch
 from torch import Tensor, nn

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Iterable, List, Optional
+from typing import Iterable, Optional
 
 import torch
 

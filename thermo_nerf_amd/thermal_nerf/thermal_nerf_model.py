@@ -23,7 +23,7 @@ from torch import Tensor, nn
 from .. import _hip
 from ..fields import FieldHeadNames, HashMLPDensityField
 from ..nerfacto_config.thermal_nerfacto import KERNEL_FAMILY, ThermalNerfactoModel, ThermalNerfactoModelConfig
-from ..rays import RayBundle, RaySamples
+from ..rays import RayBundle
 from ..rendered_image_modalities import RenderedImageModality
 from ..renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
 from ..samplers import (ProposalNetworkSampler, UniformSampler, draw_jitter, jitter_levels, linspace_bins, pdf_positions,
