@@ -482,6 +482,24 @@ def test_other_mlp_widths_run_stage_by_stage(kind, widths):
         helpers.build(kind, 48, hidden_dim=512)
 
 
+@pytest.mark.parametrize("R,P,S", [(1, (7, 5), 3), (2, (64, 32), 1), (63, (33, 17), 48), (65, (256, 96), 13), (127, (300, 130), 200),
+                                   (257, (1, 1), 2), (64, (2, 3), 64), (1000, (96, 256), 7), (5, (512, 256), 256)])
+def test_get_outputs_on_odd_shapes(R, P, S):
+    """Ray counts around the wave and tile sizes (1, 63, 65, 257), proposal and field sample counts that are multiples of nothing
+    (one sample per level included; a second proposal level with MORE samples than the first): the eval outputs against the
+    oracle at the usual tolerances — the kernels' tilings must not leak into the results (tools/odd_shapes_probe.py prints the
+    distances: 1e-7 everywhere)."""
+    gm, sd, ocfg = gpu_model("scene", S, num_proposal_samples_per_ray=P)
+    o, d = helpers.rays(40, 40, view=2)
+    o, d = o[:R].contiguous(), d[:R].contiguous()
+    want = H.get_outputs(sd, o, d, None, ocfg)
+    with torch.no_grad():
+        got = gm(bundle(o, d))
+    for k in ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1", "thermal"):
+        assert got[k].shape == want[k].shape, k
+    check_outputs(got, want, f"odd/R{R}/P{P}/S{S}")
+
+
 @pytest.mark.parametrize("kind", ["stress", "scene"])
 @pytest.mark.parametrize("S", [48, 50, 192, 13])
 def test_sample_split_tiles_match_the_oracle_and_the_serial_march(kind, S):

@@ -491,6 +491,33 @@ def test_training_step_with_other_mlp_widths(kind, widths):
     assert checked >= 18
 
 
+@pytest.mark.parametrize("R_hw,P,S", [((1, 1), (7, 5), 3), ((3, 21), (33, 17), 13), ((5, 13), (256, 96), 1), ((13, 5), (2, 3), 70),
+                                      ((1, 2), (130, 300), 200)])
+@pytest.mark.parametrize("pose", [False, True])
+def test_training_step_on_odd_shapes(R_hw, P, S, pose):
+    """The training step on shapes that are multiples of nothing — one ray, 63 and 65 rays, one field sample per ray, a second proposal
+    level larger than the first — with and without camera-pose optimisation, on an update step (the proposal networks take gradient):
+    outputs, losses and every parameter gradient against torch autograd over the oracle."""
+    over = {"camera_optimizer_mode": "SO3xR3"} if pose else {}
+    gm, sd, ocfg, o, d, jit, cam, batch = _train_setup("scene", S, R_hw=R_hw, num_proposal_samples_per_ray=P, **over)
+    out, loss_dict = _gpu_step(gm, o, d, jit, cam, batch)
+    want_out, want_loss, want_grads = T.loss_and_grads(sd, o, d, cam, batch, ocfg, jit)
+    for k in ("rgb", "thermal", "accumulation"):
+        assert (out[k].detach().cpu() - want_out[k].detach()).abs().max().item() <= 2e-5, k
+    for k, v in want_loss.items():
+        assert abs(loss_dict[k].item() - v.item()) <= 2e-5 * abs(v.item()) + 1e-8, (k, loss_dict[k].item(), v.item())
+    named = dict(gm.named_parameters())
+    checked = 0
+    for name, gw in want_grads.items():
+        if gw.numel() == 0 or name.startswith("camera_optimizer") or name.startswith("__") or gw.norm().item() < 1e-10:
+            continue
+        gg = named[name].grad
+        assert gg is not None and gg.shape == gw.shape, name
+        assert rel(gg, gw) <= 2e-3, f"{name}: rel {rel(gg, gw):.2e}"
+        checked += 1
+    assert checked >= 12
+
+
 @pytest.mark.parametrize("variant", ["default", "pose", "pose_sh", "gradient_scaling", "no_thermal_gradients", "deferred"])
 @pytest.mark.parametrize("S", [48, 192])
 def test_step_calls_equal_the_per_call_path(S, variant):
