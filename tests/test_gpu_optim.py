@@ -111,12 +111,12 @@ def test_hip_adam_refuses_host_tensors_and_bad_list_sizes():
         assert torch.allclose(q, torch.full((5,), k - 0.5, device=DEV), atol=1e-6)
 
 
-def _trainer(deferred: bool, impl: str = "hip", steps_seed: int = 0):
+def _trainer(deferred: bool, impl: str = "hip", steps_seed: int = 0, **model_over):
     from thermo_nerf_amd import synthetic
     from thermo_nerf_amd.trainer import RayDataset, Trainer, TrainerConfig
 
     V, res = 6, 48
-    cm, _, _ = helpers.build("init", 48, small=False, num_images=V, camera_optimizer_mode="SO3xR3")
+    cm, _, _ = helpers.build("init", 48, small=False, num_images=V, camera_optimizer_mode="SO3xR3", **model_over)
     cams = synthetic.orbit_cameras(res, res, list(range(V)), num_views=V, elevation_deg=[(-10.0, 20.0, 50.0)[v % 3] for v in range(V)])
     imgs, ths = [], []
     for i in range(V):
@@ -207,3 +207,29 @@ def test_deferred_update_is_joined_by_every_reader():
     path_losses = [float(tr.train_iteration(tr.step)[0])]  # the next training forward joins before its field launch
     torch.cuda.synchronize()
     assert path_losses[0] == path_losses[0]
+
+
+def test_trainer_with_other_mlp_widths_follows_torch_adam():
+    """thermo_nerf_amd.trainer.Trainer on a field with MLP widths other than 64 (field.staged: stage-by-stage forward and backward,
+    layers above 64 wide included; the table scatter joined by the backward — the deferred update belongs to the fused step) with
+    HipAdam against the same 30 iterations with torch.optim.Adam: the same losses while rounding has not separated the two runs,
+    the same descent afterwards."""
+    from thermo_nerf_amd import _hip
+
+    runs = {}
+    for impl in ("hip", "torch"):
+        torch.manual_seed(3)
+        model, tr = _trainer(impl == "hip", impl, hidden_dim=128, hidden_dim_color=96, hidden_dim_transient=32)
+        assert model.field.staged
+        losses = []
+        for _ in range(30):
+            loss, _, _ = tr.train_iteration(tr.step)
+            tr.step += 1
+            losses.append(float(loss))
+        tr.train(0)
+        assert _hip.pending(torch.device(DEV)) is None
+        runs[impl] = losses
+    a, b = runs["hip"], runs["torch"]
+    for k in range(10):
+        assert abs(a[k] - b[k]) <= 1e-3 * abs(b[k]), (k, a[k], b[k])
+    assert abs(a[-1] - b[-1]) <= 0.05 * abs(b[-1]) and a[-1] < 0.3 * a[0], (a, b)
