@@ -672,7 +672,9 @@ typedef struct tn_train_step {
     void *workspace;                     /* tn_render_workspace_bytes(cfg, num_rays)                                    */
     size_t workspace_bytes;
     void *zero_buffer;                   /* optional: cleared (hipMemsetAsync) on `second` at the start of the call — the  */
-    size_t zero_bytes;                   /* backward's gradient arena, off the calling stream (tn_train_step_bwd waits)    */
+    size_t zero_bytes;                   /* backward's gradient arena, off the calling stream (tn_train_step_bwd waits);   */
+                                         /* `second` first waits for everything queued on `stream` (the buffer's memory may */
+                                         /* have been an earlier step's gradients, still read by kernels queued there)      */
     /* regularisers (optional: loss pointers NULL = not launched); losses are += accumulators the caller zeroed         */
     float distortion_mult, interlevel_mult;
     float *distortion_loss_pair, *distortion_grad;   /* [2], [R,S]                                                      */

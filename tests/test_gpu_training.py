@@ -1183,6 +1183,9 @@ def test_config1_one_thousand_iterations_follow_the_cpu_reference_path(golden_di
         for i in range(20):
             assert abs(got[i] - want[i]) <= 2e-3 * abs(want[i]), (run, i, got[i], want[i])
         gw = got.reshape(10, 100).mean(axis=1)
+        # the first 100 steps: every valid run — nine CPU, 400 HIP — has the same mean to 2e-4.  (Before round 6's fix of the gradient
+        # arena's clear, which could overtake an earlier step's optimizer on a small problem, 1 run in 60 sat 2-25 % above it.)
+        assert abs(gw[0] - lo[0]) <= 1e-3 * lo[0], (run, gw[0], lo[0])
         assert (gw[:4] <= 1.25 * hi[:4]).all() and (gw[:4] >= lo[:4] / 1.25).all(), (run, gw, lo, hi)
         assert (np.diff(gw[:5]) < 0).all(), (run, gw)
         assert (gw[4:] <= plateau_hi).all() and (gw[4:] >= plateau_lo).all() and (gw[4:] < gw[1]).all(), (run, gw, plateau_lo, plateau_hi)

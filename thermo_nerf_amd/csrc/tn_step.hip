@@ -37,7 +37,12 @@ extern "C" int tn_train_step_fwd(const tn_train_step *s) {
     if (R <= 0) return R == 0 ? TN_OK : TN_ERR_SHAPE;
     hipStream_t main = (hipStream_t)s->stream, second = (hipStream_t)s->second, third = (hipStream_t)s->third;
     if (s->zero_buffer && s->zero_bytes) {
-        // the backward's gradient arena (75 MB with the table's): cleared beside this forward instead of in front of the backward
+        // the backward's gradient arena (75 MB with the table's): cleared beside this forward instead of in front of the backward.
+        // The buffer is the CALLING stream's allocation: its memory may have served an earlier step's gradients, which kernels
+        // still queued on the calling stream (that step's backward, its optimizer) read — the fill on the second stream must not
+        // overtake them.  (Found by the config-1 run: with no bucketed scatter queued on the second stream — small tables — and
+        // the host two steps ahead of the device, 4 runs in 240 lost part of a step's gradients to this fill.)
+        STEP_TRY(stream_after(second, main));
         if (hipMemsetAsync(s->zero_buffer, 0, s->zero_bytes, second) != hipSuccess) return TN_ERR_LAUNCH;
     }
     STEP_TRY(tn_field_prepare(s->field_raw, const_cast<float *>(s->field->prepared), s->prepared_bytes, main));
