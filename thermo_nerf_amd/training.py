@@ -926,6 +926,9 @@ class _StepCall:
         # the backward's gradient arena: allocated now, cleared by the call on the second stream
         arena = _GradArena(dict(zip(model.named_parameter_lists()[0], params)), dev, extra=R * (64 + 2 * 64 + S) + 1024, zero=False)
         st.zero_buffer, st.zero_bytes = arena.flat.data_ptr(), arena.flat.numel() * 4
+        # (the backward joins the second stream before it touches the arena; a training-mode forward that is never differentiated
+        # drops the arena with the fill possibly still queued: the allocator must know the second stream used the block)
+        arena.flat.record_stream(second)
         slot = (dev, _hip.current_stream())
         _drop_precomputed(slot)
         entry = None
